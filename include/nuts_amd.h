@@ -1,0 +1,258 @@
+/*
+ * nuts_amd.h — C ABI of the MI355X-native many-chain NUTS engine (libnuts_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of pymc-devs/nuts-rs: the per-chain driver seam
+ * `Settings::new_chain -> Chain::{set_position, draw}` (reference src/sampler.rs:53-63,
+ * src/chain.rs:24-42, :137-188), batched over many independent chains.  Everything the reference
+ * does inside `NutsChain::draw` — momentum refresh, the recursive-doubling tree with the fused
+ * leapfrog + logp/grad (src/nuts.rs:108-388, src/dynamics/transformed_hamiltonian.rs:524-736),
+ * the diagonal mass-matrix and dual-averaging adaptation (src/adapt_strategy.rs:121-222,
+ * src/transform/adapt/diagonal.rs, src/stepsize/) — runs inside hand-written HIP kernels for
+ * gfx950; the host only launches and copies results.
+ *
+ * Conventions
+ *   - plain C, no torch types; every struct field is 8 bytes wide (no padding surprises for FFI).
+ *   - per-chain vectors cross the ABI in the reference's own layout: `[chain][dim]` row-major
+ *     (one contiguous `&[f64]` of length dim per chain, reference src/chain.rs:31,34).
+ *   - pointers named `h_*` are host pointers, `d_*` are device (HBM) pointers.
+ *   - every function returns an nm_status; nm_last_error() gives the message for the calling
+ *     thread.  A handle is not thread-safe: one driver thread per engine (same contract as the
+ *     reference's `!Sync` chain, src/chain.rs:44-61).
+ *   - the library has NO CPU fallback: creating an engine without a usable HIP device fails with
+ *     NM_ERR_NO_DEVICE.
+ */
+#ifndef NUTS_AMD_H
+#define NUTS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_ABI_VERSION 1
+
+typedef enum nm_status {
+    NM_OK = 0,
+    NM_ERR_INVALID_ARG = 1,
+    NM_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image not loadable: never falls back to CPU */
+    NM_ERR_HIP = 3,            /* a HIP runtime call failed */
+    NM_ERR_UNSUPPORTED = 4,    /* valid reference setting that this engine does not implement */
+    NM_ERR_BAD_INIT = 5,       /* NutsError::BadInitGrad for >=1 chain (reference src/nuts.rs:21) */
+    NM_ERR_LOGP_FAILURE = 6,   /* NutsError::LogpFailure for >=1 chain (reference src/nuts.rs:15) */
+    NM_ERR_STATE = 7           /* call order violated (e.g. draw before set_positions) */
+} nm_status;
+
+/* Per-chain status codes written by the kernels (reference error taxonomy). */
+#define NM_CHAIN_OK 0
+#define NM_CHAIN_BAD_INIT 1     /* BadInitGrad: non-finite x/g or zero whitened gradient (transformed_hamiltonian.rs:310-324) */
+#define NM_CHAIN_LOGP_FATAL 2   /* unrecoverable logp error / invalid Bernoulli probability */
+
+/* ---------------------------------------------------------------------------------------------
+ * Settings: mirrors `DiagNutsSettings = NutsSettings<EuclideanAdaptOptions<DiagAdaptExpSettings>>`
+ * (reference src/sampler.rs:199-239, defaults :507-531 and :630-634;
+ *  src/adapt_strategy.rs:41-69; src/stepsize/adapt.rs:308-329; src/stepsize/dual_avg.rs:12-31;
+ *  src/transform/adapt/diagonal.rs:92-106).  Field names are the reference's.
+ * Booleans are uint64_t (0/1); Option<f64> is a (has_x, x) pair.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nm_settings {
+    uint64_t num_tune;                       /* 400 */
+    uint64_t num_draws;                      /* 1000 */
+    uint64_t maxdepth;                       /* 10 */
+    uint64_t mindepth;                       /* 0 */
+    double   max_energy_error;               /* 1000.0 */
+    uint64_t check_turning;                  /* 1 */
+    uint64_t extra_doublings;                /* 0 */
+    uint64_t seed;                           /* 0 */
+    uint64_t num_chains;                     /* 6 */
+    uint64_t store_gradient;                 /* 0 */
+    uint64_t store_unconstrained;            /* 0 */
+    uint64_t store_transformed;              /* 0 */
+    uint64_t store_divergences;              /* 0 */
+    uint64_t has_target_integration_time;    /* 0 (None) */
+    double   target_integration_time;
+    /* adapt_options: EuclideanAdaptOptions */
+    double   early_window;                   /* 0.3 */
+    double   step_size_window;               /* 0.15 */
+    uint64_t mass_matrix_switch_freq;        /* 80 */
+    uint64_t early_mass_matrix_switch_freq;  /* 10 */
+    uint64_t mass_matrix_update_freq;        /* 1 */
+    double   mass_matrix_window_growth;      /* 1.5 */
+    /* adapt_options.mass_matrix_options: DiagAdaptExpSettings */
+    uint64_t store_mass_matrix;              /* 0 */
+    uint64_t use_grad_based_estimate;        /* 1 */
+    /* adapt_options.step_size_settings: StepSizeSettings */
+    double   target_accept;                  /* 0.8 */
+    double   initial_step;                   /* 0.1 */
+    uint64_t has_jitter;                     /* 1 (Some) */
+    double   jitter;                         /* 0.1 */
+    uint64_t step_size_method;               /* NM_STEP_DUAL_AVERAGE */
+    double   fixed_step_size;                /* StepSizeAdaptMethod::Fixed(val) */
+    /* adapt_options.step_size_settings.adapt_options.dual_average: DualAverageOptions */
+    double   da_k;                           /* 0.75 */
+    double   da_t0;                          /* 10 */
+    double   da_gamma;                       /* 0.05 */
+    double   da_max_step_size;               /* pi */
+} nm_settings;
+
+#define NM_STEP_DUAL_AVERAGE 0
+#define NM_STEP_ADAM 1      /* reference src/stepsize/adam.rs — NM_ERR_UNSUPPORTED */
+#define NM_STEP_FIXED 2
+
+/* Fill `s` with `DiagNutsSettings::default()` (reference src/sampler.rs:630-634). */
+void nm_settings_default(nm_settings* s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Log-density registry.  The reference takes an arbitrary `CpuLogpFunc::logp(&[f64], &mut [f64])
+ * -> Result<f64, E>` (src/math/cpu_math.rs:885-891).  A host closure cannot be fused into a
+ * device kernel, so densities are device functors selected by `kind` with a parameter blob.
+ * ------------------------------------------------------------------------------------------- */
+#define NM_LOGP_IID_NORMAL 0     /* params[0]=mu.  logp = sum -0.5*(x-mu)^2, g = -(x-mu)
+                                    (reference benches/sample.rs:49-62, src/math/test_logps.rs:49-58) */
+#define NM_LOGP_DIAG_NORMAL 1    /* params[0..dim)=precision diag p_i.  logp = -0.5 sum p_i x_i^2 + norm, g=-p_i x_i
+                                    (the diagonal-P case of the MvNormal fixture, src/transform/mod.rs:98-112) */
+#define NM_LOGP_FUNNEL 2         /* Neal's funnel, dim = 1 + n (defined by this repo) */
+#define NM_LOGP_EIGHT_SCHOOLS 3  /* non-centered 8 schools, dim = 10 (defined by this repo) */
+
+typedef struct nm_logp_spec {
+    uint64_t      kind;
+    uint64_t      dim;
+    uint64_t      n_params;
+    const double* h_params;      /* host pointer, n_params doubles, copied at engine creation */
+} nm_logp_spec;
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-draw, per-chain statistics.  Union of the reference's `Progress` (src/sampler.rs:165-174)
+ * and the scalar fields of `NutsStats` and its flattened parts (src/chain.rs:215-232,
+ * src/stepsize/adapt.rs:274-306, src/dynamics/transformed_hamiltonian.rs:96-112,
+ * src/dynamics/hamiltonian.rs:38-55).  Names are the reference's stat names.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nm_draw_stats {
+    uint64_t draw;                 /* Progress.draw: index of this draw (pre-increment, chain.rs:175) */
+    uint64_t chain;                /* global chain id */
+    uint64_t depth;                /* SampleInfo.depth */
+    uint64_t maxdepth_reached;
+    uint64_t diverging;
+    uint64_t tuning;               /* strategy.is_tuning() after adapt (chain.rs:178) */
+    uint64_t n_steps;              /* Progress.num_steps = leapfrogs of this draw incl. a divergent one */
+    int64_t  index_in_trajectory;  /* of the chosen point */
+    int64_t  transformation_index; /* transform_id of the chosen point */
+    double   step_size;            /* AFTER adapt = step size of the NEXT draw (chain.rs:179) */
+    double   step_size_bar;
+    double   mean_tree_accept;
+    double   mean_tree_accept_sym;
+    double   max_energy_error;
+    double   logp;
+    double   energy;
+    double   energy_error;
+    double   fisher_distance;      /* sum (z+g_z)^2, math.rs:92 */
+    double   divergence_energy_error; /* NaN when not diverging or unknown */
+    uint64_t chain_status;         /* NM_CHAIN_* */
+} nm_draw_stats;
+
+typedef struct nm_engine nm_engine;
+
+/* Engine-side execution knobs (not reference settings). */
+typedef struct nm_engine_config {
+    int64_t  device;               /* HIP device ordinal; -1 = current device */
+    uint64_t chain_id_offset;      /* global id of local chain 0 (multi-GPU sharding: rank*r n_local) */
+    uint64_t dims_per_lane;        /* 0 = auto.  Register tile per lane, one wavefront per chain */
+    uint64_t reserved[5];
+} nm_engine_config;
+void nm_engine_config_default(nm_engine_config* c);
+
+/* Create an engine that owns `n_chains` chains (replaces `settings.new_chain(chain, math, rng)` for
+ * chain = chain_id_offset .. chain_id_offset+n_chains, reference src/sampler.rs:745-772).
+ * Chain RNGs follow the `Sampler` seeding (reference src/sampler.rs:1105-1106, :761):
+ * outer = ChaCha8(seed_from_u64(settings.seed), stream = chain_id+1); chain rng = ChaCha8 keyed by
+ * the first 32 bytes of outer. */
+nm_status nm_engine_create(const nm_settings* settings, const nm_logp_spec* logp,
+                           uint64_t n_chains, const nm_engine_config* cfg, nm_engine** out);
+void      nm_engine_destroy(nm_engine* e);
+
+/* `Chain::set_position` for every chain (reference src/chain.rs:137-149).  h_x0 is [n_chains][dim].
+ * h_chain_status (optional) receives NM_CHAIN_* per chain.  Returns NM_ERR_BAD_INIT /
+ * NM_ERR_LOGP_FAILURE if any chain failed (the other chains are still initialised). */
+nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, uint64_t* h_chain_status);
+
+/* The `init_position` of the reference's CpuMath (src/math/cpu_math.rs:171-199): x0 ~ U(-1,1) drawn
+ * from each chain's OUTER generator right after the 32 seed bytes (Sampler order, src/sampler.rs:1126-1136).
+ * Fills h_x0 [n_chains][dim]; pure host helper. */
+nm_status nm_init_positions_uniform(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains,
+                                    uint64_t dim, double* h_x0);
+
+/* Advance ALL chains by n_draws draws (`Chain::draw` x n_draws per chain, reference src/chain.rs:151-188).
+ * The whole loop runs on the device; this call enqueues the launches and returns after they finish.
+ *   d_positions : device buffer [n_draws][n_chains][dim] or NULL (positions not recorded)
+ *   d_stats     : device buffer [n_draws][n_chains] of nm_draw_stats or NULL
+ * Both may also be fetched afterwards with the nm_engine_read_* helpers. */
+nm_status nm_engine_draw(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats);
+
+/* Same, asynchronous on the engine's stream: returns after enqueueing. */
+nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats);
+nm_status nm_engine_synchronize(nm_engine* e);
+
+/* Convenience: run n_draws and copy results to host buffers ([n_draws][n_chains][dim] / [n_draws][n_chains]). */
+nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats);
+
+/* Current per-chain quantities, host copies ([n_chains][dim] unless noted). */
+nm_status nm_engine_get_positions(nm_engine* e, double* h_x);
+nm_status nm_engine_get_gradients(nm_engine* e, double* h_gx);
+nm_status nm_engine_get_mass_matrix(nm_engine* e, double* h_stds, double* h_mean);   /* sigma, mu */
+nm_status nm_engine_get_step_sizes(nm_engine* e, double* h_step_size /*[n_chains]*/);
+
+/* Totals since creation (for the metric): sum over chains of leapfrog steps, and device time in ms
+ * spent inside the draw kernels (HIP events on the engine's stream). */
+nm_status nm_engine_get_counters(nm_engine* e, uint64_t* total_leapfrogs, uint64_t* total_draws,
+                                 double* kernel_ms, uint64_t* kernel_launches);
+nm_status nm_engine_reset_counters(nm_engine* e);
+
+uint64_t  nm_engine_dim(const nm_engine* e);
+uint64_t  nm_engine_num_chains(const nm_engine* e);
+/* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */
+void*     nm_engine_stream(nm_engine* e);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched `Math` primitives on device vectors ([n][dim] row-major, one row per chain): the
+ * per-vector seam of the reference (src/math/math.rs:15-314), exported for unit-parity tests of the
+ * kernels' building blocks.  All pointers are DEVICE pointers; `stream` is a hipStream_t or NULL.
+ * ------------------------------------------------------------------------------------------- */
+/* One fused leapfrog for n independent chains (reference transformed_hamiltonian.rs:524-615 with
+ * DiagMassMatrix, src/transform/diagonal.rs:196-209).  In: z,v,g_z,sigma,mu [n][dim]; eps[n], logdet[n],
+ * initial_energy[n].  Out: z',v',g_z',x',g_x' [n][dim]; logp'[n], kinetic'[n], energy_error[n]. */
+nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uint64_t dims_per_lane,
+                            const double* d_z, const double* d_v, const double* d_gz,
+                            const double* d_sigma, const double* d_mu,
+                            const double* d_eps, const double* d_logdet, const double* d_initial_energy,
+                            double* d_z_out, double* d_v_out, double* d_gz_out,
+                            double* d_x_out, double* d_gx_out,
+                            double* d_logp_out, double* d_kinetic_out, double* d_energy_error_out,
+                            void* stream);
+
+/* U-turn criterion `is_turning` (reference transformed_hamiltonian.rs:617-638 via scalar_prods3,
+ * src/math/util.rs:221-347) for n pairs: out_t[2*i] = (z_end - z_start).v_start, out_t[2*i+1] = (..).v_end. */
+nm_status nm_turning_batch(uint64_t n, uint64_t dim, uint64_t dims_per_lane,
+                           const double* d_z_start, const double* d_v_start,
+                           const double* d_z_end, const double* d_v_end,
+                           double* d_out_t, void* stream);
+
+/* Scalar special functions used on the device (deterministic restatements):
+ * op 0 exp, 1 ln, 2 ln_1p, 3 logaddexp(a,b), 4 sqrt, 5 a/b.  d_a, d_b, d_out are device arrays [n]. */
+nm_status nm_scalar_math_batch(uint64_t op, uint64_t n, const double* d_a, const double* d_b,
+                               double* d_out, void* stream);
+
+/* Standard-normal stream of a chain generator (reference array_gaussian, src/math/cpu_math.rs:561-577):
+ * fills d_out[n][count] with the first `count` N(0,1) variates of ChaCha8(key=h_keys[i], stream 0). */
+nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const uint8_t* h_keys /*[n][32]*/,
+                                   double* d_out, uint64_t* h_words_consumed /*[n] or NULL*/, void* stream);
+
+/* Chain RNG key derivation (host helper; reference src/sampler.rs:1105-1106, :761). */
+nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]);
+
+const char* nm_last_error(void);
+uint64_t    nm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUTS_AMD_H */

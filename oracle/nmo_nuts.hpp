@@ -1,0 +1,744 @@
+// nmo_nuts.hpp — CPU oracle of one NUTS chain with diagonal mass-matrix + dual-averaging adaptation.
+// TEST INFRASTRUCTURE ONLY (see nmo_math.hpp).  Scalar, deterministic, one chain per object, written
+// to follow the reference op-for-op and in the reference's own (recursive) control structure:
+//
+//   NutsTree / draw            src/nuts.rs:94-388
+//   TransformedHamiltonian     src/dynamics/transformed_hamiltonian.rs:161-262, :310-351, :524-736 (Euclidean)
+//   DiagMassMatrix             src/transform/diagonal.rs:85-265
+//   RunningVariance / Strategy src/transform/adapt/diagonal.rs:17-236
+//   GlobalStrategy             src/adapt_strategy.rs:77-222
+//   stepsize::Strategy         src/stepsize/adapt.rs:52-272
+//   DualAverage / collectors   src/stepsize/dual_avg.rs:34-166
+//   NutsChain                  src/chain.rs:137-188
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "nmo_math.hpp"
+#include "nmo_rng.hpp"
+
+namespace nmo {
+
+typedef std::vector<double> Vec;
+
+// Same field order as nm_settings (include/nuts_amd.h); declared independently on purpose.
+struct Settings {
+    uint64_t num_tune, num_draws, maxdepth, mindepth;
+    double max_energy_error;
+    uint64_t check_turning, extra_doublings, seed, num_chains;
+    uint64_t store_gradient, store_unconstrained, store_transformed, store_divergences;
+    uint64_t has_target_integration_time;
+    double target_integration_time;
+    double early_window, step_size_window;
+    uint64_t mass_matrix_switch_freq, early_mass_matrix_switch_freq, mass_matrix_update_freq;
+    double mass_matrix_window_growth;
+    uint64_t store_mass_matrix, use_grad_based_estimate;
+    double target_accept, initial_step;
+    uint64_t has_jitter;
+    double jitter;
+    uint64_t step_size_method;
+    double fixed_step_size;
+    double da_k, da_t0, da_gamma, da_max_step_size;
+};
+
+struct DrawStats {   // same field order as nm_draw_stats
+    uint64_t draw, chain, depth, maxdepth_reached, diverging, tuning, n_steps;
+    int64_t index_in_trajectory, transformation_index;
+    double step_size, step_size_bar, mean_tree_accept, mean_tree_accept_sym, max_energy_error;
+    double logp, energy, energy_error, fisher_distance, divergence_energy_error;
+    uint64_t chain_status;
+};
+
+enum { LOGP_IID_NORMAL = 0, LOGP_DIAG_NORMAL = 1, LOGP_FUNNEL = 2, LOGP_EIGHT_SCHOOLS = 3, LOGP_HOST_CALLBACK = 100 };
+enum { ST_OK = 0, ST_BAD_INIT = 1, ST_LOGP_FATAL = 2 };
+
+// CpuLogpFunc::logp shape (reference src/math/cpu_math.rs:885-891): 0 ok, 1 recoverable, 2 fatal
+typedef int (*host_logp_fn)(void* ctx, uint64_t dim, const double* x, double* grad, double* logp);
+
+struct Density {
+    int64_t kind = LOGP_IID_NORMAL;
+    size_t dim = 0;
+    Vec params;
+    host_logp_fn cb = nullptr;
+    void* cb_ctx = nullptr;
+
+    int logp(const Ctx& m, const double* x, double* g, double* out) const {
+        const size_t n = dim;
+        switch (kind) {
+        case LOGP_IID_NORMAL: {   // reference benches/sample.rs:49-62
+            const double mu = params[0];
+            Vec t(n);
+            for (size_t i = 0; i < n; ++i) {
+                double diff = x[i] - mu;
+                g[i] = -diff;
+                t[i] = -0.5 * diff * diff;
+            }
+            *out = m.sum_terms(t.data(), n);
+            return 0;
+        }
+        case LOGP_DIAG_NORMAL: {  // diagonal-P case of MvNormal, reference src/transform/mod.rs:98-112
+            Vec t(n), lt(n);
+            for (size_t i = 0; i < n; ++i) {
+                double px = params[i] * x[i];
+                g[i] = -px;
+                t[i] = x[i] * px;
+                lt[i] = m.ln(params[i]);
+            }
+            double quad = -0.5 * m.sum_terms(t.data(), n);
+            double log_det_p = m.sum_terms(lt.data(), n);
+            double norm = -0.5 * ((double)n * m.ln(6.283185307179586) - log_det_p);
+            *out = quad + norm;
+            return 0;
+        }
+        case LOGP_FUNNEL: {       // v~N(0,3^2), x_i|v ~ N(0, e^v), i=1..n-1
+            const double v = x[0];
+            const size_t k = n - 1;
+            Vec t(n);
+            t[0] = 0.0;
+            for (size_t i = 1; i < n; ++i) t[i] = x[i] * x[i];
+            double ss = m.sum_terms(t.data(), n);
+            double ev = m.exp(-v);
+            *out = -v * v / 18.0 - 0.5 * (double)k * v - 0.5 * ev * ss;
+            g[0] = -v / 9.0 - 0.5 * (double)k + 0.5 * ev * ss;
+            for (size_t i = 1; i < n; ++i) g[i] = -ev * x[i];
+            return 0;
+        }
+        case LOGP_EIGHT_SCHOOLS: { // (mu, log tau, theta_tilde[8]); params = y[8], sigma[8]
+            const double mu = x[0], lt = x[1];
+            const double tau = m.exp(lt);
+            Vec t(n);
+            double gmu = 0.0, gtau_lin = 0.0;
+            t[0] = -mu * mu / 50.0;                                    // mu ~ N(0, 5^2)
+            // tau ~ HalfCauchy(5) with log-Jacobian: -ln(1+(tau/5)^2) + lt
+            t[1] = lt - m.ln_1p((tau / 5.0) * (tau / 5.0));
+            for (size_t i = 0; i < 8; ++i) {
+                double th = x[2 + i];
+                double r = (params[i] - (mu + tau * th)) / params[8 + i];
+                t[2 + i] = -0.5 * th * th - 0.5 * r * r;
+                double dr = r / params[8 + i];                          // d(-r^2/2)/d(mu+tau*th)
+                gmu += dr;
+                gtau_lin += dr * th;
+                g[2 + i] = -th + dr * tau;
+            }
+            g[0] = -mu / 25.0 + gmu;
+            g[1] = 1.0 - 2.0 * (tau / 5.0) * (tau / 5.0) / (1.0 + (tau / 5.0) * (tau / 5.0)) + gtau_lin * tau;
+            *out = m.sum_terms(t.data(), n);
+            return 0;
+        }
+        case LOGP_HOST_CALLBACK:
+            return cb(cb_ctx, n, x, g, out);
+        }
+        return 2;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// TransformedPoint (reference transformed_hamiltonian.rs:56-77)
+// ---------------------------------------------------------------------------------------------
+struct Point {
+    Vec x, gx, z, gz, v;
+    int64_t index_in_trajectory = 0;
+    double logp = 0, logdet = 0, kinetic_energy = 0, initial_energy = 0;
+    int64_t transform_id = -1;
+    explicit Point(size_t n) : x(n, 0.0), gx(n, 0.0), z(n, 0.0), gz(n, 0.0), v(n, 0.0) {}
+    double energy() const { return kinetic_energy - (logp + logdet); }          // :349-351
+    double energy_error() const { return energy() - initial_energy; }           // hamiltonian.rs:134-136
+};
+typedef std::shared_ptr<Point> State;
+
+// ---------------------------------------------------------------------------------------------
+// DiagMassMatrix (reference src/transform/diagonal.rs)
+// ---------------------------------------------------------------------------------------------
+struct DiagMassMatrix {
+    Vec mean, inv_stds, stds;
+    double logdet = 0;
+    int64_t id = -1;
+    explicit DiagMassMatrix(size_t n) : mean(n, 0.0), inv_stds(n, 0.0), stds(n, 0.0) {}
+
+    // update_diag_draw_grad :107-131 with array_update_var_inv_std_draw_grad cpu_math.rs:671-708
+    void update_diag_draw_grad(const Ctx& m, const Vec& draw_mean, const Vec& grad_mean, const Vec& draw_var,
+                               const Vec& grad_var, bool has_fill, double fill, double lo, double hi) {
+        const size_t n = mean.size();
+        for (size_t i = 0; i < n; ++i) {
+            double val = std::sqrt(draw_var[i] / grad_var[i]);
+            if (!std::isfinite(val) || val == 0.0) {
+                if (has_fill) { stds[i] = std::sqrt(fill); inv_stds[i] = std::sqrt(1.0 / fill); }
+            } else {
+                val = clampd(val, lo, hi);
+                stds[i] = std::sqrt(val);
+                inv_stds[i] = std::sqrt(1.0 / val);
+            }
+        }
+        Vec var(n);
+        multiply(stds.data(), stds.data(), var.data(), n);
+        multiply(var.data(), grad_mean.data(), mean.data(), n);
+        axpy(draw_mean.data(), mean.data(), 1.0, n);
+        logdet = m.sum_ln(inv_stds.data(), n);
+        id += 1;
+    }
+    // update_diag_draw :85-105 with array_update_var_inv_std_draw cpu_math.rs:633-669
+    void update_diag_draw(const Ctx& m, const Vec& draw_mean, const Vec& draw_var, double scale, bool has_fill,
+                          double fill, double lo, double hi) {
+        const size_t n = mean.size();
+        for (size_t i = 0; i < n; ++i) {
+            double dv = draw_var[i] * scale;
+            if (!std::isfinite(dv) || dv == 0.0) {
+                if (has_fill) { stds[i] = std::sqrt(fill); inv_stds[i] = std::sqrt(1.0 / fill); }
+            } else {
+                double val = clampd(dv, lo, hi);
+                stds[i] = std::sqrt(val);
+                inv_stds[i] = std::sqrt(1.0 / val);
+            }
+        }
+        mean = draw_mean;
+        logdet = m.sum_ln(inv_stds.data(), n);
+        id += 1;
+    }
+    // update_diag_grad :133-154 with array_update_var_inv_std_grad cpu_math.rs:710-738
+    void update_diag_grad(const Ctx& m, const Vec& position, const Vec& gradient, double fill, double lo, double hi) {
+        const size_t n = mean.size();
+        for (size_t i = 0; i < n; ++i) {
+            double val = 1.0 / clampd(std::fabs(gradient[i]), lo, hi);
+            if (!std::isfinite(val)) val = fill;
+            stds[i] = std::sqrt(val);
+            inv_stds[i] = std::sqrt(1.0 / val);
+        }
+        Vec var(n);
+        multiply(stds.data(), stds.data(), var.data(), n);
+        multiply(var.data(), gradient.data(), mean.data(), n);
+        axpy(position.data(), mean.data(), 1.0, n);
+        logdet = m.sum_ln(inv_stds.data(), n);
+        id += 1;
+    }
+    // :233-265
+    void compute_transformed_position(const Vec& x, Vec& z) const {
+        axpy_out(mean.data(), x.data(), -1.0, z.data(), x.size());
+        for (size_t i = 0; i < x.size(); ++i) z[i] = inv_stds[i] * z[i];
+    }
+    void compute_untransformed_position(const Vec& z, Vec& x) const {
+        multiply(z.data(), stds.data(), x.data(), z.size());
+        axpy(mean.data(), x.data(), 1.0, z.size());
+    }
+    void compute_transformed_gradient(const Vec& gx, Vec& gz) const {
+        multiply(gx.data(), stds.data(), gz.data(), gx.size());
+    }
+};
+
+// AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:83-166)
+struct AcceptanceRateCollector {
+    double initial_energy = 0;
+    double mean_sum = 0, mean_sym_sum = 0;
+    uint64_t mean_count = 0, mean_sym_count = 0;
+    double max_energy_error = 0;
+    void register_init(double e0) { initial_energy = e0; mean_sum = mean_sym_sum = 0; mean_count = mean_sym_count = 0; max_energy_error = 0; }
+    void register_leapfrog(const Ctx& m, const Point* end, bool divergent) {
+        if (divergent) {
+            mean_count++; mean_sym_count++;            // add(0.)
+            mean_sum += 0.; mean_sym_sum += 0.;
+            max_energy_error = -INFINITY;
+        } else {
+            double diff = initial_energy - end->energy();
+            double e = m.exp(std::fmin(diff, 0.));
+            mean_sum += e; mean_count++;
+            mean_sym_sum += 2. * e / (1. + m.exp(diff)); mean_sym_count++;
+            if (std::fabs(diff) > std::fabs(max_energy_error)) max_energy_error = diff;
+        }
+    }
+    double mean() const { return mean_sum / (double)mean_count; }
+    double mean_sym() const { return mean_sym_sum / (double)mean_sym_count; }
+};
+
+// DrawGradCollector (reference src/transform/adapt/diagonal.rs:57-84)
+struct DrawGradCollector {
+    Vec draw, grad;
+    bool is_good = true;
+    explicit DrawGradCollector(size_t n) : draw(n, 0.0), grad(n, 0.0) {}
+    void register_draw(const Point& p, bool diverging) {
+        draw = p.x; grad = p.gx;
+        int64_t idx = p.index_in_trajectory;
+        is_good = diverging ? (std::llabs(idx) > 4) : (idx != 0);
+    }
+};
+
+struct Collector {   // CombinedCollector (reference src/adapt_strategy.rs:286-350)
+    AcceptanceRateCollector acc;
+    DrawGradCollector dg;
+    explicit Collector(size_t n) : dg(n) {}
+};
+
+struct DivergenceInfo { bool present = false; bool has_energy_error = false; double energy_error = 0; };
+enum LeapfrogKind { LF_OK, LF_DIVERGENCE, LF_ERR };
+struct LeapfrogResult { LeapfrogKind kind; State state; DivergenceInfo info; };
+
+// ---------------------------------------------------------------------------------------------
+// TransformedHamiltonian<DiagMassMatrix>, Euclidean kinetic energy
+// ---------------------------------------------------------------------------------------------
+struct Hamiltonian {
+    const Ctx* m;
+    const Density* dens;
+    DiagMassMatrix mm;
+    double step_size = 0;
+    size_t n;
+    Hamiltonian(const Ctx* m_, const Density* d) : m(m_), dens(d), mm(d->dim), n(d->dim) {}
+
+    // leapfrog :524-615.  `acc` may be null (no collector).
+    LeapfrogResult leapfrog(const State& start, int sign, double step_size_factor, double energy_baseline,
+                            double max_energy_error, AcceptanceRateCollector* acc) {
+        State out = std::make_shared<Point>(n);
+        Point& o = *out;
+        const Point& s = *start;
+        o.initial_energy = s.initial_energy;
+        o.transform_id = s.transform_id;
+        const double epsilon = (double)sign * step_size * step_size_factor;
+        axpy_out(s.gz.data(), s.v.data(), epsilon / 2., o.v.data(), n);          // first_velocity_halfstep :178-184
+        axpy_out(o.v.data(), s.z.data(), epsilon, o.z.data(), n);                // position_step :220-225
+        // init_from_transformed_position (diagonal.rs:196-209)
+        mm.compute_untransformed_position(o.z, o.x);
+        double logp = 0;
+        int st = dens->logp(*m, o.x.data(), o.gx.data(), &logp);
+        if (st != 0) {
+            if (st == 2) return {LF_ERR, nullptr, {}};
+            DivergenceInfo info; info.present = true;
+            if (acc) acc->register_leapfrog(*m, out.get(), true);
+            return {LF_DIVERGENCE, nullptr, info};
+        }
+        mm.compute_transformed_gradient(o.gx, o.gz);
+        o.logp = logp;
+        o.logdet = mm.logdet;
+        o.transform_id = mm.id;
+        axpy(o.gz.data(), o.v.data(), epsilon / 2., n);                          // second_velocity_halfstep :245-247
+        o.kinetic_energy = 0.5 * m->vector_dot(o.v.data(), o.v.data(), n);      // :260-262
+        o.index_in_trajectory = s.index_in_trajectory + sign;
+        const double energy_error = o.energy() - energy_baseline;
+        if ((energy_error > max_energy_error) | !std::isfinite(energy_error)) {  // :590-610
+            DivergenceInfo info; info.present = true; info.has_energy_error = true; info.energy_error = energy_error;
+            if (acc) acc->register_leapfrog(*m, out.get(), true);
+            return {LF_DIVERGENCE, nullptr, info};
+        }
+        if (acc) acc->register_leapfrog(*m, out.get(), false);
+        return {LF_OK, out, {}};
+    }
+
+    // is_turning :617-638
+    bool is_turning(const State& s1, const State& s2) const {
+        const Point *start, *end;
+        if (s1->index_in_trajectory < s2->index_in_trajectory) { start = s1.get(); end = s2.get(); }
+        else { start = s2.get(); end = s1.get(); }
+        Vec zeros(n, 0.0);
+        double t1, t2;
+        m->scalar_prods3(end->z.data(), start->z.data(), zeros.data(), start->v.data(), end->v.data(), n, &t1, &t2);
+        return (t1 < 0.) | (t2 < 0.);
+    }
+
+    // check_all :310-324
+    bool check_all(const Point& p) const {
+        return all_finite(p.z.data(), n) && all_finite_and_nonzero(p.gz.data(), n) &&
+               all_finite(p.gx.data(), n) && all_finite(p.x.data(), n);
+    }
+
+    // init_state :640-661.  returns status
+    int init_state(const double* init, State* out) {
+        State st = std::make_shared<Point>(n);
+        Point& p = *st;
+        for (size_t i = 0; i < n; ++i) p.x[i] = init[i];
+        double logp = 0;
+        int rc = dens->logp(*m, p.x.data(), p.gx.data(), &logp);               // init_from_untransformed_position
+        if (rc != 0) return ST_LOGP_FATAL;
+        mm.compute_transformed_position(p.x, p.z);
+        mm.compute_transformed_gradient(p.gx, p.gz);
+        p.logp = logp; p.logdet = mm.logdet; p.transform_id = mm.id;
+        if (!check_all(p)) return ST_BAD_INIT;
+        *out = st;
+        return ST_OK;
+    }
+
+    // init_state_untransformed :663-685
+    int init_state_untransformed(const double* init, State* out) {
+        State st = std::make_shared<Point>(n);
+        Point& p = *st;
+        for (size_t i = 0; i < n; ++i) p.x[i] = init[i];
+        double logp = 0;
+        int rc = dens->logp(*m, p.x.data(), p.gx.data(), &logp);
+        if (rc != 0) return ST_LOGP_FATAL;
+        p.logp = logp;
+        p.transform_id = -1;
+        if (!(all_finite(p.gx.data(), n) && all_finite(p.x.data(), n))) return ST_BAD_INIT;
+        *out = st;
+        return ST_OK;
+    }
+
+    // initialize_trajectory :687-736 (resample_velocity = true)
+    void initialize_trajectory(Point& p, ChaCha8Rng& rng) {
+        for (size_t i = 0; i < n; ++i) p.v[i] = 1.0 * standard_normal(rng, *m);  // array_gaussian cpu_math.rs:561-577
+        if (mm.id != p.transform_id) {                                           // inv_transform_normalize diagonal.rs:210-221
+            mm.compute_transformed_position(p.x, p.z);
+            mm.compute_transformed_gradient(p.gx, p.gz);
+            p.logdet = mm.logdet;
+            p.transform_id = mm.id;
+        }
+        p.kinetic_energy = 0.5 * m->vector_dot(p.v.data(), p.v.data(), n);
+        p.index_in_trajectory = 0;
+        p.initial_energy = p.energy();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// NUTS tree (reference src/nuts.rs)
+// ---------------------------------------------------------------------------------------------
+struct NutsOptions { uint64_t maxdepth, mindepth; bool check_turning; uint64_t extra_doublings; double max_energy_error;
+                     bool has_target_time; double target_time; };
+struct SampleInfo { uint64_t depth = 0; DivergenceInfo divergence; bool reached_maxdepth = false; };
+
+struct NutsTree {
+    State left, right, draw;
+    double log_size = 0;
+    uint64_t depth = 0;
+    bool is_main = true;
+};
+enum ExtendKind { EX_OK, EX_ERR, EX_TURNING, EX_DIVERGING };
+struct ExtendResult { ExtendKind kind; NutsTree tree; DivergenceInfo info; };
+
+struct TreeBuilder {
+    const Ctx* m; Hamiltonian* h; ChaCha8Rng* rng; Collector* coll; int* fatal;
+
+    // single_step :209-245
+    LeapfrogResult single_step(const NutsTree& self, int dir, const NutsOptions& opt) {
+        const State& start = dir > 0 ? self.right : self.left;
+        return h->leapfrog(start, dir, 1.0, start->initial_energy, opt.max_energy_error, &coll->acc);
+    }
+    // merge_into :172-207
+    void merge_into(NutsTree& self, NutsTree& other, int dir) {
+        if (dir > 0) self.right = other.right; else self.left = other.left;
+        double log_size = m->logaddexp(self.log_size, other.log_size);
+        double self_log_size = self.is_main ? self.log_size : log_size;
+        bool take = other.log_size >= self_log_size;
+        if (!take) {
+            int b = random_bool(*rng, m->exp(other.log_size - self_log_size));
+            if (b < 0) { *fatal = 1; b = 0; }
+            take = b == 1;
+        }
+        if (take) self.draw = other.draw;
+        self.depth += 1;
+        self.log_size = log_size;
+    }
+    // extend :108-170
+    ExtendResult extend(NutsTree self, int dir, const NutsOptions& opt) {
+        LeapfrogResult lf = single_step(self, dir, opt);
+        if (lf.kind == LF_DIVERGENCE) return {EX_DIVERGING, self, lf.info};
+        if (lf.kind == LF_ERR) return {EX_ERR, self, {}};
+        NutsTree other;
+        other.left = other.right = other.draw = lf.state;
+        other.depth = 0; other.log_size = -lf.state->energy_error(); other.is_main = false;
+        while (other.depth < self.depth) {
+            ExtendResult r = extend(other, dir, opt);
+            if (r.kind == EX_OK) other = r.tree;
+            else if (r.kind == EX_TURNING) return {EX_TURNING, self, {}};
+            else if (r.kind == EX_DIVERGING) return {EX_DIVERGING, self, r.info};
+            else return {EX_ERR, self, {}};
+        }
+        const State& first = dir > 0 ? self.left : other.left;
+        const State& last = dir > 0 ? other.right : self.right;
+        bool turning = false;
+        if (opt.check_turning) {
+            turning = h->is_turning(first, last);
+            if (self.depth > 0) {
+                if (!turning) turning = h->is_turning(self.right, other.right);
+                if (!turning) turning = h->is_turning(self.left, other.left);
+            }
+        }
+        merge_into(self, other, dir);
+        return {turning ? EX_TURNING : EX_OK, self, {}};
+    }
+};
+
+// nuts::draw :281-388.  returns 0 ok, 2 fatal
+static inline int nuts_draw(const Ctx& m, State& init, ChaCha8Rng& rng, Hamiltonian& h, const NutsOptions& options,
+                            Collector& coll, State* out_state, SampleInfo* out_info) {
+    h.initialize_trajectory(*init, rng);
+    coll.acc.register_init(init->energy());
+    NutsTree tree;
+    tree.left = tree.right = tree.draw = init;
+    uint64_t mindepth = options.mindepth, maxdepth = options.maxdepth;
+    if (options.has_target_time) {                                                 // :300-320
+        uint64_t max_steps = (uint64_t)std::ceil(options.target_time / h.step_size);
+        uint64_t md = (uint64_t)std::floor(std::log2((double)max_steps));
+        mindepth = md > options.mindepth ? md : options.mindepth;
+        uint64_t xd = (uint64_t)std::ceil(std::log2((double)max_steps));
+        xd = xd > mindepth ? xd : mindepth;
+        maxdepth = xd < options.maxdepth ? xd : options.maxdepth;
+    }
+    int fatal = 0;
+    TreeBuilder tb{&m, &h, &rng, &coll, &fatal};
+    SampleInfo info;
+    auto finish = [&](const NutsTree& t, bool maxd, const DivergenceInfo& div) {
+        info.depth = t.depth; info.divergence = div; info.reached_maxdepth = maxd;
+        coll.dg.register_draw(*t.draw, div.present);
+        *out_state = t.draw; *out_info = info;
+        return fatal ? 2 : 0;
+    };
+    if (h.n == 0) return finish(tree, false, {});
+    NutsOptions no_check = options; no_check.check_turning = false;
+    while (tree.depth < maxdepth) {
+        int dir = rng.random_bool_std() ? 1 : -1;                                  // :334, hamiltonian.rs:111-118
+        const NutsOptions& cur = tree.depth < mindepth ? no_check : options;
+        ExtendResult r = tb.extend(tree, dir, cur);
+        if (fatal) return 2;
+        if (r.kind == EX_OK) { tree = r.tree; continue; }
+        if (r.kind == EX_TURNING) {
+            tree = r.tree;
+            for (uint64_t e = 0; e < options.extra_doublings; ++e) {
+                ExtendResult r2 = tb.extend(tree, dir, no_check);
+                if (fatal) return 2;
+                if (r2.kind == EX_OK || r2.kind == EX_TURNING) tree = r2.tree;
+                else if (r2.kind == EX_DIVERGING) return finish(r2.tree, false, r2.info);
+                else return 2;
+            }
+            return finish(tree, false, {});
+        }
+        if (r.kind == EX_DIVERGING) return finish(r.tree, false, r.info);
+        return 2;
+    }
+    return finish(tree, true, {});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adaptation
+// ---------------------------------------------------------------------------------------------
+struct RunningVariance {   // reference src/transform/adapt/diagonal.rs:17-55
+    Vec mean, variance;
+    uint64_t count = 0;
+    explicit RunningVariance(size_t n) : mean(n, 0.0), variance(n, 0.0) {}
+    void add_sample(const Vec& value) {
+        count += 1;
+        if (count == 1) { mean = value; return; }
+        const double diff_scale = 1.0 / (double)count;
+        for (size_t i = 0; i < mean.size(); ++i) {       // array_update_variance cpu_math.rs:605-631
+            double diff = value[i] - mean[i];
+            mean[i] += diff * diff_scale;
+            variance[i] += diff * diff;
+        }
+    }
+};
+
+struct DualAverage {       // reference src/stepsize/dual_avg.rs:34-81
+    double log_step, log_step_adapted, hbar, mu;
+    uint64_t count;
+    double k, t0, gamma, max_step_size;
+    void reset(const Ctx& m, double initial_step) {
+        log_step = m.ln(initial_step); log_step_adapted = m.ln(initial_step);
+        hbar = 0.; mu = m.ln(10. * initial_step); count = 1;
+    }
+    void advance(const Ctx& m, double accept_stat, double target) {
+        double w = 1. / ((double)count + t0);
+        hbar = (1. - w) * hbar + w * (target - accept_stat);
+        log_step = mu - hbar * std::sqrt((double)count) / gamma;
+        log_step = std::fmin(log_step, m.ln(max_step_size));
+        double mk = m.powf((double)count, -k);
+        log_step_adapted = mk * log_step + (1. - mk) * log_step_adapted;
+        count += 1;
+    }
+};
+
+struct Chain {
+    Ctx m;
+    Density dens;
+    Settings s;
+    uint64_t chain_id;
+    ChaCha8Rng rng;
+    Hamiltonian h;
+    Collector coll;
+    NutsOptions options;
+    State state;
+    SampleInfo last_info;
+    uint64_t draw_count = 0;
+    // GlobalStrategy (adapt_strategy.rs:24-39)
+    uint64_t num_tune, early_end, final_step_size_window, last_update = 0, current_window_size;
+    bool tuning = true, has_initial_mass_matrix = true;
+    // diag Strategy (adapt/diagonal.rs:108-115)
+    RunningVariance var_draw, var_grad, var_draw_bg, var_grad_bg;
+    // stepsize::Strategy (stepsize/adapt.rs:52-65)
+    DualAverage da;
+    double last_mean_tree_accept = 0, last_sym_mean_tree_accept = 0, last_max_energy_error = 0;
+    uint64_t last_n_steps = 0;
+    size_t n;
+
+    Chain(const Settings& s_, const Density& d, const MathCfg& cfg, uint64_t chain, const uint8_t key[32])
+        : m{cfg}, dens(d), s(s_), chain_id(chain), rng(ChaCha8Rng::from_seed(key)), h(&m, &dens), coll(d.dim),
+          var_draw(d.dim), var_grad(d.dim), var_draw_bg(d.dim), var_grad_bg(d.dim), n(d.dim) {
+        h.m = &m; h.dens = &dens;
+        options = {s.maxdepth, s.mindepth, s.check_turning != 0, s.extra_doublings, s.max_energy_error,
+                   s.has_target_integration_time != 0, s.target_integration_time};
+        // GlobalStrategy::new adapt_strategy.rs:77-98
+        num_tune = s.num_tune;
+        double num_tune_f = (double)num_tune;
+        uint64_t step_size_window = (uint64_t)(s.step_size_window * num_tune_f);
+        early_end = (uint64_t)(s.early_window * num_tune_f);
+        final_step_size_window = num_tune >= step_size_window ? num_tune - step_size_window : 0;
+        current_window_size = s.mass_matrix_switch_freq;
+        da.k = s.da_k; da.t0 = s.da_t0; da.gamma = s.da_gamma; da.max_step_size = s.da_max_step_size;
+        da.reset(m, s.initial_step);                                            // stepsize/adapt.rs:69-72
+    }
+    Chain(const Chain&) = delete;
+
+    bool is_fixed() const { return s.step_size_method == 2; }
+
+    // stepsize::Strategy::init  stepsize/adapt.rs:91-199
+    int stepsize_init(const double* position) {
+        if (is_fixed()) { h.step_size = s.fixed_step_size; return ST_OK; }
+        State st;
+        int rc = h.init_state(position, &st);
+        if (rc != ST_OK) return rc;
+        h.initialize_trajectory(*st, rng);
+        AcceptanceRateCollector c;
+        c.register_init(st->energy());
+        h.step_size = s.initial_step;
+        LeapfrogResult r = h.leapfrog(st, +1, 1.0, st->initial_energy, 1000.0, &c);
+        if (r.kind == LF_ERR) return ST_OK;          // `let LeapfrogResult::Ok(_) = .. else { return Ok(()) }`
+        if (r.kind != LF_OK) return ST_OK;
+        double accept_stat = c.mean();
+        int dir = accept_stat > s.target_accept ? +1 : -1;
+        for (int it = 0; it < 100; ++it) {
+            AcceptanceRateCollector c2;
+            c2.register_init(st->energy());
+            LeapfrogResult r2 = h.leapfrog(st, dir, 1.0, st->initial_energy, 1000.0, &c2);
+            if (r2.kind != LF_OK) { h.step_size = s.initial_step; return ST_OK; }
+            double a = c2.mean();
+            if (dir > 0) {
+                if ((a <= s.target_accept) | (h.step_size > 1e5)) { da.reset(m, h.step_size); return ST_OK; }
+                h.step_size *= 2.;
+            } else {
+                if ((a >= s.target_accept) | (h.step_size < 1e-10)) { da.reset(m, h.step_size); return ST_OK; }
+                h.step_size /= 2.;
+            }
+        }
+        h.step_size = s.initial_step;
+        return ST_OK;
+    }
+
+    // update_stepsize stepsize/adapt.rs:235-267
+    void update_stepsize(bool use_best_guess) {
+        double step = is_fixed() ? s.fixed_step_size
+                                 : (use_best_guess ? m.exp(da.log_step_adapted) : m.exp(da.log_step));
+        if (s.has_jitter) {
+            UniformF64 u = UniformF64::make(1.0 - s.jitter, 1.0 + s.jitter);
+            double j = u.sample(rng);
+            h.step_size = step * j;
+        } else h.step_size = step;
+    }
+    void update_estimator(bool late) {
+        if (is_fixed()) return;
+        da.advance(m, late ? last_sym_mean_tree_accept : last_mean_tree_accept, s.target_accept);
+    }
+
+    // NutsChain::set_position chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119
+    int set_position(const double* position) {
+        State st;
+        int rc = h.init_state_untransformed(position, &st);
+        if (rc != ST_OK) return rc;
+        // DiagAdaptStrategy::init adapt/diagonal.rs:209-231
+        var_draw.add_sample(st->x); var_draw_bg.add_sample(st->x);
+        var_grad.add_sample(st->gx); var_grad_bg.add_sample(st->gx);
+        h.mm.update_diag_grad(m, st->x, st->gx, 1.0, 1e-20, 1e20);
+        rc = stepsize_init(position);
+        if (rc != ST_OK) return rc;
+        rc = h.init_state(position, &state);
+        return rc;
+    }
+
+    // GlobalStrategy::adapt adapt_strategy.rs:121-222
+    int adapt(uint64_t draw, const State& st) {
+        last_mean_tree_accept = coll.acc.mean();                                  // step_size.update, adapt.rs:201-209
+        last_sym_mean_tree_accept = coll.acc.mean_sym();
+        last_n_steps = coll.acc.mean_count;
+        last_max_energy_error = coll.acc.max_energy_error;
+        if (draw >= num_tune) { update_stepsize(true); tuning = false; return ST_OK; }
+        if (draw < final_step_size_window) {
+            bool is_early = draw < early_end;
+            if (!is_early && draw == early_end)
+                current_window_size = std::max(current_window_size, var_draw_bg.count);
+            uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : current_window_size;
+            if (coll.dg.is_good) {                                                // update_estimators adapt/diagonal.rs:134-141
+                var_draw.add_sample(coll.dg.draw); var_grad.add_sample(coll.dg.grad);
+                var_draw_bg.add_sample(coll.dg.draw); var_grad_bg.add_sample(coll.dg.grad);
+            }
+            bool could_switch = var_draw_bg.count >= switch_freq;
+            uint64_t next_window_size;
+            if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
+            else {
+                uint64_t grown = (uint64_t)std::round((double)current_window_size * s.mass_matrix_window_growth);
+                next_window_size = std::max(current_window_size + 1, grown);
+            }
+            bool is_late = next_window_size + draw > final_step_size_window;
+            bool force_update = false;
+            if (could_switch && !is_late) {
+                var_draw = var_draw_bg; var_draw_bg = RunningVariance(n);         // switch adapt/diagonal.rs:143-148
+                var_grad = var_grad_bg; var_grad_bg = RunningVariance(n);
+                force_update = true;
+                if (!is_early) current_window_size = next_window_size;
+            }
+            bool did_change = false;
+            if (force_update | (draw - last_update >= s.mass_matrix_update_freq)) {
+                if (var_draw.count >= 3) {                                        // Strategy::adapt adapt/diagonal.rs:161-196
+                    if (s.use_grad_based_estimate)
+                        h.mm.update_diag_draw_grad(m, var_draw.mean, var_grad.mean, var_draw.variance, var_grad.variance,
+                                                   false, 0.0, 1e-20, 1e20);
+                    else
+                        h.mm.update_diag_draw(m, var_draw.mean, var_draw.variance, 1.0 / (double)var_draw.count,
+                                              false, 0.0, 1e-20, 1e20);
+                    did_change = true;
+                }
+            }
+            if (did_change) last_update = draw;
+            update_estimator(is_late);
+            if (did_change & has_initial_mass_matrix) {
+                has_initial_mass_matrix = false;
+                Vec position = st->x;
+                return stepsize_init(position.data());
+            }
+            update_stepsize(false);
+            return ST_OK;
+        }
+        update_estimator(true);
+        update_stepsize(draw == num_tune - 1);
+        return ST_OK;
+    }
+
+    // NutsChain::draw chain.rs:151-188 (+ the stats of expanded_draw :190-232)
+    int draw(double* out_position, DrawStats* stats) {
+        State chosen;
+        SampleInfo info;
+        int rc = nuts_draw(m, state, rng, h, options, coll, &chosen, &info);
+        if (rc != 0) { if (stats) stats->chain_status = ST_LOGP_FATAL; return ST_LOGP_FATAL; }
+        if (out_position) for (size_t i = 0; i < n; ++i) out_position[i] = chosen->x[i];
+        int arc = adapt(draw_count, chosen);
+        if (stats) {
+            DrawStats& o = *stats;
+            o.draw = draw_count; o.chain = chain_id; o.depth = info.depth; o.maxdepth_reached = info.reached_maxdepth;
+            o.diverging = info.divergence.present; o.tuning = tuning; o.n_steps = last_n_steps;
+            o.index_in_trajectory = chosen->index_in_trajectory; o.transformation_index = chosen->transform_id;
+            o.step_size = h.step_size;
+            o.step_size_bar = is_fixed() ? s.fixed_step_size : m.exp(da.log_step_adapted);
+            o.mean_tree_accept = last_mean_tree_accept; o.mean_tree_accept_sym = last_sym_mean_tree_accept;
+            o.max_energy_error = last_max_energy_error;
+            o.logp = chosen->logp; o.energy = chosen->energy(); o.energy_error = chosen->energy_error();
+            o.fisher_distance = m.sq_norm_sum(chosen->z.data(), chosen->gz.data(), n);
+            o.divergence_energy_error = (info.divergence.present && info.divergence.has_energy_error)
+                                            ? info.divergence.energy_error : NAN;
+            o.chain_status = arc;
+        }
+        draw_count += 1;
+        state = chosen;
+        last_info = info;
+        return arc;
+    }
+};
+
+// Chain RNG key: Sampler seeding (reference src/sampler.rs:1105-1106 then :761)
+static inline ChaCha8Rng outer_rng(uint64_t seed, uint64_t chain_id) {
+    ChaCha8Rng r = ChaCha8Rng::seed_from_u64(seed);
+    r.set_stream(chain_id + 1);
+    return r;
+}
+
+}  // namespace nmo

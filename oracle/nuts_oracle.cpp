@@ -1,0 +1,240 @@
+// nuts_oracle.cpp — C API (ctypes) of the CPU oracle.  TEST INFRASTRUCTURE ONLY (see nmo_math.hpp).
+// Built by oracle/Makefile into oracle/libnuts_oracle.so with -O2 -ffp-contract=off (the reference's Rust
+// never contracts a*b+c; FMAs appear only where src/math/util.rs writes mul_add).
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include "nmo_nuts.hpp"
+
+using namespace nmo;
+
+extern "C" {
+
+// DiagNutsSettings::default() (reference src/sampler.rs:507-531, :630-634; src/adapt_strategy.rs:56-69;
+// src/stepsize/adapt.rs:320-329; src/stepsize/dual_avg.rs:22-31; src/transform/adapt/diagonal.rs:99-106)
+void nmo_settings_default(Settings* s) {
+    std::memset(s, 0, sizeof(*s));
+    s->num_tune = 400; s->num_draws = 1000; s->maxdepth = 10; s->mindepth = 0;
+    s->max_energy_error = 1000.0; s->check_turning = 1; s->extra_doublings = 0; s->seed = 0; s->num_chains = 6;
+    s->early_window = 0.3; s->step_size_window = 0.15;
+    s->mass_matrix_switch_freq = 80; s->early_mass_matrix_switch_freq = 10; s->mass_matrix_update_freq = 1;
+    s->mass_matrix_window_growth = 1.5;
+    s->store_mass_matrix = 0; s->use_grad_based_estimate = 1;
+    s->target_accept = 0.8; s->initial_step = 0.1; s->has_jitter = 1; s->jitter = 0.1;
+    s->step_size_method = 0; s->fixed_step_size = 0.0;
+    s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
+}
+uint64_t nmo_settings_size(void) { return sizeof(Settings); }
+uint64_t nmo_draw_stats_size(void) { return sizeof(DrawStats); }
+
+static Density make_density(int64_t kind, uint64_t dim, const double* params, uint64_t n_params) {
+    Density d;
+    d.kind = kind; d.dim = dim;
+    d.params.assign(params, params + n_params);
+    return d;
+}
+
+void nmo_chain_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]) {
+    ChaCha8Rng outer = outer_rng(seed, chain_id);
+    ChaCha8Rng c = outer.fork();
+    for (int i = 0; i < 8; ++i) {
+        key_out[4 * i] = (uint8_t)c.key[i]; key_out[4 * i + 1] = (uint8_t)(c.key[i] >> 8);
+        key_out[4 * i + 2] = (uint8_t)(c.key[i] >> 16); key_out[4 * i + 3] = (uint8_t)(c.key[i] >> 24);
+    }
+}
+
+// CpuMath::init_position (reference src/math/cpu_math.rs:171-199) from the outer generator, after the fork
+void nmo_init_position_uniform(uint64_t seed, uint64_t chain_id, uint64_t dim, double* out) {
+    ChaCha8Rng outer = outer_rng(seed, chain_id);
+    (void)outer.fork();
+    for (uint64_t i = 0; i < dim; ++i) out[i] = outer.random_f64() * 2.0 - 1.0;
+}
+
+void* nmo_chain_create(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+                       const MathCfg* cfg, uint64_t chain_id, const uint8_t key[32]) {
+    Density d = make_density(kind, dim, params, n_params);
+    return new Chain(*s, d, *cfg, chain_id, key);
+}
+void* nmo_chain_create_callback(const Settings* s, uint64_t dim, host_logp_fn cb, void* cb_ctx, const MathCfg* cfg,
+                                uint64_t chain_id, const uint8_t key[32]) {
+    Density d;
+    d.kind = LOGP_HOST_CALLBACK; d.dim = dim; d.cb = cb; d.cb_ctx = cb_ctx;
+    return new Chain(*s, d, *cfg, chain_id, key);
+}
+void nmo_chain_destroy(void* c) { delete (Chain*)c; }
+int nmo_chain_set_position(void* c, const double* x0) { return ((Chain*)c)->set_position(x0); }
+int nmo_chain_draw(void* c, double* out_position, DrawStats* stats) { return ((Chain*)c)->draw(out_position, stats); }
+void nmo_chain_get_state(void* cv, double* x, double* gx, double* stds, double* mean, double* step_size,
+                         uint64_t* rng_pos) {
+    Chain* c = (Chain*)cv;
+    for (size_t i = 0; i < c->n; ++i) {
+        if (x) x[i] = c->state->x[i];
+        if (gx) gx[i] = c->state->gx[i];
+        if (stds) stds[i] = c->h.mm.stds[i];
+        if (mean) mean[i] = c->h.mm.mean[i];
+    }
+    if (step_size) *step_size = c->h.step_size;
+    if (rng_pos) *rng_pos = c->rng.pos;
+}
+
+// Many chains, one task per chain over `n_threads` host threads (the structure of the reference's Rayon
+// Sampler, src/sampler.rs:1116, :1287-1326).  x0 [n][dim]; out_positions [n_draws][n][dim] or NULL;
+// out_stats [n_draws][n] or NULL.  Returns the number of chains that failed.
+int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+            const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_draws,
+            double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads) {
+    std::atomic<uint64_t> next{0}, steps{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        for (;;) {
+            uint64_t c = next.fetch_add(1);
+            if (c >= n_chains) break;
+            uint8_t key[32];
+            nmo_chain_key(s->seed, chain_offset + c, key);
+            Density d = make_density(kind, dim, params, n_params);
+            Chain ch(*s, d, *cfg, chain_offset + c, key);
+            if (ch.set_position(x0 + c * dim) != ST_OK) { failed++; continue; }
+            uint64_t local = 0;
+            for (uint64_t t = 0; t < n_draws; ++t) {
+                DrawStats st;
+                int rc = ch.draw(out_positions ? out_positions + (t * n_chains + c) * dim : nullptr, &st);
+                if (out_stats) out_stats[t * n_chains + c] = st;
+                local += st.n_steps;
+                if (rc != ST_OK) { failed++; break; }
+            }
+            steps += local;
+        }
+    };
+    if (n_threads <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (uint64_t i = 0; i < n_threads; ++i) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
+    if (out_total_steps) *out_total_steps = steps.load();
+    return failed.load();
+}
+
+// ----- primitives for known-answer tests ------------------------------------------------------
+double nmo_logaddexp(const MathCfg* cfg, double a, double b) { Ctx m{*cfg}; return m.logaddexp(a, b); }
+double nmo_scalar_fn(const MathCfg* cfg, int64_t op, double a, double b) {
+    Ctx m{*cfg};
+    switch (op) {
+    case 0: return m.exp(a);
+    case 1: return m.ln(a);
+    case 2: return m.ln_1p(a);
+    case 3: return m.logaddexp(a, b);
+    case 4: return std::sqrt(a);
+    case 5: return a / b;
+    case 6: return m.powf(a, b);
+    }
+    return NAN;
+}
+void nmo_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int64_t rounds, uint32_t out[16]) {
+    chacha_block(key, counter, stream, (int)rounds, out);
+}
+void nmo_rng_words(const uint8_t key[32], uint64_t stream, uint64_t count, uint32_t* out) {
+    ChaCha8Rng r = ChaCha8Rng::from_seed(key);
+    r.set_stream(stream);
+    for (uint64_t i = 0; i < count; ++i) out[i] = r.next_u32();
+}
+void nmo_seed_from_u64(uint64_t state, uint8_t key_out[32]) {
+    ChaCha8Rng r = ChaCha8Rng::seed_from_u64(state);
+    for (int i = 0; i < 8; ++i) for (int b = 0; b < 4; ++b) key_out[4 * i + b] = (uint8_t)(r.key[i] >> (8 * b));
+}
+uint64_t nmo_standard_normal_stream(const MathCfg* cfg, const uint8_t key[32], uint64_t count, double* out) {
+    Ctx m{*cfg};
+    ChaCha8Rng r = ChaCha8Rng::from_seed(key);
+    for (uint64_t i = 0; i < count; ++i) out[i] = standard_normal(r, m);
+    return r.pos;
+}
+void nmo_zig_tables(double* x257, double* f257) {
+    const ZigguratTables& t = zig_tables();
+    for (int i = 0; i < 257; ++i) { x257[i] = t.x[i]; f257[i] = t.f[i]; }
+}
+// distribution samplers on a fresh ChaCha8(key): kind 0 bool, 1 f64, 2 random_bool(p=a), 3 Uniform(a,b)
+void nmo_rng_samples(const uint8_t key[32], int64_t kind, double a, double b, uint64_t count, double* out) {
+    ChaCha8Rng r = ChaCha8Rng::from_seed(key);
+    UniformF64 u = UniformF64::make(kind == 3 ? a : 0.0, kind == 3 ? b : 1.0);
+    for (uint64_t i = 0; i < count; ++i) {
+        switch (kind) {
+        case 0: out[i] = r.random_bool_std() ? 1.0 : 0.0; break;
+        case 1: out[i] = r.random_f64(); break;
+        case 2: out[i] = (double)random_bool(r, a); break;
+        case 3: out[i] = u.sample(r); break;
+        }
+    }
+}
+double nmo_vector_dot(const MathCfg* cfg, const double* a, const double* b, uint64_t n) { Ctx m{*cfg}; return m.vector_dot(a, b, n); }
+void nmo_scalar_prods3(const MathCfg* cfg, const double* p1, const double* n1, const double* p2, const double* x,
+                       const double* y, uint64_t n, double* out2) {
+    Ctx m{*cfg};
+    m.scalar_prods3(p1, n1, p2, x, y, n, &out2[0], &out2[1]);
+}
+void nmo_axpy(const double* x, double* y, double a, uint64_t n) { axpy(x, y, a, n); }
+void nmo_axpy_out(const double* x, const double* y, double a, double* out, uint64_t n) { axpy_out(x, y, a, out, n); }
+void nmo_multiply(const double* x, const double* y, double* out, uint64_t n) { multiply(x, y, out, n); }
+int nmo_logp(const MathCfg* cfg, int64_t kind, uint64_t dim, const double* params, uint64_t n_params, const double* x,
+             double* g, double* out) {
+    Ctx m{*cfg};
+    Density d = make_density(kind, dim, params, n_params);
+    return d.logp(m, x, g, out);
+}
+
+// DiagMassMatrix known-answer harness (reference tests src/transform/mod.rs:175-377):
+// update_diag_draw_grad(draw_mean, grad_mean, draw_var, grad_var, None, (1e-20,1e20)), then
+// init_from_untransformed_position(x) and init_from_transformed_position(z) round trip.
+int nmo_diag_kat(const MathCfg* cfg, uint64_t dim, const double* precision_diag, const double* draw_mean,
+                 const double* grad_mean, const double* draw_var, const double* grad_var, const double* x,
+                 double* z, double* gz, double* logp, double* logdet, double* x_rt, double* logp_rt, double* logdet_rt,
+                 double* stds, double* inv_stds, double* mean) {
+    Ctx m{*cfg};
+    Density d = make_density(LOGP_DIAG_NORMAL, dim, precision_diag, dim);
+    DiagMassMatrix mm(dim);
+    Vec dm(draw_mean, draw_mean + dim), gm(grad_mean, grad_mean + dim), dv(draw_var, draw_var + dim), gv(grad_var, grad_var + dim);
+    mm.update_diag_draw_grad(m, dm, gm, dv, gv, false, 0.0, 1e-20, 1e20);
+    Vec X(x, x + dim), GX(dim), Z(dim), GZ(dim);
+    int rc = d.logp(m, X.data(), GX.data(), logp);
+    mm.compute_transformed_position(X, Z);
+    mm.compute_transformed_gradient(GX, GZ);
+    *logdet = mm.logdet;
+    Vec XR(dim), GXR(dim), GZR(dim);
+    mm.compute_untransformed_position(Z, XR);
+    rc |= d.logp(m, XR.data(), GXR.data(), logp_rt);
+    mm.compute_transformed_gradient(GXR, GZR);
+    *logdet_rt = mm.logdet;
+    for (uint64_t i = 0; i < dim; ++i) {
+        z[i] = Z[i]; gz[i] = GZ[i]; x_rt[i] = XR[i];
+        stds[i] = mm.stds[i]; inv_stds[i] = mm.inv_stds[i]; mean[i] = mm.mean[i];
+    }
+    return rc;
+}
+
+// One leapfrog from (z, v, gz) with mass matrix (sigma, mu, logdet): the unit that nm_leapfrog_batch fuses.
+int nmo_leapfrog(const MathCfg* cfg, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+                 const double* z, const double* v, const double* gz, const double* sigma, const double* mu,
+                 double eps, double logdet, double initial_energy,
+                 double* z_out, double* v_out, double* gz_out, double* x_out, double* gx_out,
+                 double* logp_out, double* kinetic_out, double* energy_error_out) {
+    Ctx m{*cfg};
+    Density d = make_density(kind, dim, params, n_params);
+    Hamiltonian h(&m, &d);
+    for (uint64_t i = 0; i < dim; ++i) { h.mm.stds[i] = sigma[i]; h.mm.mean[i] = mu[i]; h.mm.inv_stds[i] = 1.0 / sigma[i]; }
+    h.mm.logdet = logdet; h.mm.id = 0;
+    h.step_size = std::fabs(eps);
+    State s = std::make_shared<Point>(dim);
+    for (uint64_t i = 0; i < dim; ++i) { s->z[i] = z[i]; s->v[i] = v[i]; s->gz[i] = gz[i]; }
+    s->initial_energy = initial_energy; s->transform_id = 0;
+    LeapfrogResult r = h.leapfrog(s, eps < 0 ? -1 : +1, 1.0, initial_energy, INFINITY, nullptr);
+    if (r.kind != LF_OK) return 1;
+    for (uint64_t i = 0; i < dim; ++i) {
+        z_out[i] = r.state->z[i]; v_out[i] = r.state->v[i]; gz_out[i] = r.state->gz[i];
+        x_out[i] = r.state->x[i]; gx_out[i] = r.state->gx[i];
+    }
+    *logp_out = r.state->logp; *kinetic_out = r.state->kinetic_energy;
+    *energy_error_out = r.state->energy() - initial_energy;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""ctypes binding of the CPU oracle (oracle/libnuts_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (nuts_rs_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnuts_oracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("nuts_oracle.cpp", "nmo_math.hpp", "nmo_rng.hpp", "nmo_nuts.hpp")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class Settings(C.Structure):
+    """Field-for-field the reference's DiagNutsSettings (see include/nuts_amd.h nm_settings)."""
+    _fields_ = [
+        ("num_tune", C.c_uint64), ("num_draws", C.c_uint64), ("maxdepth", C.c_uint64), ("mindepth", C.c_uint64),
+        ("max_energy_error", C.c_double), ("check_turning", C.c_uint64), ("extra_doublings", C.c_uint64),
+        ("seed", C.c_uint64), ("num_chains", C.c_uint64),
+        ("store_gradient", C.c_uint64), ("store_unconstrained", C.c_uint64), ("store_transformed", C.c_uint64),
+        ("store_divergences", C.c_uint64),
+        ("has_target_integration_time", C.c_uint64), ("target_integration_time", C.c_double),
+        ("early_window", C.c_double), ("step_size_window", C.c_double),
+        ("mass_matrix_switch_freq", C.c_uint64), ("early_mass_matrix_switch_freq", C.c_uint64),
+        ("mass_matrix_update_freq", C.c_uint64), ("mass_matrix_window_growth", C.c_double),
+        ("store_mass_matrix", C.c_uint64), ("use_grad_based_estimate", C.c_uint64),
+        ("target_accept", C.c_double), ("initial_step", C.c_double), ("has_jitter", C.c_uint64),
+        ("jitter", C.c_double), ("step_size_method", C.c_uint64), ("fixed_step_size", C.c_double),
+        ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
+    ]
+
+
+STATS_DTYPE = np.dtype([
+    ("draw", "<u8"), ("chain", "<u8"), ("depth", "<u8"), ("maxdepth_reached", "<u8"), ("diverging", "<u8"),
+    ("tuning", "<u8"), ("n_steps", "<u8"), ("index_in_trajectory", "<i8"), ("transformation_index", "<i8"),
+    ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
+    ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
+    ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
+])
+
+
+class MathCfg(C.Structure):
+    _fields_ = [("detmath", C.c_int64), ("reduce_mode", C.c_int64), ("simd_lanes", C.c_int64),
+                ("gpu_threads", C.c_int64)]
+
+
+REDUCE_REF_SIMD, REDUCE_GPU = 0, 1
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS = 0, 1, 2, 3
+
+
+def ref_cfg(simd_lanes=4):
+    """What the reference does on this box: libm transcendentals, pulp-style 4-accumulator SIMD sums."""
+    return MathCfg(0, REDUCE_REF_SIMD, simd_lanes, 64)
+
+
+def gpu_cfg(gpu_threads=64):
+    """The arithmetic contract of the HIP engine: restated exp/ln, fixed lane-tiled reduction order."""
+    return MathCfg(1, REDUCE_GPU, 4, gpu_threads)
+
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    L.nmo_settings_default.argtypes = [C.POINTER(Settings)]
+    L.nmo_settings_size.restype = C.c_uint64
+    L.nmo_draw_stats_size.restype = C.c_uint64
+    L.nmo_chain_key.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    L.nmo_init_position_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _dp]
+    L.nmo_chain_create.restype = C.c_void_p
+    L.nmo_chain_create.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64,
+                                   C.POINTER(MathCfg), C.c_uint64, C.c_void_p]
+    L.nmo_chain_destroy.argtypes = [C.c_void_p]
+    L.nmo_chain_set_position.argtypes = [C.c_void_p, _dp]
+    L.nmo_chain_set_position.restype = C.c_int
+    L.nmo_chain_draw.argtypes = [C.c_void_p, _dp, C.c_void_p]
+    L.nmo_chain_draw.restype = C.c_int
+    L.nmo_chain_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.nmo_run.restype = C.c_int
+    L.nmo_run.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
+                          C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_void_p, C.c_void_p,
+                          C.POINTER(C.c_uint64), C.c_uint64]
+    L.nmo_logaddexp.restype = C.c_double
+    L.nmo_logaddexp.argtypes = [C.POINTER(MathCfg), C.c_double, C.c_double]
+    L.nmo_scalar_fn.restype = C.c_double
+    L.nmo_scalar_fn.argtypes = [C.POINTER(MathCfg), C.c_int64, C.c_double, C.c_double]
+    L.nmo_chacha_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
+    L.nmo_rng_words.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.nmo_seed_from_u64.argtypes = [C.c_uint64, C.c_void_p]
+    L.nmo_standard_normal_stream.restype = C.c_uint64
+    L.nmo_standard_normal_stream.argtypes = [C.POINTER(MathCfg), C.c_void_p, C.c_uint64, _dp]
+    L.nmo_zig_tables.argtypes = [_dp, _dp]
+    L.nmo_rng_samples.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_uint64, _dp]
+    L.nmo_vector_dot.restype = C.c_double
+    L.nmo_vector_dot.argtypes = [C.POINTER(MathCfg), _dp, _dp, C.c_uint64]
+    L.nmo_scalar_prods3.argtypes = [C.POINTER(MathCfg), _dp, _dp, _dp, _dp, _dp, C.c_uint64, _dp]
+    L.nmo_axpy.argtypes = [_dp, _dp, C.c_double, C.c_uint64]
+    L.nmo_axpy_out.argtypes = [_dp, _dp, C.c_double, _dp, C.c_uint64]
+    L.nmo_multiply.argtypes = [_dp, _dp, _dp, C.c_uint64]
+    L.nmo_logp.restype = C.c_int
+    L.nmo_logp.argtypes = [C.POINTER(MathCfg), C.c_int64, C.c_uint64, _dp, C.c_uint64, _dp, _dp,
+                           C.POINTER(C.c_double)]
+    L.nmo_diag_kat.restype = C.c_int
+    L.nmo_diag_kat.argtypes = [C.POINTER(MathCfg), C.c_uint64] + [_dp] * 6 + [_dp, _dp, C.POINTER(C.c_double),
+                               C.POINTER(C.c_double), _dp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               _dp, _dp, _dp]
+    L.nmo_leapfrog.restype = C.c_int
+    L.nmo_leapfrog.argtypes = [C.POINTER(MathCfg), C.c_int64, C.c_uint64, _dp, C.c_uint64, _dp, _dp, _dp, _dp, _dp,
+                               C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp,
+                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    assert L.nmo_settings_size() == C.sizeof(Settings)
+    assert L.nmo_draw_stats_size() == STATS_DTYPE.itemsize
+    _lib = L
+    return L
+
+
+def default_settings(**overrides):
+    s = Settings()
+    lib().nmo_settings_default(C.byref(s))
+    for k, v in overrides.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def chain_key(seed, chain_id):
+    key = (C.c_uint8 * 32)()
+    lib().nmo_chain_key(seed, chain_id, key)
+    return bytes(key)
+
+
+def init_positions_uniform(seed, chain_offset, n_chains, dim):
+    out = np.empty((n_chains, dim))
+    row = np.empty(dim)
+    for c in range(n_chains):
+        lib().nmo_init_position_uniform(seed, chain_offset + c, dim, row)
+        out[c] = row
+    return out
+
+
+class Chain:
+    """One oracle chain: the reference's `settings.new_chain(chain, math, rng)` + set_position + draw."""
+
+    def __init__(self, settings, kind, dim, params, cfg, chain_id=0, key=None):
+        self.dim = dim
+        self.cfg = cfg
+        self.params = np.ascontiguousarray(params, dtype=np.float64)
+        if key is None:
+            key = chain_key(settings.seed, chain_id)
+        self._key = (C.c_uint8 * 32).from_buffer_copy(key)
+        self._h = lib().nmo_chain_create(C.byref(settings), kind, dim, self.params, len(self.params),
+                                         C.byref(cfg), chain_id, self._key)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nmo_chain_destroy(self._h)
+            self._h = None
+
+    def set_position(self, x0):
+        return lib().nmo_chain_set_position(self._h, np.ascontiguousarray(x0, dtype=np.float64))
+
+    def draw(self):
+        pos = np.empty(self.dim)
+        st = np.zeros(1, dtype=STATS_DTYPE)
+        rc = lib().nmo_chain_draw(self._h, pos, st.ctypes.data)
+        return pos, st[0], rc
+
+    def state(self):
+        x, gx, sd, mu = (np.empty(self.dim) for _ in range(4))
+        eps = C.c_double()
+        pos = C.c_uint64()
+        lib().nmo_chain_get_state(self._h, x.ctypes.data, gx.ctypes.data, sd.ctypes.data, mu.ctypes.data,
+                                  C.byref(eps), C.byref(pos))
+        return dict(x=x, gx=gx, stds=sd, mean=mu, step_size=eps.value, rng_pos=pos.value)
+
+
+def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0, n_threads=1,
+        want_positions=True, want_stats=True):
+    """Many chains on host threads (reference Sampler structure).  Returns positions [draws][chains][dim], stats, steps."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    pos = np.empty((n_draws, n_chains, dim)) if want_positions else None
+    st = np.zeros((n_draws, n_chains), dtype=STATS_DTYPE) if want_stats else None
+    steps = C.c_uint64()
+    failed = lib().nmo_run(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains, chain_offset,
+                           x0, n_draws, pos.ctypes.data if pos is not None else None,
+                           st.ctypes.data if st is not None else None, C.byref(steps), n_threads)
+    return pos, st, steps.value, failed
