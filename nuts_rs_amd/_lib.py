@@ -1,0 +1,128 @@
+"""ctypes loader for libnuts_amd.so — the C ABI of include/nuts_amd.h.
+
+There is no CPU fallback: if the shared library is missing this module raises, and the library itself refuses
+to create an engine without a HIP device (NM_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnuts_amd.so")
+
+NM_OK = 0
+STATUS_NAMES = {0: "NM_OK", 1: "NM_ERR_INVALID_ARG", 2: "NM_ERR_NO_DEVICE", 3: "NM_ERR_HIP", 4: "NM_ERR_UNSUPPORTED",
+                5: "NM_ERR_BAD_INIT", 6: "NM_ERR_LOGP_FAILURE", 7: "NM_ERR_STATE"}
+
+# every symbol include/nuts_amd.h declares
+ABI_SYMBOLS = [
+    "nm_settings_default", "nm_engine_config_default", "nm_engine_create", "nm_engine_destroy",
+    "nm_engine_set_positions", "nm_init_positions_uniform", "nm_engine_draw", "nm_engine_draw_async",
+    "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
+    "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
+    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
+    "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
+]
+
+
+class NmSettings(C.Structure):
+    """nm_settings == the reference's DiagNutsSettings, field for field (src/sampler.rs:199-239)."""
+    _fields_ = [
+        ("num_tune", C.c_uint64), ("num_draws", C.c_uint64), ("maxdepth", C.c_uint64), ("mindepth", C.c_uint64),
+        ("max_energy_error", C.c_double), ("check_turning", C.c_uint64), ("extra_doublings", C.c_uint64),
+        ("seed", C.c_uint64), ("num_chains", C.c_uint64),
+        ("store_gradient", C.c_uint64), ("store_unconstrained", C.c_uint64), ("store_transformed", C.c_uint64),
+        ("store_divergences", C.c_uint64),
+        ("has_target_integration_time", C.c_uint64), ("target_integration_time", C.c_double),
+        ("early_window", C.c_double), ("step_size_window", C.c_double),
+        ("mass_matrix_switch_freq", C.c_uint64), ("early_mass_matrix_switch_freq", C.c_uint64),
+        ("mass_matrix_update_freq", C.c_uint64), ("mass_matrix_window_growth", C.c_double),
+        ("store_mass_matrix", C.c_uint64), ("use_grad_based_estimate", C.c_uint64),
+        ("target_accept", C.c_double), ("initial_step", C.c_double), ("has_jitter", C.c_uint64),
+        ("jitter", C.c_double), ("step_size_method", C.c_uint64), ("fixed_step_size", C.c_double),
+        ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
+    ]
+
+
+class NmLogpSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint64), ("dim", C.c_uint64), ("n_params", C.c_uint64), ("h_params", C.c_void_p)]
+
+
+class NmEngineConfig(C.Structure):
+    _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
+                ("reserved", C.c_uint64 * 5)]
+
+
+STATS_DTYPE = np.dtype([
+    ("draw", "<u8"), ("chain", "<u8"), ("depth", "<u8"), ("maxdepth_reached", "<u8"), ("diverging", "<u8"),
+    ("tuning", "<u8"), ("n_steps", "<u8"), ("index_in_trajectory", "<i8"), ("transformation_index", "<i8"),
+    ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
+    ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
+    ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
+])
+
+_lib = None
+
+
+class NutsAmdError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def load():
+    """Load the shared library (no compute, no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension with `python -m nuts_rs_amd.build` "
+            "(nuts_rs_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, dbl = C.c_void_p, C.c_uint64, C.c_double
+    L.nm_settings_default.argtypes = [C.POINTER(NmSettings)]
+    L.nm_settings_default.restype = None
+    L.nm_engine_config_default.argtypes = [C.POINTER(NmEngineConfig)]
+    L.nm_engine_config_default.restype = None
+    L.nm_engine_create.argtypes = [C.POINTER(NmSettings), C.POINTER(NmLogpSpec), u64, C.POINTER(NmEngineConfig),
+                                   C.POINTER(vp)]
+    L.nm_engine_destroy.argtypes = [vp]
+    L.nm_engine_destroy.restype = None
+    L.nm_engine_set_positions.argtypes = [vp, vp, vp]
+    L.nm_init_positions_uniform.argtypes = [u64, u64, u64, u64, vp]
+    L.nm_engine_draw.argtypes = [vp, u64, vp, vp]
+    L.nm_engine_draw_async.argtypes = [vp, u64, vp, vp]
+    L.nm_engine_synchronize.argtypes = [vp]
+    L.nm_engine_draw_to_host.argtypes = [vp, u64, vp, vp]
+    L.nm_engine_get_positions.argtypes = [vp, vp]
+    L.nm_engine_get_gradients.argtypes = [vp, vp]
+    L.nm_engine_get_mass_matrix.argtypes = [vp, vp, vp]
+    L.nm_engine_get_step_sizes.argtypes = [vp, vp]
+    L.nm_engine_get_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(dbl), C.POINTER(u64)]
+    L.nm_engine_reset_counters.argtypes = [vp]
+    L.nm_engine_dim.argtypes = [vp]
+    L.nm_engine_dim.restype = u64
+    L.nm_engine_num_chains.argtypes = [vp]
+    L.nm_engine_num_chains.restype = u64
+    L.nm_engine_stream.argtypes = [vp]
+    L.nm_engine_stream.restype = vp
+    L.nm_leapfrog_batch.argtypes = [C.POINTER(NmLogpSpec), u64, u64] + [vp] * 16 + [vp]
+    L.nm_turning_batch.argtypes = [u64, u64, u64, vp, vp, vp, vp, vp, vp]
+    L.nm_scalar_math_batch.argtypes = [u64, u64, vp, vp, vp, vp]
+    L.nm_standard_normal_batch.argtypes = [u64, u64, vp, vp, vp, vp]
+    L.nm_chain_rng_key.argtypes = [u64, u64, vp]
+    L.nm_last_error.restype = C.c_char_p
+    L.nm_abi_version.restype = u64
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("nm_settings_default",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != NM_OK:
+        raise NutsAmdError(status, load().nm_last_error().decode())

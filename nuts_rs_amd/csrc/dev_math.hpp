@@ -1,0 +1,292 @@
+// dev_math.hpp — device-side scalar math, wavefront reductions and the ChaCha8 word stream (gfx950).
+//
+// One wavefront (64 lanes) owns one chain.  A chain vector of padded length DP = 64*DPL lives in HBM as
+// [DP] doubles; lane l holds, for m = 0..DPL/2-1, the PAIR of elements d = 2*(m*64 + l) + {0,1} in registers,
+// so every global access is a 16-byte-per-lane, 1-KiB-per-wave coalesced double2 transaction.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; FMAs only where the reference
+// writes mul_add (src/math/util.rs:161-168, :273-280, :376-379, :426-429, :477-480); reductions over dim are
+// a per-lane serial sum in (m, j) order followed by an xor butterfly with offsets 1,2,4,8,16,32;
+// exp / ln are the fdlibm algorithms written out in binary64 operations (the platform libm the reference
+// calls through Rust's f64::exp is not bit-stable across machines; these are, and the CPU oracle has the
+// same sequences so GPU and oracle agree bit-for-bit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nm {
+
+#define NM_DEV __device__ __forceinline__
+
+#define NM_HD __host__ __device__ __forceinline__
+NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
+NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ---- wavefront reductions ---------------------------------------------------------------------
+NM_DEV double wave_sum(double x) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) x = x + __shfl_xor(x, s, 64);
+    return x;
+}
+// two sums at once (independent butterflies interleave in the issue stream)
+NM_DEV void wave_sum2(double& a, double& b) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        double ta = __shfl_xor(a, s, 64), tb = __shfl_xor(b, s, 64);
+        a = a + ta;
+        b = b + tb;
+    }
+}
+NM_DEV double wave_bcast(double x, int src) { return __shfl(x, src, 64); }
+NM_DEV uint64_t wave_bcast_u64(uint64_t x, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src, 64);
+    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- deterministic exp / ln (Sun fdlibm e_exp.c / e_log.c algorithms) ---------------------------
+__host__ __device__ __noinline__ double dexp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __builtin_inf();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    double ax = __builtin_fabs(x);
+    double hi = x, lo = 0.0;
+    int k = 0;
+    if (ax > 0.34657359027997264) {
+        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
+        double t = (double)k;
+        hi = x - t * ln2HI;
+        lo = t * ln2LO;
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {
+        return 1.0 + x;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) {
+        if (k == 1024) return y * 2.0 * u2d((uint64_t)(1023 + 1023) << 52);
+        return y * u2d((uint64_t)(1023 + k) << 52);
+    }
+    return y * u2d((uint64_t)(1023 + k + 1000) << 52) * 9.33263618503218878990e-302;
+}
+
+__host__ __device__ __noinline__ double dlog(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = d2u(x);
+    int32_t hx = (int32_t)(u >> 32);
+    uint32_t lx = (uint32_t)u;
+    int k = 0;
+    if (hx < 0x00100000) {
+        if (((hx & 0x7fffffff) | lx) == 0) return -__builtin_inf();
+        if (hx < 0) return __builtin_nan("");
+        k -= 54;
+        x *= 1.80143985094819840000e+16;
+        u = d2u(x);
+        hx = (int32_t)(u >> 32);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    u = (u & 0xffffffffull) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
+    x = u2d(u);
+    k += (i >> 20);
+    double f = x - 1.0;
+    double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            return dk * ln2_hi + dk * ln2_lo;
+        }
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    double s = f / (2.0 + f);
+    double z = s * s;
+    i = hx - 0x6147a;
+    double w = z * z;
+    int32_t j = 0x6b851 - hx;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    double R = t2 + t1;
+    if (i > 0) {
+        double hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+NM_DEV double dlog1p(double x) {
+    double u = 1.0 + x;
+    if (u == 1.0) return x;
+    if (!(u == u) || __builtin_isinf(u)) return dlog(u);
+    return dlog(u) * (x / (u - 1.0));
+}
+
+// reference src/math/util.rs:6-19
+NM_DEV double logaddexp(double a, double b) {
+    if (a == b) return a + dlog(2.0);
+    double diff = a - b;
+    if (diff > 0.) return a + dlog1p(dexp(-diff));
+    if (diff < 0.) return b + dlog1p(dexp(diff));
+    return diff;
+}
+
+NM_DEV bool is_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
+NM_DEV double clampd(double v, double lo, double hi) {   // f64::clamp: NaN stays NaN
+    if (v < lo) return lo;
+    if (v > hi) return hi;
+    return v;
+}
+// f64::min(self, other): if one is NaN returns the other
+NM_DEV double fmin_rs(double a, double b) { return __builtin_fmin(a, b); }
+
+// ---- ChaCha8 word stream (rand's ChaCha8Rng semantics; see oracle/nmo_rng.hpp for the restated spec) -----
+NM_DEV void chacha8_block(const uint32_t (&key)[8], uint64_t counter, uint64_t stream, uint32_t (&out)[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                      key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
+#define NM_QR(a, b, c, d)                                                   \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = __builtin_rotateleft32(x[d], 16);    \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = __builtin_rotateleft32(x[b], 12);    \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = __builtin_rotateleft32(x[d], 8);     \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = __builtin_rotateleft32(x[b], 7);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        NM_QR(0, 4, 8, 12) NM_QR(1, 5, 9, 13) NM_QR(2, 6, 10, 14) NM_QR(3, 7, 11, 15)
+        NM_QR(0, 5, 10, 15) NM_QR(1, 6, 11, 12) NM_QR(2, 7, 8, 13) NM_QR(3, 4, 9, 14)
+    }
+#undef NM_QR
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+}
+
+// Wave-uniform generator.  The 64 lanes produce 64 consecutive blocks (1024 words) into an LDS cache; every
+// lane then reads the same word (LDS broadcast), so all scalar control flow driven by the stream is uniform.
+constexpr int RNG_CACHE_WORDS = 1024;
+struct DevRng {
+    uint32_t key[8];
+    uint64_t pos;      // next u32 word of the stream
+    uint64_t base;     // stream position of cache word 0 (multiple of 16)
+    uint32_t* cache;   // LDS, RNG_CACHE_WORDS words, private to this wave
+
+    NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* lds) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) key[i] = k[i];
+        pos = p;
+        base = p + 16;   // invalid: forces a refill on first use
+        cache = lds;
+    }
+    NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)RNG_CACHE_WORDS; }
+    NM_DEV void refill() {
+        __syncthreads();
+        base = pos & ~15ull;
+        uint32_t out[16];
+        chacha8_block(key, (base >> 4) + (uint64_t)lane_id(), 0ull, out);
+        uint4* dst = reinterpret_cast<uint4*>(cache + lane_id() * 16);
+        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+        dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+        dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+        __syncthreads();
+    }
+    NM_DEV uint32_t next_u32() {
+        if (!has(1)) refill();
+        uint32_t w = cache[pos - base];
+        pos += 1;
+        return w;
+    }
+    NM_DEV uint64_t next_u64() {
+        if (!has(2)) refill();
+        uint64_t lo = cache[pos - base], hi = cache[pos - base + 1];
+        pos += 2;
+        return (hi << 32) | lo;
+    }
+    // StandardUniform: bool = sign bit of a u32; f64 = 53 high bits of a u64
+    NM_DEV bool random_bool_std() { return (int32_t)next_u32() < 0; }
+    NM_DEV double random_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    // Bernoulli (rng.random_bool(p), reference src/nuts.rs:200): 1/0, or -1 for p outside [0,1] (reference panics)
+    NM_DEV int random_bool(double p) {
+        if (!(p >= 0.0 && p < 1.0)) return p == 1.0 ? 1 : -1;
+        uint64_t p_int = (uint64_t)(p * 18446744073709551616.0);
+        return next_u64() < p_int ? 1 : 0;
+    }
+};
+
+struct ZigTables { const double* x; const double* f; };   // 257 entries each, HBM (L1/L2 resident)
+constexpr double ZIG_R = 3.654152885361008796;
+
+// Tail of rand_distr's ziggurat loop for ONE sample whose first fast-path test failed; uniform over the wave.
+NM_DEV double normal_slow_path(DevRng& rng, uint64_t bits, ZigTables T) {
+    for (;;) {
+        int i = (int)(bits & 0xff);
+        double u = u2d((bits >> 12) | 0x4000000000000000ull) - 3.0;
+        double x = u * T.x[i];
+        if (__builtin_fabs(x) < T.x[i + 1]) return x;
+        if (i == 0) {
+            double xx = 1.0, yy = 0.0;
+            while (-2.0 * yy < xx * xx) {
+                double a = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
+                double b = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
+                xx = dlog(a) / ZIG_R;
+                yy = dlog(b);
+            }
+            return u < 0.0 ? xx - ZIG_R : ZIG_R - xx;
+        }
+        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * rng.random_f64() < dexp(-x * x / 2.0)) return x;
+        bits = rng.next_u64();
+    }
+}
+
+// `count` StandardNormal variates of the stream, in stream order, into stage[0..count) (LDS).
+// 64 samples are attempted per pass from 64 consecutive u64 of the stream (one per lane); the samples before
+// the first lane whose fast-path test fails are exactly what the sequential algorithm would have produced;
+// that lane's sample is finished on the slow path and the pass restarts behind it.
+NM_DEV void fill_standard_normals(DevRng& rng, double* stage, int count, ZigTables T) {
+    const int lane = lane_id();
+    int i = 0;
+    while (i < count) {
+        if (!rng.has(128)) rng.refill();
+        const int nvalid = (count - i) < 64 ? (count - i) : 64;
+        const uint32_t off = (uint32_t)(rng.pos - rng.base) + 2u * (uint32_t)lane;
+        uint64_t bits = ((uint64_t)rng.cache[off + 1] << 32) | rng.cache[off];
+        int zi = (int)(bits & 0xff);
+        double u = u2d((bits >> 12) | 0x4000000000000000ull) - 3.0;
+        double x = u * T.x[zi];
+        bool ok = __builtin_fabs(x) < T.x[zi + 1];
+        uint64_t fail = __ballot(lane < nvalid && !ok);
+        int nacc = fail ? (int)__builtin_ctzll(fail) : nvalid;
+        if (lane < nacc) stage[i + lane] = x;
+        rng.pos += 2ull * (uint64_t)nacc;
+        i += nacc;
+        if (fail) {
+            uint64_t fbits = wave_bcast_u64(bits, nacc);
+            rng.pos += 2;
+            double xs = normal_slow_path(rng, fbits, T);
+            if (lane == 0) stage[i] = xs;
+            i += 1;
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace nm

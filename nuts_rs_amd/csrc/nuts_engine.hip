@@ -1,0 +1,686 @@
+// nuts_engine.hip — host side of libnuts_amd.so: the C ABI of include/nuts_amd.h over the gfx950 kernels
+// of nuts_kernels.hpp.  No CPU fallback: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nuts_kernels.hpp"
+
+using namespace nm;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static nm_status fail(nm_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(NM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char* nm_last_error(void) { return g_last_error.c_str(); }
+extern "C" uint64_t nm_abi_version(void) { return NM_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// host-side random stream (chain keys, init positions): rand's ChaCha8Rng / seed_from_u64 semantics,
+// same published algorithms as the device generator in dev_math.hpp.
+// ---------------------------------------------------------------------------------------------
+namespace {
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+void host_chacha8_block(const uint32_t key[8], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], (uint32_t)counter, (uint32_t)(counter >> 32),
+                      (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl32(x[d], 16);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl32(x[b], 12);
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl32(x[d], 8);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl32(x[b], 7);
+    };
+    for (int r = 0; r < 4; ++r) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+}
+struct HostRng {
+    uint32_t key[8];
+    uint64_t stream = 0, pos = 0, buf_block = ~0ull;
+    uint32_t buf[16];
+    static HostRng seed_from_u64(uint64_t state) {            // PCG32 expansion (rand_core)
+        HostRng r;
+        const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+        for (int c = 0; c < 8; ++c) {
+            state = state * MUL + INC;
+            uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            r.key[c] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+        return r;
+    }
+    uint32_t next_u32() {
+        uint64_t b = pos >> 4;
+        if (b != buf_block) { host_chacha8_block(key, b, stream, buf); buf_block = b; }
+        return buf[pos++ & 15];
+    }
+    uint64_t next_u64() { uint64_t lo = next_u32(); uint64_t hi = next_u32(); return (hi << 32) | lo; }
+};
+// outer generator of a chain (reference src/sampler.rs:1105-1106)
+HostRng outer_rng(uint64_t seed, uint64_t chain_id) {
+    HostRng r = HostRng::seed_from_u64(seed);
+    r.stream = chain_id + 1;
+    return r;
+}
+}  // namespace
+
+extern "C" nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]) {
+    if (!key_out) return fail(NM_ERR_INVALID_ARG, "key_out is null");
+    HostRng o = outer_rng(seed, chain_id);
+    for (int i = 0; i < 8; ++i) {                              // ChaCha8Rng::try_from_rng (src/sampler.rs:761)
+        uint32_t w = o.next_u32();
+        for (int b = 0; b < 4; ++b) key_out[4 * i + b] = (uint8_t)(w >> (8 * b));
+    }
+    return NM_OK;
+}
+
+extern "C" nm_status nm_init_positions_uniform(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains,
+                                               uint64_t dim, double* h_x0) {
+    if (!h_x0) return fail(NM_ERR_INVALID_ARG, "h_x0 is null");
+    for (uint64_t c = 0; c < n_chains; ++c) {
+        HostRng o = outer_rng(seed, chain_id_offset + c);
+        for (int i = 0; i < 8; ++i) (void)o.next_u32();
+        for (uint64_t d = 0; d < dim; ++d) {                   // CpuMath::init_position (cpu_math.rs:184-187)
+            double val = (double)(o.next_u64() >> 11) * (1.0 / 9007199254740992.0);
+            h_x0[c * dim + d] = val * 2.0 - 1.0;
+        }
+    }
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// settings
+// ---------------------------------------------------------------------------------------------
+extern "C" void nm_settings_default(nm_settings* s) {
+    memset(s, 0, sizeof *s);
+    s->num_tune = 400; s->num_draws = 1000; s->maxdepth = 10; s->mindepth = 0;
+    s->max_energy_error = 1000.0; s->check_turning = 1; s->extra_doublings = 0; s->seed = 0; s->num_chains = 6;
+    s->early_window = 0.3; s->step_size_window = 0.15;
+    s->mass_matrix_switch_freq = 80; s->early_mass_matrix_switch_freq = 10; s->mass_matrix_update_freq = 1;
+    s->mass_matrix_window_growth = 1.5;
+    s->store_mass_matrix = 0; s->use_grad_based_estimate = 1;
+    s->target_accept = 0.8; s->initial_step = 0.1; s->has_jitter = 1; s->jitter = 0.1;
+    s->step_size_method = NM_STEP_DUAL_AVERAGE; s->fixed_step_size = 0.0;
+    s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
+}
+extern "C" void nm_engine_config_default(nm_engine_config* c) {
+    memset(c, 0, sizeof *c);
+    c->device = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch
+// ---------------------------------------------------------------------------------------------
+enum KernelKind { K_INIT, K_DRAW };
+
+template <int DPL, class Dens>
+static hipError_t launch_t(KernelKind kind, const KParams& P, hipStream_t stream) {
+    dim3 grid((unsigned)P.n_chains), block(64);
+    if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, Dens>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((nuts_draw_kernel<DPL, Dens>), grid, block, 0, stream, P);
+    return hipGetLastError();
+}
+template <class Dens>
+static hipError_t launch_d(int dpl, KernelKind kind, const KParams& P, hipStream_t stream) {
+    switch (dpl) {
+    case 2: return launch_t<2, Dens>(kind, P, stream);
+    case 4: return launch_t<4, Dens>(kind, P, stream);
+    case 8: return launch_t<8, Dens>(kind, P, stream);
+    case 16: return launch_t<16, Dens>(kind, P, stream);
+    }
+    return hipErrorInvalidValue;
+}
+static hipError_t launch(uint64_t logp_kind, int dpl, KernelKind kind, const KParams& P, hipStream_t stream) {
+    switch (logp_kind) {
+    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, kind, P, stream);
+    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, kind, P, stream);
+    }
+    return hipErrorInvalidValue;
+}
+static int pick_dpl(uint64_t dim, uint64_t requested) {
+    const int opts[4] = {2, 4, 8, 16};
+    if (requested) {
+        for (int o : opts) if ((uint64_t)o == requested && (uint64_t)o * 64 >= dim) return o;
+        return 0;
+    }
+    for (int o : opts) if ((uint64_t)o * 64 >= dim) return o;
+    return 0;
+}
+static nm_status check_logp(const nm_logp_spec* l) {
+    if (!l) return fail(NM_ERR_INVALID_ARG, "logp spec is null");
+    if (l->dim == 0) return fail(NM_ERR_INVALID_ARG, "dim must be > 0");
+    switch (l->kind) {
+    case NM_LOGP_IID_NORMAL:
+        if (l->n_params != 1 || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_IID_NORMAL takes 1 parameter (mu)");
+        return NM_OK;
+    case NM_LOGP_DIAG_NORMAL:
+        if (l->n_params != l->dim || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_DIAG_NORMAL takes dim parameters");
+        return NM_OK;
+    case NM_LOGP_FUNNEL:
+    case NM_LOGP_EIGHT_SCHOOLS:
+        return fail(NM_ERR_UNSUPPORTED, "logp kind %llu is declared but not implemented in this build", (unsigned long long)l->kind);
+    }
+    return fail(NM_ERR_INVALID_ARG, "unknown logp kind %llu", (unsigned long long)l->kind);
+}
+
+static nm_status ensure_device(int64_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(NM_ERR_NO_DEVICE, "no HIP device available (%s); libnuts_amd has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device >= 0) {
+        if (device >= n) return fail(NM_ERR_INVALID_ARG, "device %lld out of range (%d devices)", (long long)device, n);
+        HIP_TRY(hipSetDevice((int)device));
+    }
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------
+struct nm_engine {
+    nm_settings s;
+    nm_engine_config cfg;
+    uint64_t logp_kind = 0, dim = 0, n_chains = 0;
+    int dpl = 0;
+    int device = 0;
+    bool positioned = false;
+    KParams P;
+    double* d_vec = nullptr;
+    ChainScalars* d_sc = nullptr;
+    double* d_zig = nullptr;      // x[257] then f[257]
+    double* d_params = nullptr;
+    double* d_x0 = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    uint64_t steps_base = 0, draws_total = 0;
+    bool pending_timing = false;
+};
+
+static void engine_free(nm_engine* e) {
+    if (!e) return;
+    if (e->d_vec) (void)hipFree(e->d_vec);
+    if (e->d_sc) (void)hipFree(e->d_sc);
+    if (e->d_zig) (void)hipFree(e->d_zig);
+    if (e->d_params) (void)hipFree(e->d_params);
+    if (e->d_x0) (void)hipFree(e->d_x0);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" void nm_engine_destroy(nm_engine* e) { engine_free(e); }
+
+extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp_spec* logp, uint64_t n_chains,
+                                      const nm_engine_config* cfg_in, nm_engine** out) {
+    if (!settings || !out) return fail(NM_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    nm_status st = check_logp(logp);
+    if (st != NM_OK) return st;
+    if (n_chains == 0) return fail(NM_ERR_INVALID_ARG, "n_chains must be > 0");
+    const nm_settings& s = *settings;
+    if (s.maxdepth > (uint64_t)MAX_MAXDEPTH) return fail(NM_ERR_UNSUPPORTED, "maxdepth %llu > %d", (unsigned long long)s.maxdepth, MAX_MAXDEPTH);
+    if (s.step_size_method == NM_STEP_ADAM) return fail(NM_ERR_UNSUPPORTED, "Adam step-size adaptation is not implemented (reference src/stepsize/adam.rs)");
+    if (s.step_size_method != NM_STEP_DUAL_AVERAGE && s.step_size_method != NM_STEP_FIXED) return fail(NM_ERR_INVALID_ARG, "unknown step_size_method");
+    // GlobalStrategy::new asserts (adapt_strategy.rs:83-84)
+    const double num_tune_f = (double)s.num_tune;
+    const uint64_t step_size_window = (uint64_t)(s.step_size_window * num_tune_f);
+    const uint64_t early_end = (uint64_t)(s.early_window * num_tune_f);
+    if (!(early_end < s.num_tune)) return fail(NM_ERR_INVALID_ARG, "early_end < num_tune violated (reference asserts, adapt_strategy.rs:83)");
+    if (!(s.mass_matrix_window_growth >= 1.0)) return fail(NM_ERR_INVALID_ARG, "mass_matrix_window_growth must be >= 1");
+    if (s.has_jitter && !(1.0 - s.jitter < 1.0 + s.jitter)) return fail(NM_ERR_INVALID_ARG, "invalid jitter");
+    nm_engine_config cfg;
+    if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
+    const int dpl = pick_dpl(logp->dim, cfg.dims_per_lane);
+    if (!dpl) return fail(NM_ERR_UNSUPPORTED, "dim %llu needs more than 16 doubles per lane (or dims_per_lane %llu invalid); max dim is 1024 in this build",
+                          (unsigned long long)logp->dim, (unsigned long long)cfg.dims_per_lane);
+    st = ensure_device(cfg.device);
+    if (st != NM_OK) return st;
+
+    nm_engine* e = new (std::nothrow) nm_engine();
+    if (!e) return fail(NM_ERR_HIP, "out of host memory");
+    e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl;
+    (void)hipGetDevice(&e->device);
+    const uint64_t dpad = 64ull * (uint64_t)dpl;
+    const uint64_t nslot = (uint64_t)num_slots((int)s.maxdepth);
+#define E_TRY(expr)                                                                                 \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) { engine_free(e); return fail(NM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } \
+    } while (0)
+    E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    E_TRY(hipEventCreate(&e->ev0));
+    E_TRY(hipEventCreate(&e->ev1));
+    const size_t vec_bytes = (size_t)n_chains * nslot * dpad * sizeof(double);
+    E_TRY(hipMalloc(&e->d_vec, vec_bytes));
+    E_TRY(hipMemsetAsync(e->d_vec, 0, vec_bytes, e->stream));
+    E_TRY(hipMalloc(&e->d_sc, n_chains * sizeof(ChainScalars)));
+    E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
+    E_TRY(hipMalloc(&e->d_params, logp->n_params * sizeof(double)));
+    E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
+    E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    {   // ziggurat tables of rand_distr's StandardNormal (Marsaglia & Tsang, 256 layers)
+        std::vector<double> t(2 * 257);
+        double* x = t.data();
+        double* f = t.data() + 257;
+        const double r = ZIG_R, v = 0.00492867323399;
+        auto pdf = [](double u) { return std::exp(-u * u / 2.0); };
+        x[0] = v / pdf(r); x[1] = r;
+        for (int i = 2; i < 256; ++i) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + pdf(x[i - 1])));
+        x[256] = 0.0;
+        for (int i = 0; i < 257; ++i) f[i] = pdf(x[i]);
+        E_TRY(hipMemcpy(e->d_zig, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // per-chain scalars: NutsChain::new / GlobalStrategy::new state (the DualAverage is reset on the device)
+    {
+        std::vector<ChainScalars> sc(n_chains);
+        for (uint64_t c = 0; c < n_chains; ++c) {
+            ChainScalars& q = sc[c];
+            memset(&q, 0, sizeof q);
+            uint8_t key[32];
+            nm_chain_rng_key(s.seed, cfg.chain_id_offset + c, key);
+            for (int i = 0; i < 8; ++i)
+                q.key[i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) | ((uint32_t)key[4 * i + 3] << 24);
+            q.transform_id = -1; q.mm_id = -1;
+            q.tuning = 1; q.has_initial_mass_matrix = 1;
+            q.current_window_size = s.mass_matrix_switch_freq;
+            q.status = NM_CHAIN_OK;
+        }
+        E_TRY(hipMemcpy(e->d_sc, sc.data(), n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    }
+    KParams& P = e->P;
+    memset(&P, 0, sizeof P);
+    P.s = s;
+    P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nslot = nslot;
+    P.vec = e->d_vec; P.sc = e->d_sc; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
+    P.early_end = early_end;
+    P.final_step_size_window = s.num_tune >= step_size_window ? s.num_tune - step_size_window : 0;   // saturating_sub
+    P.ln_max_step = dlog(s.da_max_step_size);
+    if (s.has_jitter) {   // Uniform::new(1 - j, 1 + j)
+        const double low = 1.0 - s.jitter, high = 1.0 + s.jitter, max_rand = 1.0 - 2.220446049250313e-16;
+        double scale = high - low;
+        while (scale * max_rand + low >= high) scale = u2d(d2u(scale) - 1);
+        P.jitter_low = low; P.jitter_scale = scale;
+    }
+    P.x0 = e->d_x0;
+    E_TRY(hipStreamSynchronize(e->stream));
+#undef E_TRY
+    *out = e;
+    return NM_OK;
+}
+
+static nm_status collect_timing(nm_engine* e) {
+    if (e->pending_timing) {
+        HIP_TRY(hipEventSynchronize(e->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += (double)ms;
+        e->pending_timing = false;
+    }
+    return NM_OK;
+}
+
+extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, uint64_t* h_chain_status) {
+    if (!e || !h_x0) return fail(NM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    KParams P = e->P;
+    HIP_TRY(launch(e->logp_kind, e->dpl, K_INIT, P, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<ChainScalars> sc(e->n_chains);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    uint64_t bad = 0, fatal = 0;
+    for (uint64_t c = 0; c < e->n_chains; ++c) {
+        if (h_chain_status) h_chain_status[c] = sc[c].status;
+        if (sc[c].status == NM_CHAIN_BAD_INIT) bad++;
+        else if (sc[c].status != NM_CHAIN_OK) fatal++;
+    }
+    e->positioned = true;
+    if (fatal) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s): logp failure during set_position", (unsigned long long)fatal);
+    if (bad) return fail(NM_ERR_BAD_INIT, "%llu chain(s): Could not initialize state because of bad initial gradient", (unsigned long long)bad);
+    return NM_OK;
+}
+
+extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (!e->positioned) return fail(NM_ERR_STATE, "nm_engine_draw before nm_engine_set_positions");
+    if (n_draws == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    nm_status st = collect_timing(e);
+    if (st != NM_OK) return st;
+    KParams P = e->P;
+    P.n_draws = n_draws; P.out_positions = d_positions; P.out_stats = d_stats;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, K_DRAW, P, e->stream));
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    e->pending_timing = true;
+    e->kernel_launches += 1;
+    e->draws_total += n_draws;
+    return NM_OK;
+}
+extern "C" nm_status nm_engine_synchronize(nm_engine* e) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return collect_timing(e);
+}
+extern "C" nm_status nm_engine_draw(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
+    nm_status st = nm_engine_draw_async(e, n_draws, d_positions, d_stats);
+    if (st != NM_OK) return st;
+    return nm_engine_synchronize(e);
+}
+
+extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    double* d_pos = nullptr;
+    nm_draw_stats* d_st = nullptr;
+    const size_t pos_bytes = (size_t)n_draws * e->n_chains * e->dim * sizeof(double);
+    const size_t st_bytes = (size_t)n_draws * e->n_chains * sizeof(nm_draw_stats);
+    if (h_positions && pos_bytes) HIP_TRY(hipMalloc(&d_pos, pos_bytes));
+    if (h_stats && st_bytes) {
+        hipError_t er = hipMalloc(&d_st, st_bytes);
+        if (er != hipSuccess) { if (d_pos) (void)hipFree(d_pos); return fail(NM_ERR_HIP, "hipMalloc stats: %s", hipGetErrorString(er)); }
+    }
+    nm_status st = nm_engine_draw(e, n_draws, d_pos, d_st);
+    if (st == NM_OK && d_pos && hipMemcpy(h_positions, d_pos, pos_bytes, hipMemcpyDeviceToHost) != hipSuccess) st = fail(NM_ERR_HIP, "copy positions");
+    if (st == NM_OK && d_st && hipMemcpy(h_stats, d_st, st_bytes, hipMemcpyDeviceToHost) != hipSuccess) st = fail(NM_ERR_HIP, "copy stats");
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_st) (void)hipFree(d_st);
+    if (st != NM_OK) return st;
+    // surface chain failures the way Chain::draw's Result does
+    std::vector<ChainScalars> sc(e->n_chains);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    uint64_t failed = 0;
+    for (auto& q : sc) if (q.status != NM_CHAIN_OK) failed++;
+    if (failed) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s) stopped with an error status", (unsigned long long)failed);
+    return NM_OK;
+}
+
+static nm_status read_slot(nm_engine* e, int slot, double* h_out) {
+    if (!e || !h_out) return fail(NM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const KParams& P = e->P;
+    // strided copy: row c = vec[c][slot][0..dim)
+    HIP_TRY(hipMemcpy2D(h_out, e->dim * sizeof(double), e->d_vec + (size_t)slot * P.dpad,
+                        P.nslot * P.dpad * sizeof(double), e->dim * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+extern "C" nm_status nm_engine_get_positions(nm_engine* e, double* h_x) { return read_slot(e, P_X, h_x); }
+extern "C" nm_status nm_engine_get_gradients(nm_engine* e, double* h_gx) { return read_slot(e, P_GX, h_gx); }
+extern "C" nm_status nm_engine_get_mass_matrix(nm_engine* e, double* h_stds, double* h_mean) {
+    nm_status st = NM_OK;
+    if (h_stds) st = read_slot(e, P_SIG, h_stds);
+    if (st == NM_OK && h_mean) st = read_slot(e, P_MU, h_mean);
+    return st;
+}
+extern "C" nm_status nm_engine_get_step_sizes(nm_engine* e, double* h_step_size) {
+    if (!e || !h_step_size) return fail(NM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<ChainScalars> sc(e->n_chains);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    for (uint64_t c = 0; c < e->n_chains; ++c) h_step_size[c] = sc[c].step_size;
+    return NM_OK;
+}
+extern "C" nm_status nm_engine_get_counters(nm_engine* e, uint64_t* total_leapfrogs, uint64_t* total_draws,
+                                            double* kernel_ms, uint64_t* kernel_launches) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    nm_status st = nm_engine_synchronize(e);
+    if (st != NM_OK) return st;
+    if (total_leapfrogs) {
+        std::vector<ChainScalars> sc(e->n_chains);
+        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        uint64_t tot = 0;
+        for (auto& q : sc) tot += q.total_steps;
+        *total_leapfrogs = tot - e->steps_base;
+    }
+    if (total_draws) *total_draws = e->draws_total;
+    if (kernel_ms) *kernel_ms = e->kernel_ms;
+    if (kernel_launches) *kernel_launches = e->kernel_launches;
+    return NM_OK;
+}
+extern "C" nm_status nm_engine_reset_counters(nm_engine* e) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    uint64_t tot = 0;
+    nm_status st = nm_engine_get_counters(e, &tot, nullptr, nullptr, nullptr);
+    if (st != NM_OK) return st;
+    e->steps_base += tot; e->draws_total = 0; e->kernel_ms = 0.0; e->kernel_launches = 0;
+    return NM_OK;
+}
+extern "C" uint64_t nm_engine_dim(const nm_engine* e) { return e ? e->dim : 0; }
+extern "C" uint64_t nm_engine_num_chains(const nm_engine* e) { return e ? e->n_chains : 0; }
+extern "C" void* nm_engine_stream(nm_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// batched Math primitives (unit-parity surface): rows are [n][dim], unpadded
+// ---------------------------------------------------------------------------------------------
+namespace nm {
+struct LfArgs {
+    KParams P;
+    const double *z, *v, *gz, *sigma, *mu, *eps, *logdet, *e0;
+    double *z_out, *v_out, *gz_out, *x_out, *gx_out, *logp_out, *ke_out, *err_out;
+};
+template <int DPL>
+NM_DEV void load_row(Tile<DPL>& t, const double* row, int dim) {
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) { int d = elem_index(k); t.a[k] = d < dim ? row[d] : 0.0; }
+}
+template <int DPL>
+NM_DEV void store_row(const Tile<DPL>& t, double* row, int dim) {
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) { int d = elem_index(k); if (d < dim) row[d] = t.a[k]; }
+}
+template <int DPL, class Dens>
+__global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
+    const uint64_t i = blockIdx.x;
+    const int dim = (int)A.P.dim;
+    ChainCtx<DPL, Dens> C(A.P);
+    C.dim = dim;
+    C.dens.init(A.P.logp_params, dim);
+    load_row(C.sig, A.sigma + i * dim, dim);
+    load_row(C.mu, A.mu + i * dim, dim);
+    Live<DPL> s;
+    load_row(s.z, A.z + i * dim, dim);
+    load_row(s.v, A.v + i * dim, dim);
+    load_row(s.g, A.gz + i * dim, dim);
+    Tile<DPL> x;
+    leapfrog(C, s, A.eps[i], &x);
+    store_row(s.z, A.z_out + i * dim, dim); store_row(s.v, A.v_out + i * dim, dim);
+    store_row(s.g, A.gz_out + i * dim, dim); store_row(x, A.x_out + i * dim, dim);
+    store_row(s.gx, A.gx_out + i * dim, dim);
+    if (lane_id() == 0) {
+        A.logp_out[i] = s.logp;
+        A.ke_out[i] = s.ke;
+        A.err_out[i] = (s.ke - (s.logp + A.logdet[i])) - A.e0[i];
+    }
+}
+template <int DPL>
+__global__ __launch_bounds__(64) void turning_batch_kernel(uint64_t dim, const double* zs, const double* vs,
+                                                           const double* ze, const double* ve, double* out) {
+    const uint64_t i = blockIdx.x;
+    Tile<DPL> a, b, c, d;
+    load_row(a, zs + i * dim, (int)dim); load_row(b, vs + i * dim, (int)dim);
+    load_row(c, ze + i * dim, (int)dim); load_row(d, ve + i * dim, (int)dim);
+    double t1 = 0., t2 = 0.;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) turn_acc(a.a[k], b.a[k], c.a[k], d.a[k], t1, t2);
+    wave_sum2(t1, t2);
+    if (lane_id() == 0) { out[2 * i] = t1; out[2 * i + 1] = t2; }
+}
+__global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, const double* b, double* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], y = b ? b[i] : 0.0, r;
+    switch (op) {
+    case 0: r = dexp(x); break;
+    case 1: r = dlog(x); break;
+    case 2: r = dlog1p(x); break;
+    case 3: r = logaddexp(x, y); break;
+    case 4: r = __builtin_sqrt(x); break;
+    case 5: r = x / y; break;
+    default: r = __builtin_nan("");
+    }
+    out[i] = r;
+}
+__global__ __launch_bounds__(64) void normal_batch_kernel(uint64_t count, const uint32_t* keys, const double* zig_x,
+                                                          const double* zig_f, double* out, uint64_t* words) {
+    __shared__ uint32_t cache[RNG_CACHE_WORDS];
+    __shared__ double stage[1024];
+    const uint64_t i = blockIdx.x;
+    DevRng rng;
+    rng.init(keys + 8 * i, 0, cache);
+    ZigTables T = {zig_x, zig_f};
+    uint64_t done = 0;
+    while (done < count) {
+        int chunk = (count - done) < 1024 ? (int)(count - done) : 1024;
+        fill_standard_normals(rng, stage, chunk, T);
+        for (int j = lane_id(); j < chunk; j += 64) out[i * count + done + j] = stage[j];
+        __syncthreads();
+        done += chunk;
+    }
+    if (words && lane_id() == 0) words[i] = rng.pos;
+}
+}  // namespace nm
+
+template <class Dens>
+static hipError_t launch_lf_d(int dpl, const LfArgs& A, uint64_t n, hipStream_t st) {
+    dim3 g((unsigned)n), b(64);
+    switch (dpl) {
+    case 2: hipLaunchKernelGGL((leapfrog_batch_kernel<2, Dens>), g, b, 0, st, A); break;
+    case 4: hipLaunchKernelGGL((leapfrog_batch_kernel<4, Dens>), g, b, 0, st, A); break;
+    case 8: hipLaunchKernelGGL((leapfrog_batch_kernel<8, Dens>), g, b, 0, st, A); break;
+    case 16: hipLaunchKernelGGL((leapfrog_batch_kernel<16, Dens>), g, b, 0, st, A); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uint64_t dims_per_lane,
+                                       const double* d_z, const double* d_v, const double* d_gz,
+                                       const double* d_sigma, const double* d_mu,
+                                       const double* d_eps, const double* d_logdet, const double* d_initial_energy,
+                                       double* d_z_out, double* d_v_out, double* d_gz_out,
+                                       double* d_x_out, double* d_gx_out,
+                                       double* d_logp_out, double* d_kinetic_out, double* d_energy_error_out,
+                                       void* stream) {
+    nm_status st = check_logp(logp);
+    if (st != NM_OK) return st;
+    st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    const int dpl = pick_dpl(logp->dim, dims_per_lane);
+    if (!dpl) return fail(NM_ERR_UNSUPPORTED, "unsupported dim / dims_per_lane");
+    if (n == 0) return NM_OK;
+    double* d_params = nullptr;
+    HIP_TRY(hipMalloc(&d_params, logp->n_params * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    LfArgs A;
+    memset(&A, 0, sizeof A);
+    A.P.dim = logp->dim; A.P.dpad = 64ull * dpl; A.P.logp_params = d_params; A.P.n_chains = n;
+    A.z = d_z; A.v = d_v; A.gz = d_gz; A.sigma = d_sigma; A.mu = d_mu; A.eps = d_eps; A.logdet = d_logdet; A.e0 = d_initial_energy;
+    A.z_out = d_z_out; A.v_out = d_v_out; A.gz_out = d_gz_out; A.x_out = d_x_out; A.gx_out = d_gx_out;
+    A.logp_out = d_logp_out; A.ke_out = d_kinetic_out; A.err_out = d_energy_error_out;
+    hipError_t er = logp->kind == NM_LOGP_IID_NORMAL ? launch_lf_d<IidNormal>(dpl, A, n, (hipStream_t)stream)
+                                                     : launch_lf_d<DiagNormal>(dpl, A, n, (hipStream_t)stream);
+    if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_params);
+    if (er != hipSuccess) return fail(NM_ERR_HIP, "leapfrog_batch: %s", hipGetErrorString(er));
+    return NM_OK;
+}
+
+extern "C" nm_status nm_turning_batch(uint64_t n, uint64_t dim, uint64_t dims_per_lane,
+                                      const double* d_z_start, const double* d_v_start,
+                                      const double* d_z_end, const double* d_v_end, double* d_out_t, void* stream) {
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    const int dpl = pick_dpl(dim, dims_per_lane);
+    if (!dpl) return fail(NM_ERR_UNSUPPORTED, "unsupported dim / dims_per_lane");
+    if (n == 0) return NM_OK;
+    dim3 g((unsigned)n), b(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dpl) {
+    case 2: hipLaunchKernelGGL((turning_batch_kernel<2>), g, b, 0, s, dim, d_z_start, d_v_start, d_z_end, d_v_end, d_out_t); break;
+    case 4: hipLaunchKernelGGL((turning_batch_kernel<4>), g, b, 0, s, dim, d_z_start, d_v_start, d_z_end, d_v_end, d_out_t); break;
+    case 8: hipLaunchKernelGGL((turning_batch_kernel<8>), g, b, 0, s, dim, d_z_start, d_v_start, d_z_end, d_v_end, d_out_t); break;
+    case 16: hipLaunchKernelGGL((turning_batch_kernel<16>), g, b, 0, s, dim, d_z_start, d_v_start, d_z_end, d_v_end, d_out_t); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return NM_OK;
+}
+
+extern "C" nm_status nm_scalar_math_batch(uint64_t op, uint64_t n, const double* d_a, const double* d_b, double* d_out, void* stream) {
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    if (op > 5) return fail(NM_ERR_INVALID_ARG, "unknown op");
+    if (n == 0) return NM_OK;
+    hipLaunchKernelGGL(scalar_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, n, d_a, d_b, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return NM_OK;
+}
+
+extern "C" nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const uint8_t* h_keys, double* d_out,
+                                              uint64_t* h_words_consumed, void* stream) {
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    if (!h_keys || !d_out) return fail(NM_ERR_INVALID_ARG, "null argument");
+    if (n == 0 || count == 0) return NM_OK;
+    std::vector<uint32_t> keys(8 * n);
+    for (uint64_t i = 0; i < 8 * n; ++i)
+        keys[i] = (uint32_t)h_keys[4 * i] | ((uint32_t)h_keys[4 * i + 1] << 8) | ((uint32_t)h_keys[4 * i + 2] << 16) | ((uint32_t)h_keys[4 * i + 3] << 24);
+    std::vector<double> t(2 * 257);
+    {
+        double* x = t.data();
+        double* f = t.data() + 257;
+        const double r = ZIG_R, v = 0.00492867323399;
+        auto pdf = [](double u) { return std::exp(-u * u / 2.0); };
+        x[0] = v / pdf(r); x[1] = r;
+        for (int i = 2; i < 256; ++i) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + pdf(x[i - 1])));
+        x[256] = 0.0;
+        for (int i = 0; i < 257; ++i) f[i] = pdf(x[i]);
+    }
+    uint32_t* d_keys = nullptr; double* d_zig = nullptr; uint64_t* d_words = nullptr;
+    HIP_TRY(hipMalloc(&d_keys, keys.size() * 4));
+    HIP_TRY(hipMalloc(&d_zig, t.size() * 8));
+    HIP_TRY(hipMalloc(&d_words, n * 8));
+    HIP_TRY(hipMemcpy(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_zig, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(normal_batch_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, count, d_keys, d_zig, d_zig + 257, d_out, d_words);
+    hipError_t er = hipGetLastError();
+    if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);
+    if (er == hipSuccess && h_words_consumed) er = hipMemcpy(h_words_consumed, d_words, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_keys); (void)hipFree(d_zig); (void)hipFree(d_words);
+    if (er != hipSuccess) return fail(NM_ERR_HIP, "standard_normal_batch: %s", hipGetErrorString(er));
+    return NM_OK;
+}

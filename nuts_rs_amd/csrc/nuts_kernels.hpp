@@ -1,0 +1,1040 @@
+// nuts_kernels.hpp — the many-chain NUTS kernels for gfx950 (MI355X).
+//
+// ONE WAVEFRONT = ONE CHAIN.  A wave keeps the live phase-space point (z, v, g_z, g_x) and the chain's mass
+// matrix (sigma, mu) in VGPRs (DPL doubles per lane per vector), runs the whole NUTS transition — momentum
+// refresh, every doubling of the tree with the fused leapfrog + logp/grad, the U-turn / divergence tests, the
+// multinomial merges, then the per-draw adaptation — and loops over draws without returning to the host.
+// All per-chain control flow (tree depth, termination, RNG consumption) is wave-uniform, so ragged trees cost
+// no lane divergence: a chain that stops early simply frees its wave for the next chain (hardware dispatch
+// replaces the host-side active mask + stream compaction of a lockstep design).
+// HBM is touched only for what the tree must remember: sub-tree end points (for U-turn tests between
+// non-adjacent states), multinomial candidates and the two edges of the main tree.
+//
+// Everything here is force-inlined into the kernels: the register tiles are passed by reference, and a real
+// call would force them through scratch memory.
+//
+// Reference semantics (pymc-devs/nuts-rs 0.18.3), cited per function below:
+//   src/nuts.rs:94-388, src/dynamics/transformed_hamiltonian.rs:161-262,:310-351,:524-736,
+//   src/transform/diagonal.rs:85-265, src/transform/adapt/diagonal.rs:17-236, src/adapt_strategy.rs:77-222,
+//   src/stepsize/adapt.rs:52-272, src/stepsize/dual_avg.rs:34-166, src/chain.rs:137-188.
+#pragma once
+#include "dev_math.hpp"
+#include "../../include/nuts_amd.h"
+
+namespace nm {
+
+constexpr int MAX_MAXDEPTH = 20;
+
+// ---------------------------------------------------------------------------------------------
+// HBM layout.  vec[chain][slot][DP] doubles.  Persistent slots first, then tree scratch.
+// ---------------------------------------------------------------------------------------------
+enum Slot : int {
+    P_X = 0, P_GX, P_Z, P_GZ,          // current point (TransformedPoint, transformed_hamiltonian.rs:56-77)
+    P_SIG, P_ISIG, P_MU,               // DiagMassMatrix stds / inv_stds / mean (transform/diagonal.rs:9-17)
+    E_DM, E_DV, E_GM, E_GV,            // foreground RunningVariance of draws / grads (adapt/diagonal.rs:108-115)
+    B_DM, B_DV, B_GM, B_GV,            // background
+    ML_Z, ML_V, ML_G, MR_Z, MR_V, MR_G,// main tree: left / right edge (z, v, g_z)
+    S_DYN                              // first dynamic slot
+};
+// dynamic slots: F[k] (z,v), L[k] (z,v) for k in 0..=maxdepth, then candidate pool C[p] (z, g_x), p in 0..maxdepth+2
+__host__ __device__ inline int slot_F(int k) { return S_DYN + 2 * k; }
+__host__ __device__ inline int slot_L(int maxdepth, int k) { return S_DYN + 2 * (maxdepth + 1) + 2 * k; }
+__host__ __device__ inline int slot_C(int maxdepth, int p) { return S_DYN + 4 * (maxdepth + 1) + 2 * p; }
+__host__ __device__ inline int num_slots(int maxdepth) { return S_DYN + 4 * (maxdepth + 1) + 2 * (maxdepth + 3); }
+
+// Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
+struct ChainScalars {
+    uint32_t key[8];
+    uint64_t rng_pos;
+    // current point
+    double logp, logdet;
+    int64_t transform_id;
+    // mass matrix
+    double mm_logdet;
+    int64_t mm_id;
+    // hamiltonian
+    double step_size;
+    // GlobalStrategy (adapt_strategy.rs:24-39)
+    uint64_t draw_count, last_update, current_window_size, tuning, has_initial_mass_matrix;
+    // RunningVariance counts (draw and grad estimators always have equal counts)
+    uint64_t cnt_fg, cnt_bg;
+    // DualAverage (dual_avg.rs:34-41)
+    double log_step, log_step_adapted, hbar, mu;
+    uint64_t da_count;
+    // stepsize::Strategy last_* (stepsize/adapt.rs:58-64)
+    double last_mean_tree_accept, last_sym_mean_tree_accept, last_max_energy_error;
+    uint64_t last_n_steps;
+    uint64_t status;       // NM_CHAIN_*
+    uint64_t total_steps;  // leapfrogs since creation (metric)
+};
+
+struct KParams {
+    nm_settings s;
+    uint64_t n_chains, dim, dpad, chain_id_offset, nslot;
+    double* vec;
+    ChainScalars* sc;
+    const double* zig_x;
+    const double* zig_f;
+    const double* logp_params;
+    // derived schedule constants (GlobalStrategy::new, adapt_strategy.rs:77-98)
+    uint64_t early_end, final_step_size_window;
+    double ln_max_step;                // ln(da_max_step_size), dual_avg.rs:59
+    double jitter_low, jitter_scale;   // Uniform::new(1-j, 1+j) (stepsize/adapt.rs:259-261)
+    // outputs of the draw kernel
+    double* out_positions;       // [n_draws][n_chains][dim] or null
+    nm_draw_stats* out_stats;    // [n_draws][n_chains] or null
+    uint64_t n_draws;
+    const double* x0;            // init kernel: [n_chains][dim]
+};
+
+// ---------------------------------------------------------------------------------------------
+// register tiles
+// ---------------------------------------------------------------------------------------------
+template <int DPL>
+struct Tile {
+    double a[DPL];
+};
+
+template <int DPL>
+NM_DEV void load_tile(Tile<DPL>& t, const double* base) {
+    const double2* p = reinterpret_cast<const double2*>(base) + lane_id();
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        double2 q = p[m * 64];
+        t.a[2 * m] = q.x;
+        t.a[2 * m + 1] = q.y;
+    }
+}
+template <int DPL>
+NM_DEV void store_tile(const Tile<DPL>& t, double* base) {
+    double2* p = reinterpret_cast<double2*>(base) + lane_id();
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) p[m * 64] = make_double2(t.a[2 * m], t.a[2 * m + 1]);
+}
+// element index held in register k of this lane
+NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 + lane_id()) + (k & 1); }
+
+// ---------------------------------------------------------------------------------------------
+// densities: eval(x, gx, dim) -> logp (wave-uniform), fills gx; padded elements (index >= dim) must give
+// zero terms and zero gradient.
+// ---------------------------------------------------------------------------------------------
+struct IidNormal {   // reference benches/sample.rs:49-62
+    double mu;
+    NM_DEV void init(const double* params, int) { mu = params[0]; }
+    template <int DPL>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            bool valid = elem_index(k) < dim;
+            double diff = x.a[k] - mu;
+            double term = -0.5 * diff * diff;
+            gx.a[k] = valid ? -diff : 0.0;
+            acc = acc + (valid ? term : 0.0);
+        }
+        return wave_sum(acc);
+    }
+};
+
+struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/transform/mod.rs:98-112
+    const double* prec;
+    double norm;
+    NM_DEV void init(const double* params, int dim) {
+        prec = params;
+        double acc = 0.0;
+        for (int m = 0; m < (dim + 127) / 128; ++m)
+            for (int j = 0; j < 2; ++j) {
+                int d = 2 * (m * 64 + lane_id()) + j;
+                acc = acc + (d < dim ? dlog(params[d < dim ? d : 0]) : 0.0);
+            }
+        double log_det_p = wave_sum(acc);
+        norm = -0.5 * ((double)dim * dlog(6.283185307179586) - log_det_p);
+    }
+    template <int DPL>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            bool valid = d < dim;
+            double p = valid ? prec[d] : 0.0;
+            double px = p * x.a[k];
+            gx.a[k] = valid ? -px : 0.0;
+            acc = acc + (valid ? x.a[k] * px : 0.0);
+        }
+        double quad = -0.5 * wave_sum(acc);
+        return quad + norm;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-wave context: everything a chain keeps in registers / SGPRs while its kernel runs
+// ---------------------------------------------------------------------------------------------
+struct PendEntry {        // a completed sub-tree of `other` waiting for its sibling (one per level); lives in LDS
+    double log_size;
+    double cand_logp, cand_ke;
+    int64_t cand_idx;
+    int cand_slot;        // -2: live registers, -1: the trajectory's initial point, >=0: pool slot C[slot]
+    int pad;
+};
+
+template <int DPL>
+struct WaveShared {       // LDS of one wave (one block = one wave)
+    uint32_t rng_cache[RNG_CACHE_WORDS];
+    double stage[64 * DPL];
+    PendEntry pend[MAX_MAXDEPTH + 1];
+};
+
+template <int DPL, class Dens>
+struct ChainCtx {
+    const KParams& P;
+    Dens dens;
+    DevRng rng;
+    ZigTables zig;
+    double* vec;        // this chain's slot array
+    double* stage;      // LDS [64*DPL] staging for normals
+    PendEntry* pend;    // LDS
+    int dim;
+    int maxdepth_cfg;
+    ChainScalars sc;
+    Tile<DPL> sig, mu;  // mass matrix in registers for the whole kernel
+
+    __device__ ChainCtx(const KParams& p) : P(p) {}
+    NM_DEV double* slot(int s) const { return vec + (size_t)s * P.dpad; }
+};
+
+template <int DPL, class Dens>
+NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chain) {
+    const KParams& P = C.P;
+    C.dim = (int)P.dim;
+    C.maxdepth_cfg = (int)P.s.maxdepth;
+    C.vec = P.vec + (size_t)chain * P.nslot * P.dpad;
+    C.stage = sh.stage;
+    C.pend = sh.pend;
+    C.zig = {P.zig_x, P.zig_f};
+    C.sc = P.sc[chain];
+    C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
+    C.dens.init(P.logp_params, C.dim);
+}
+template <int DPL, class Dens>
+NM_DEV void ctx_end(ChainCtx<DPL, Dens>& C, uint64_t chain) {
+    C.sc.rng_pos = C.rng.pos;
+    if (lane_id() == 0) C.P.sc[chain] = C.sc;
+}
+
+// the live phase-space point
+template <int DPL>
+struct Live {
+    Tile<DPL> z, v, g, gx;   // g = transformed gradient g_z, gx = untransformed gradient
+    double logp, ke;
+    int64_t idx;
+};
+
+// One leapfrog in registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
+//   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
+//   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
+template <int DPL, class Dens>
+NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, Live<DPL>& s, double epsilon, Tile<DPL>* x_out) {
+    const double half = epsilon / 2.;
+    Tile<DPL> x;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        s.v.a[k] = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+        s.z.a[k] = __builtin_fma(epsilon, s.v.a[k], s.z.a[k]);
+        double t = s.z.a[k] * C.sig.a[k];
+        x.a[k] = __builtin_fma(1.0, C.mu.a[k], t);
+    }
+    s.logp = C.dens.template eval<DPL>(x, s.gx, C.dim);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        s.g.a[k] = s.gx.a[k] * C.sig.a[k];
+        s.v.a[k] = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+        acc = __builtin_fma(s.v.a[k], s.v.a[k], acc);
+    }
+    s.ke = 0.5 * wave_sum(acc);
+    if (x_out) *x_out = x;
+}
+
+// AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:112-166)
+struct AcceptCollector {
+    double initial_energy, sum, sum_sym, max_energy_error;
+    uint64_t count;
+    NM_DEV void register_init(double e0) { initial_energy = e0; sum = 0.; sum_sym = 0.; count = 0; max_energy_error = 0.; }
+    NM_DEV void register_divergent() { sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf(); }
+    NM_DEV void register_ok(double end_energy) {
+        double diff = initial_energy - end_energy;
+        double e = dexp(fmin_rs(diff, 0.));
+        sum = sum + e;
+        sum_sym = sum_sym + 2. * e / (1. + dexp(diff));
+        count += 1;
+        if (__builtin_fabs(diff) > __builtin_fabs(max_energy_error)) max_energy_error = diff;
+    }
+    NM_DEV double mean() const { return sum / (double)count; }
+    NM_DEV double mean_sym() const { return sum_sym / (double)count; }
+};
+
+// is_turning partial sums (reference transformed_hamiltonian.rs:617-638, scalar_prods3 util.rs:221-347):
+// s = (z_end + 0) - z_start; t1 += s*v_start; t2 += s*v_end
+NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, double& t2) {
+    double s = (ze + 0.0) - zs;
+    t1 = __builtin_fma(s, vs, t1);
+    t2 = __builtin_fma(s, ve, t2);
+}
+
+// momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577)
+template <int DPL, class Dens>
+NM_DEV void sample_velocity(ChainCtx<DPL, Dens>& C, Tile<DPL>& v) {
+    fill_standard_normals(C.rng, C.stage, C.dim, C.zig);
+    const double2* st = reinterpret_cast<const double2*>(C.stage) + lane_id();
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        double2 q = st[m * 64];
+        v.a[2 * m] = elem_index(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+        v.a[2 * m + 1] = elem_index(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+    }
+    __syncthreads();
+}
+
+template <int DPL>
+NM_DEV double kinetic(const Tile<DPL>& v) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc = __builtin_fma(v.a[k], v.a[k], acc);
+    return 0.5 * wave_sum(acc);
+}
+
+// Σ ln(t) over valid elements (array_sum_ln, cpu_math.rs:300-304)
+template <int DPL, class Dens>
+NM_DEV double sum_ln_tile(const ChainCtx<DPL, Dens>& C, const Tile<DPL>& t) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        bool valid = elem_index(k) < C.dim;
+        acc = acc + (valid ? dlog(valid ? t.a[k] : 1.0) : 0.0);
+    }
+    return wave_sum(acc);
+}
+
+NM_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
+
+NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // DualAverage::new dual_avg.rs:44-53
+    sc.log_step = dlog(initial_step);
+    sc.log_step_adapted = dlog(initial_step);
+    sc.hbar = 0.;
+    sc.mu = dlog(10. * initial_step);
+    sc.da_count = 1;
+}
+
+// Hamiltonian::init_state at x with the current mass matrix (reference transformed_hamiltonian.rs:640-661,
+// check_all :310-324).  Fills st.z, st.g, st.gx, st.logp; returns false for BadInitGrad.
+template <int DPL, class Dens>
+NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Live<DPL>& st) {
+    st.logp = C.dens.template eval<DPL>(x, st.gx, C.dim);
+    Tile<DPL> isig;
+    load_tile(isig, C.slot(P_ISIG));
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);     // compute_transformed_position diagonal.rs:233-246
+        st.z.a[k] = isig.a[k] * t;
+        st.g.a[k] = st.gx.a[k] * C.sig.a[k];                  // compute_transformed_gradient :258-265
+        bool valid = elem_index(k) < C.dim;
+        ok = ok && (!valid || (is_finite(st.z.a[k]) && is_finite(st.g.a[k]) && st.g.a[k] != 0.0 &&
+                               is_finite(st.gx.a[k]) && is_finite(x.a[k])));
+    }
+    return wave_all(ok);
+}
+
+// stepsize::Strategy::init (reference src/stepsize/adapt.rs:91-199): step-size search at `x`.
+template <int DPL, class Dens>
+NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
+    Live<DPL> st;
+    if (!init_state(C, x, st)) return NM_CHAIN_BAD_INIT;
+    const double logdet = C.sc.mm_logdet;
+    sample_velocity(C, st.v);                                   // initialize_trajectory(resample) :687-736
+    const double ke0 = kinetic(st.v);
+    const double e0 = ke0 - (st.logp + logdet);
+    AcceptCollector col;
+    C.sc.step_size = s.initial_step;
+    int dir = 0;
+    for (int it = 0; it < 101; ++it) {
+        Live<DPL> o;
+        o.z = st.z; o.v = st.v; o.g = st.g;
+        const int sign = it == 0 ? 1 : dir;
+        col.register_init(e0);
+        leapfrog(C, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr);
+        const double energy = o.ke - (o.logp + logdet);
+        const double err = energy - e0;
+        if ((err > 1000.0) | !is_finite(err)) {                 // hard-coded 1000.0 (adapt.rs:118, :142)
+            if (it > 0) C.sc.step_size = s.initial_step;
+            return NM_CHAIN_OK;
+        }
+        col.register_ok(energy);
+        const double accept = col.mean();
+        if (it == 0) { dir = accept > s.target_accept ? 1 : -1; continue; }
+        if (dir > 0) {
+            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { dual_average_reset(C.sc, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size *= 2.;
+        } else {
+            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { dual_average_reset(C.sc, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size /= 2.;
+        }
+    }
+    C.sc.step_size = s.initial_step;
+    return NM_CHAIN_OK;
+}
+
+// update_stepsize (reference src/stepsize/adapt.rs:235-267)
+template <int DPL, class Dens>
+NM_DEV void update_stepsize(ChainCtx<DPL, Dens>& C, bool use_best_guess) {
+    const nm_settings& s = C.P.s;
+    double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
+                                                      : (use_best_guess ? dexp(C.sc.log_step_adapted) : dexp(C.sc.log_step));
+    if (s.has_jitter) {
+        double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
+        double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
+        C.sc.step_size = step * j;
+    } else {
+        C.sc.step_size = step;
+    }
+}
+// DualAverage::advance (reference src/stepsize/dual_avg.rs:55-64)
+template <int DPL, class Dens>
+NM_DEV void update_estimator(ChainCtx<DPL, Dens>& C, bool late) {
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) return;
+    ChainScalars& sc = C.sc;
+    const double accept_stat = late ? sc.last_sym_mean_tree_accept : sc.last_mean_tree_accept;
+    const double w = 1. / ((double)sc.da_count + s.da_t0);
+    sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
+    sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
+    sc.log_step = fmin_rs(sc.log_step, C.P.ln_max_step);
+    const double mk = dexp(-s.da_k * dlog((double)sc.da_count));
+    sc.log_step_adapted = mk * sc.log_step + (1. - mk) * sc.log_step_adapted;
+    sc.da_count += 1;
+}
+
+// RunningVariance::add_sample (reference adapt/diagonal.rs:31-44, array_update_variance cpu_math.rs:605-631)
+template <int DPL, class Dens>
+NM_DEV void running_variance_add(ChainCtx<DPL, Dens>& C, int slot_mean, int slot_var, uint64_t new_count, const Tile<DPL>& value) {
+    if (new_count == 1) { store_tile(value, C.slot(slot_mean)); return; }
+    const double diff_scale = 1.0 / (double)new_count;
+    Tile<DPL> mean, var;
+    load_tile(mean, C.slot(slot_mean));
+    load_tile(var, C.slot(slot_var));
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        double diff = value.a[k] - mean.a[k];
+        mean.a[k] = mean.a[k] + diff * diff_scale;
+        var.a[k] = var.a[k] + diff * diff;
+    }
+    store_tile(mean, C.slot(slot_mean));
+    store_tile(var, C.slot(slot_var));
+}
+
+// writes sigma/inv_sigma/mu (registers + HBM), logdet, id
+template <int DPL, class Dens>
+NM_DEV void commit_mass_matrix(ChainCtx<DPL, Dens>& C, const Tile<DPL>& isig) {
+    store_tile(C.sig, C.slot(P_SIG));
+    store_tile(isig, C.slot(P_ISIG));
+    store_tile(C.mu, C.slot(P_MU));
+    C.sc.mm_logdet = sum_ln_tile(C, isig);
+    C.sc.mm_id += 1;
+}
+
+// DiagMassMatrix::update_diag_grad (reference diagonal.rs:133-154, cpu_math.rs:710-738)
+template <int DPL, class Dens>
+NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, const Tile<DPL>& gx) {
+    Tile<DPL> isig;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        bool valid = elem_index(k) < C.dim;
+        double val = 1.0 / clampd(__builtin_fabs(gx.a[k]), 1e-20, 1e20);
+        if (!is_finite(val)) val = 1.0;
+        double sd = __builtin_sqrt(val), isd = __builtin_sqrt(1.0 / val);
+        double var = sd * sd;
+        double mean = var * gx.a[k];
+        mean = __builtin_fma(1.0, x.a[k], mean);
+        C.sig.a[k] = valid ? sd : 0.0;
+        isig.a[k] = valid ? isd : 0.0;
+        C.mu.a[k] = valid ? mean : 0.0;
+    }
+    commit_mass_matrix(C, isig);
+}
+
+// Strategy::adapt -> update_diag_draw_grad / update_diag_draw (reference adapt/diagonal.rs:161-196,
+// diagonal.rs:85-131, cpu_math.rs:633-708).  Returns did_change.
+template <int DPL, class Dens>
+NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
+    if (C.sc.cnt_fg < 3) return false;
+    Tile<DPL> isig, dm, dv;
+    load_tile(isig, C.slot(P_ISIG));
+    load_tile(dm, C.slot(E_DM));
+    load_tile(dv, C.slot(E_DV));
+    if (C.P.s.use_grad_based_estimate) {
+        Tile<DPL> gm, gv;
+        load_tile(gm, C.slot(E_GM));
+        load_tile(gv, C.slot(E_GV));
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            bool valid = elem_index(k) < C.dim;
+            double val = __builtin_sqrt(dv.a[k] / gv.a[k]);
+            double sd = C.sig.a[k], isd = isig.a[k];
+            if (!(!is_finite(val) | (val == 0.0))) {
+                val = clampd(val, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            double var = sd * sd;
+            double mean = var * gm.a[k];
+            mean = __builtin_fma(1.0, dm.a[k], mean);
+            C.sig.a[k] = valid ? sd : 0.0;
+            isig.a[k] = valid ? isd : 0.0;
+            C.mu.a[k] = valid ? mean : 0.0;
+        }
+    } else {
+        const double scale = 1.0 / (double)C.sc.cnt_fg;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            bool valid = elem_index(k) < C.dim;
+            double d = dv.a[k] * scale;
+            double sd = C.sig.a[k], isd = isig.a[k];
+            if (!(!is_finite(d) | (d == 0.0))) {
+                double val = clampd(d, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            C.sig.a[k] = valid ? sd : 0.0;
+            isig.a[k] = valid ? isd : 0.0;
+            C.mu.a[k] = valid ? dm.a[k] : 0.0;
+        }
+    }
+    commit_mass_matrix(C, isig);
+    return true;
+}
+
+template <int DPL, class Dens>
+NM_DEV void copy_slot(ChainCtx<DPL, Dens>& C, int dst, int src) {
+    Tile<DPL> t;
+    load_tile(t, C.slot(src));
+    store_tile(t, C.slot(dst));
+}
+
+// GlobalStrategy::adapt (reference src/adapt_strategy.rs:121-222).  x, gx = chosen draw.
+template <int DPL, class Dens>
+NM_DEV uint64_t adapt(ChainCtx<DPL, Dens>& C, const AcceptCollector& col, bool is_good,
+                      const Tile<DPL>& x, const Tile<DPL>& gx) {
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const uint64_t draw = sc.draw_count;
+    sc.last_mean_tree_accept = col.mean();                       // step_size.update (stepsize/adapt.rs:201-209)
+    sc.last_sym_mean_tree_accept = col.mean_sym();
+    sc.last_n_steps = col.count;
+    sc.last_max_energy_error = col.max_energy_error;
+    if (draw >= s.num_tune) {
+        update_stepsize(C, true);
+        sc.tuning = 0;
+        return NM_CHAIN_OK;
+    }
+    if (draw < C.P.final_step_size_window) {
+        const bool is_early = draw < C.P.early_end;
+        if (!is_early && draw == C.P.early_end)
+            sc.current_window_size = sc.current_window_size > sc.cnt_bg ? sc.current_window_size : sc.cnt_bg;
+        const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
+        if (is_good) {                                           // update_estimators (adapt/diagonal.rs:134-141)
+            sc.cnt_fg += 1;
+            sc.cnt_bg += 1;
+            running_variance_add(C, E_DM, E_DV, sc.cnt_fg, x);
+            running_variance_add(C, E_GM, E_GV, sc.cnt_fg, gx);
+            running_variance_add(C, B_DM, B_DV, sc.cnt_bg, x);
+            running_variance_add(C, B_GM, B_GV, sc.cnt_bg, gx);
+        }
+        const bool could_switch = sc.cnt_bg >= switch_freq;
+        uint64_t next_window_size;
+        if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
+        else {
+            // (current_window_size as f64 * growth).round() as u64 : round half away from zero
+            double gv = (double)sc.current_window_size * s.mass_matrix_window_growth;
+            double fl = __builtin_floor(gv);
+            uint64_t grown = (uint64_t)((gv - fl >= 0.5) ? fl + 1.0 : fl);
+            next_window_size = sc.current_window_size + 1 > grown ? sc.current_window_size + 1 : grown;
+        }
+        const bool is_late = next_window_size + draw > C.P.final_step_size_window;
+        bool force_update = false;
+        if (could_switch && !is_late) {                          // switch (adapt/diagonal.rs:143-148)
+            copy_slot(C, E_DM, B_DM); copy_slot(C, E_DV, B_DV);
+            copy_slot(C, E_GM, B_GM); copy_slot(C, E_GV, B_GV);
+            sc.cnt_fg = sc.cnt_bg;
+            sc.cnt_bg = 0;
+            Tile<DPL> zero;
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) zero.a[k] = 0.0;
+            store_tile(zero, C.slot(B_DM)); store_tile(zero, C.slot(B_DV));
+            store_tile(zero, C.slot(B_GM)); store_tile(zero, C.slot(B_GV));
+            force_update = true;
+            if (!is_early) sc.current_window_size = next_window_size;
+        }
+        bool did_change = false;
+        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = mass_matrix_adapt(C);
+        if (did_change) sc.last_update = draw;
+        update_estimator(C, is_late);
+        if (did_change & (sc.has_initial_mass_matrix != 0)) {
+            sc.has_initial_mass_matrix = 0;
+            return stepsize_init(C, x);
+        }
+        update_stepsize(C, false);
+        return NM_CHAIN_OK;
+    }
+    update_estimator(C, true);
+    update_stepsize(C, draw == s.num_tune - 1);
+    return NM_CHAIN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tree.  Iterative restatement of NutsTree::extend (reference src/nuts.rs:108-170).
+//
+// A doubling of the main tree at depth j generates 2^j leaves in one direction.  Leaf n (0-based) closes
+// the sub-trees of levels 1..t, t = number of trailing one bits of n; each closing is a merge of the pending
+// level-(k-1) sub-tree A with the just-completed level-(k-1) sub-tree B (whose last leaf is the live point).
+// The end points the U-turn tests need are addressed by level, with no copies:
+//   even leaf n  -> F[tz(n)]  (F[j] for n = 0): first leaf of every sub-tree that starts at n
+//   odd  leaf n  -> L[to(n)]                  : last leaf of the pending level-to(n) sub-tree
+//   merge at level k at leaf n: A.first = F[tz(n+1-2^k)] (F[j] if that leaf is 0), A.last = L[k-1], B.first = F[k-1].
+// Candidates are renamed, never copied: a pool slot index travels with the (log_size, candidate) scalars.
+// ---------------------------------------------------------------------------------------------
+struct CandRef { int slot; double logp, ke; int64_t idx; };
+enum TreeStop { STOP_NONE = 0, STOP_TURNING = 1, STOP_DIVERGING = 2, STOP_FATAL = 3 };
+
+// multinomial merge weights (reference merge_into, src/nuts.rs:172-207).  Returns take_B.
+template <int DPL, class Dens>
+NM_DEV bool merge_weights(ChainCtx<DPL, Dens>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
+    total = logaddexp(a_log_size, b_log_size);
+    const double self_log_size = is_main ? a_log_size : total;
+    if (b_log_size >= self_log_size) return true;
+    int b = C.rng.random_bool(dexp(b_log_size - self_log_size));
+    if (b < 0) { fatal = true; return false; }
+    return b == 1;
+}
+
+struct DrawResult {
+    uint64_t depth;
+    bool diverging, reached_maxdepth, has_divergence_energy_error;
+    double divergence_energy_error;
+    CandRef chosen;
+    double e0;
+};
+
+template <int DPL>
+NM_DEV const double2* lane_ptr(const double* base) { return reinterpret_cast<const double2*>(base) + lane_id(); }
+
+// nuts::draw (reference src/nuts.rs:281-388).  On entry the chain's current point is in HBM slots P_*.
+// On exit, if R.chosen.slot != -1, cur.z / cur.gx hold the chosen point's z and g_x.
+template <int DPL, class Dens>
+NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, DrawResult& R, Live<DPL>& cur) {
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const int MD = C.maxdepth_cfg;
+    // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
+    sample_velocity(C, cur.v);
+    if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
+        Tile<DPL> x, isig;
+        load_tile(x, C.slot(P_X));
+        load_tile(cur.gx, C.slot(P_GX));
+        load_tile(isig, C.slot(P_ISIG));
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);
+            cur.z.a[k] = isig.a[k] * t;
+            cur.g.a[k] = cur.gx.a[k] * C.sig.a[k];
+        }
+        store_tile(cur.z, C.slot(P_Z));
+        store_tile(cur.g, C.slot(P_GZ));
+        sc.logdet = sc.mm_logdet;
+        sc.transform_id = sc.mm_id;
+    } else {
+        load_tile(cur.z, C.slot(P_Z));
+        load_tile(cur.g, C.slot(P_GZ));
+    }
+    const double logdet = sc.logdet;
+    const double ke_init = kinetic(cur.v);
+    const double e0 = ke_init - (sc.logp + logdet);
+    R.e0 = e0;
+    col.register_init(e0);
+    // main tree = the initial point
+    store_tile(cur.z, C.slot(ML_Z)); store_tile(cur.v, C.slot(ML_V)); store_tile(cur.g, C.slot(ML_G));
+    store_tile(cur.z, C.slot(MR_Z)); store_tile(cur.v, C.slot(MR_V)); store_tile(cur.g, C.slot(MR_G));
+    uint64_t depth = 0;
+    double log_size = 0.;
+    int64_t left_idx = 0, right_idx = 0;
+    CandRef mc = {-1, sc.logp, ke_init, 0};
+    uint32_t used = 0;   // candidate-pool occupancy bitmask
+
+    uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
+    if (s.has_target_integration_time) {                         // src/nuts.rs:300-320
+        double q = __builtin_ceil(s.target_integration_time / sc.step_size);
+        uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
+        uint64_t fl = 63 - __builtin_clzll(max_steps | 1ull);
+        uint64_t ce = ((max_steps & (max_steps - 1)) == 0) ? fl : fl + 1;
+        mindepth = fl > s.mindepth ? fl : s.mindepth;
+        uint64_t xd = ce > mindepth ? ce : mindepth;
+        maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
+    }
+    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false;
+    R.divergence_energy_error = 0.;
+    bool fatal = false;
+    bool in_extra = false;        // inside the `for _ in 0..extra_doublings` loop of src/nuts.rs:350-371
+    uint64_t extra_left = 0;
+    int sign = 1;
+
+    for (;;) {
+        bool check;
+        if (!in_extra) {
+            if (!(depth < maxdepth)) { R.reached_maxdepth = true; break; }
+            sign = C.rng.random_bool_std() ? 1 : -1;             // src/nuts.rs:334, hamiltonian.rs:111-118
+            check = (s.check_turning != 0) && !(depth < mindepth);
+        } else {
+            if (extra_left == 0) break;
+            extra_left -= 1;
+            check = false;
+        }
+        const bool fwd = sign > 0;
+        // ---- one doubling: build `other` with 2^depth leaves from the edge
+        load_tile(cur.z, C.slot(fwd ? MR_Z : ML_Z));
+        load_tile(cur.v, C.slot(fwd ? MR_V : ML_V));
+        load_tile(cur.g, C.slot(fwd ? MR_G : ML_G));
+        const int64_t edge_idx = fwd ? right_idx : left_idx;
+        const uint64_t nleaf = 1ull << depth;
+        const uint32_t used_before = used;
+        int stop = STOP_NONE;
+        double sub_log_size = 0.;
+        CandRef sub_cand = {-2, 0., 0., 0};
+        const double epsilon = (double)sign * sc.step_size * 1.0;
+        for (uint64_t n = 0; n < nleaf; ++n) {
+            leapfrog(C, cur, epsilon, (Tile<DPL>*)nullptr);
+            cur.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
+            const double energy = cur.ke - (cur.logp + logdet);
+            const double err = energy - e0;
+            if ((err > s.max_energy_error) | !is_finite(err)) {   // transformed_hamiltonian.rs:590-610
+                col.register_divergent();
+                R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err;
+                stop = STOP_DIVERGING;
+                break;
+            }
+            col.register_ok(energy);
+            sub_log_size = -err;                                  // single_step, src/nuts.rs:235
+            sub_cand = {-2, cur.logp, cur.ke, cur.idx};
+            const int t = (int)__builtin_ctzll(~n);               // trailing ones of n: merges at levels 1..t
+            for (int k = 1; k <= t; ++k) {
+                const PendEntry A = C.pend[k - 1];
+                bool turning = false;
+                if (check) {
+                    const uint64_t a_first = n + 1 - (1ull << k);
+                    const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
+                    const double2* afz = lane_ptr<DPL>(C.slot(slot_F(fa)));
+                    const double2* afv = lane_ptr<DPL>(C.slot(slot_F(fa) + 1));
+                    double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+                    if (k == 1) {
+                        // depth-0 siblings: the single test is_turning(A, B = live point)
+#pragma unroll
+                        for (int m = 0; m < DPL / 2; ++m) {
+                            double2 az = afz[m * 64], av = afv[m * 64];
+                            if (fwd) {
+                                turn_acc(az.x, av.x, cur.z.a[2 * m], cur.v.a[2 * m], s1, s2);
+                                turn_acc(az.y, av.y, cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], s1, s2);
+                            } else {
+                                turn_acc(cur.z.a[2 * m], cur.v.a[2 * m], az.x, av.x, s1, s2);
+                                turn_acc(cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], az.y, av.y, s1, s2);
+                            }
+                        }
+                        wave_sum2(s1, s2);
+                        turning = (s1 < 0.) | (s2 < 0.);
+                    } else {
+                        // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
+                        const double2* alz = lane_ptr<DPL>(C.slot(slot_L(MD, k - 1)));
+                        const double2* alv = lane_ptr<DPL>(C.slot(slot_L(MD, k - 1) + 1));
+                        const double2* bfz = lane_ptr<DPL>(C.slot(slot_F(k - 1)));
+                        const double2* bfv = lane_ptr<DPL>(C.slot(slot_F(k - 1) + 1));
+#pragma unroll
+                        for (int m = 0; m < DPL / 2; ++m) {
+                            double2 az = afz[m * 64], av = afv[m * 64];
+                            double2 lz = alz[m * 64], lv = alv[m * 64];
+                            double2 bz = bfz[m * 64], bv = bfv[m * 64];
+                            const double cz0 = cur.z.a[2 * m], cz1 = cur.z.a[2 * m + 1];
+                            const double cv0 = cur.v.a[2 * m], cv1 = cur.v.a[2 * m + 1];
+                            if (fwd) {
+                                turn_acc(az.x, av.x, cz0, cv0, s1, s2); turn_acc(az.y, av.y, cz1, cv1, s1, s2);
+                                turn_acc(lz.x, lv.x, cz0, cv0, s3, s4); turn_acc(lz.y, lv.y, cz1, cv1, s3, s4);
+                                turn_acc(az.x, av.x, bz.x, bv.x, s5, s6); turn_acc(az.y, av.y, bz.y, bv.y, s5, s6);
+                            } else {
+                                turn_acc(cz0, cv0, az.x, av.x, s1, s2); turn_acc(cz1, cv1, az.y, av.y, s1, s2);
+                                turn_acc(cz0, cv0, lz.x, lv.x, s3, s4); turn_acc(cz1, cv1, lz.y, lv.y, s3, s4);
+                                turn_acc(bz.x, bv.x, az.x, av.x, s5, s6); turn_acc(bz.y, bv.y, az.y, av.y, s5, s6);
+                            }
+                        }
+                        wave_sum2(s1, s2); wave_sum2(s3, s4); wave_sum2(s5, s6);
+                        turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+                    }
+                }
+                double total;
+                const bool take = merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
+                if (take) {
+                    if (A.cand_slot >= 0) used &= ~(1u << A.cand_slot);
+                } else {
+                    if (sub_cand.slot >= 0) used &= ~(1u << sub_cand.slot);
+                    sub_cand = {A.cand_slot, A.cand_logp, A.cand_ke, A.cand_idx};
+                }
+                sub_log_size = total;
+                if (fatal) { stop = STOP_FATAL; break; }
+                if (turning) { stop = STOP_TURNING; break; }
+            }
+            if (stop != STOP_NONE) break;
+            if (n + 1 < nleaf) {
+                // this leaf's (z, v) is an end point of the pending level-t sub-tree
+                const int zslot = t == 0 ? slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n)) : slot_L(MD, t);
+                store_tile(cur.z, C.slot(zslot));
+                store_tile(cur.v, C.slot(zslot + 1));
+                if (sub_cand.slot == -2) {
+                    const int p = (int)__builtin_ctz(~used);
+                    used |= 1u << p;
+                    store_tile(cur.z, C.slot(slot_C(MD, p)));
+                    store_tile(cur.gx, C.slot(slot_C(MD, p) + 1));
+                    sub_cand.slot = p;
+                }
+                PendEntry e;
+                e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
+                e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
+                C.pend[t] = e;
+            }
+        }
+        if (stop == STOP_FATAL) { fatal = true; break; }
+        if (stop == STOP_DIVERGING) { used = used_before; break; }     // tree unchanged (src/nuts.rs:123, :134-136)
+        if (stop == STOP_TURNING) {                                    // `other` discarded (src/nuts.rs:131-133)
+            used = used_before;
+            if (!in_extra) { in_extra = true; extra_left = s.extra_doublings; }
+            continue;
+        }
+        // ---- `other` is complete: top-level turning tests, then merge into the main tree
+        bool turning = false;
+        if (check) {
+            double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+            const double2* mlz = lane_ptr<DPL>(C.slot(ML_Z));
+            const double2* mlv = lane_ptr<DPL>(C.slot(ML_V));
+            const double2* mrz = lane_ptr<DPL>(C.slot(MR_Z));
+            const double2* mrv = lane_ptr<DPL>(C.slot(MR_V));
+            if (depth == 0) {
+#pragma unroll
+                for (int m = 0; m < DPL / 2; ++m) {
+                    if (fwd) {
+                        double2 az = mlz[m * 64], av = mlv[m * 64];
+                        turn_acc(az.x, av.x, cur.z.a[2 * m], cur.v.a[2 * m], s1, s2);
+                        turn_acc(az.y, av.y, cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], s1, s2);
+                    } else {
+                        double2 az = mrz[m * 64], av = mrv[m * 64];
+                        turn_acc(cur.z.a[2 * m], cur.v.a[2 * m], az.x, av.x, s1, s2);
+                        turn_acc(cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], az.y, av.y, s1, s2);
+                    }
+                }
+                wave_sum2(s1, s2);
+                turning = (s1 < 0.) | (s2 < 0.);
+            } else {
+                const double2* ofz = lane_ptr<DPL>(C.slot(slot_F((int)depth)));
+                const double2* ofv = lane_ptr<DPL>(C.slot(slot_F((int)depth) + 1));
+#pragma unroll
+                for (int m = 0; m < DPL / 2; ++m) {
+                    double2 lz = mlz[m * 64], lv = mlv[m * 64];
+                    double2 rz = mrz[m * 64], rv = mrv[m * 64];
+                    double2 oz = ofz[m * 64], ov = ofv[m * 64];
+                    const double cz0 = cur.z.a[2 * m], cz1 = cur.z.a[2 * m + 1];
+                    const double cv0 = cur.v.a[2 * m], cv1 = cur.v.a[2 * m + 1];
+                    if (fwd) {
+                        // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = live
+                        turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
+                        turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
+                        turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6);
+                    } else {
+                        // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = live
+                        turn_acc(cz0, cv0, rz.x, rv.x, s1, s2); turn_acc(cz1, cv1, rz.y, rv.y, s1, s2);
+                        turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
+                        turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
+                    }
+                }
+                wave_sum2(s1, s2); wave_sum2(s3, s4); wave_sum2(s5, s6);
+                turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+            }
+        }
+        double total;
+        const bool take = merge_weights(C, log_size, sub_log_size, true, total, fatal);
+        if (fatal) break;
+        if (take) {
+            if (mc.slot >= 0) used &= ~(1u << mc.slot);
+            if (sub_cand.slot == -2) {
+                const int p = (int)__builtin_ctz(~used);
+                used |= 1u << p;
+                store_tile(cur.z, C.slot(slot_C(MD, p)));
+                store_tile(cur.gx, C.slot(slot_C(MD, p) + 1));
+                sub_cand.slot = p;
+            }
+            mc = sub_cand;
+        } else if (sub_cand.slot >= 0) {
+            used &= ~(1u << sub_cand.slot);
+        }
+        store_tile(cur.z, C.slot(fwd ? MR_Z : ML_Z));
+        store_tile(cur.v, C.slot(fwd ? MR_V : ML_V));
+        store_tile(cur.g, C.slot(fwd ? MR_G : ML_G));
+        if (fwd) right_idx = cur.idx; else left_idx = cur.idx;
+        depth += 1;
+        log_size = total;
+        if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
+    }
+    R.depth = depth;
+    R.chosen = mc;
+    if (fatal) return NM_CHAIN_LOGP_FATAL;
+    if (mc.slot >= 0) {
+        load_tile(cur.z, C.slot(slot_C(MD, mc.slot)));
+        load_tile(cur.gx, C.slot(slot_C(MD, mc.slot) + 1));
+    }
+    return NM_CHAIN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NutsChain::draw (reference src/chain.rs:151-188) + the scalar stats of expanded_draw (:190-232)
+// ---------------------------------------------------------------------------------------------
+template <int DPL, class Dens>
+NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    AcceptCollector col;
+    DrawResult R;
+    Live<DPL> cur;
+    uint64_t st = nuts_transition(C, col, R, cur);
+    nm_draw_stats out;
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    if (st != NM_CHAIN_OK) {
+        sc.status = st;
+        if (P.out_stats && lane_id() == 0) {
+            nm_draw_stats z = {};
+            z.draw = sc.draw_count; z.chain = P.chain_id_offset + chain; z.chain_status = st;
+            P.out_stats[t_out * P.n_chains + chain] = z;
+        }
+        return;
+    }
+    Tile<DPL> x, gx, z, gz;
+    if (R.chosen.slot == -1) {                                   // the draw is the trajectory's initial point
+        load_tile(x, C.slot(P_X)); load_tile(gx, C.slot(P_GX));
+        load_tile(z, C.slot(P_Z)); load_tile(gz, C.slot(P_GZ));
+    } else {
+        z = cur.z; gx = cur.gx;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            double tt = z.a[k] * C.sig.a[k];                      // same operations as inside the leapfrog => same bits
+            x.a[k] = __builtin_fma(1.0, C.mu.a[k], tt);
+            gz.a[k] = gx.a[k] * C.sig.a[k];
+        }
+        store_tile(x, C.slot(P_X)); store_tile(gx, C.slot(P_GX));
+        store_tile(z, C.slot(P_Z)); store_tile(gz, C.slot(P_GZ));
+        sc.logp = R.chosen.logp;
+    }
+    // DrawGradCollector::register_draw (adapt/diagonal.rs:73-83)
+    const int64_t idx = R.chosen.idx;
+    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
+    if (P.out_positions) {
+        double* dst = P.out_positions + (t_out * P.n_chains + chain) * P.dim;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            if (d < C.dim) dst[d] = x.a[k];
+        }
+    }
+    double fd = 0.0;                                             // sq_norm_sum (cpu_math.rs:235-243)
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) fd = fd + (z.a[k] + gz.a[k]) * (z.a[k] + gz.a[k]);
+    fd = wave_sum(fd);
+    const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
+    const int64_t tid = sc.transform_id;
+    sc.total_steps += col.count;
+    uint64_t ast = adapt(C, col, is_good, x, gx);
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.index_in_trajectory = idx; out.transformation_index = tid;
+    out.step_size = sc.step_size;
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size : dexp(sc.log_step_adapted);
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
+    out.chain_status = ast;
+    if (P.out_stats && lane_id() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: one block = one wave = one chain
+// ---------------------------------------------------------------------------------------------
+template <int DPL, class Dens>
+__global__ __launch_bounds__(64) void nuts_draw_kernel(const KParams P) {
+    __shared__ WaveShared<DPL> sh;
+    const uint64_t chain = blockIdx.x;
+    if (chain >= P.n_chains) return;
+    ChainCtx<DPL, Dens> C(P);
+    ctx_begin(C, sh, chain);
+    if (C.sc.status == NM_CHAIN_OK) {
+        load_tile(C.sig, C.slot(P_SIG));
+        load_tile(C.mu, C.slot(P_MU));
+        for (uint64_t t = 0; t < P.n_draws; ++t) {
+            chain_draw(C, chain, t);
+            if (C.sc.status != NM_CHAIN_OK) break;
+        }
+    }
+    ctx_end(C, chain);
+}
+
+// NutsChain::set_position (reference src/chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119)
+template <int DPL, class Dens>
+__global__ __launch_bounds__(64) void nuts_init_kernel(const KParams P) {
+    __shared__ WaveShared<DPL> sh;
+    const uint64_t chain = blockIdx.x;
+    if (chain >= P.n_chains) return;
+    ChainCtx<DPL, Dens> C(P);
+    ctx_begin(C, sh, chain);
+    ChainScalars& sc = C.sc;
+    dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
+    Tile<DPL> x, gx;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        int d = elem_index(k);
+        x.a[k] = d < C.dim ? P.x0[chain * P.dim + d] : 0.0;
+    }
+    // init_state_untransformed (transformed_hamiltonian.rs:663-685)
+    (void)C.dens.template eval<DPL>(x, gx, C.dim);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) ok = ok && is_finite(gx.a[k]) && is_finite(x.a[k]);
+    uint64_t status = NM_CHAIN_OK;
+    if (!wave_all(ok)) status = NM_CHAIN_BAD_INIT;
+    if (status == NM_CHAIN_OK) {
+        // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
+        store_tile(x, C.slot(E_DM)); store_tile(x, C.slot(B_DM));
+        store_tile(gx, C.slot(E_GM)); store_tile(gx, C.slot(B_GM));
+        sc.cnt_fg = 1; sc.cnt_bg = 1;
+        mass_matrix_from_grad(C, x, gx);
+        status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
+    }
+    if (status == NM_CHAIN_OK) {
+        Live<DPL> st;                                             // hamiltonian.init_state (chain.rs:147)
+        if (!init_state(C, x, st)) status = NM_CHAIN_BAD_INIT;
+        else {
+            store_tile(x, C.slot(P_X)); store_tile(st.gx, C.slot(P_GX));
+            store_tile(st.z, C.slot(P_Z)); store_tile(st.g, C.slot(P_GZ));
+            sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
+        }
+    }
+    sc.status = status;
+    ctx_end(C, chain);
+}
+
+}  // namespace nm

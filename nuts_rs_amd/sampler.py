@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's per-chain driver seam, batched over many chains.
+
+Reference interface being mirrored (pymc-devs/nuts-rs 0.18.3):
+  * `DiagNutsSettings` and its nested option structs           src/sampler.rs:199-239, :507-531, :630-634
+  * `Settings::new_chain(chain, math, rng) -> impl Chain`       src/sampler.rs:53-63, :745-772
+  * `Chain::{set_position, draw, dim}`                          src/chain.rs:24-42, :137-188
+  * `Progress`                                                  src/sampler.rs:165-174
+Names, argument meaning and error behaviour follow the reference; the only structural change is that one
+`ChainBatch` stands for `n_chains` independent `NutsChain`s that advance together on one MI355X.
+All arithmetic happens in libnuts_amd.so (HIP); this file only marshals arguments.
+"""
+import ctypes as C
+from dataclasses import dataclass, field, fields
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, check
+
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS = 0, 1, 2, 3
+STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
+
+
+@dataclass
+class DualAverageOptions:          # src/stepsize/dual_avg.rs:12-31
+    k: float = 0.75
+    t0: float = 10.0
+    gamma: float = 0.05
+    max_step_size: float = float(np.pi)
+
+
+@dataclass
+class StepSizeSettings:            # src/stepsize/adapt.rs:308-329
+    target_accept: float = 0.8
+    initial_step: float = 0.1
+    jitter: Optional[float] = 0.1
+    method: int = STEP_DUAL_AVERAGE          # StepSizeAdaptMethod::{DualAverage, Adam, Fixed(f64)}
+    fixed_step_size: float = 0.0
+    dual_average: DualAverageOptions = field(default_factory=DualAverageOptions)
+
+
+@dataclass
+class DiagAdaptExpSettings:        # src/transform/adapt/diagonal.rs:92-106
+    store_mass_matrix: bool = False
+    use_grad_based_estimate: bool = True
+
+
+@dataclass
+class EuclideanAdaptOptions:       # src/adapt_strategy.rs:41-69
+    step_size_settings: StepSizeSettings = field(default_factory=StepSizeSettings)
+    mass_matrix_options: DiagAdaptExpSettings = field(default_factory=DiagAdaptExpSettings)
+    early_window: float = 0.3
+    step_size_window: float = 0.15
+    mass_matrix_switch_freq: int = 80
+    early_mass_matrix_switch_freq: int = 10
+    mass_matrix_update_freq: int = 1
+    mass_matrix_window_growth: float = 1.5
+
+
+@dataclass
+class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
+    num_tune: int = 400
+    num_draws: int = 1000
+    maxdepth: int = 10
+    mindepth: int = 0
+    store_gradient: bool = False
+    store_unconstrained: bool = False
+    store_transformed: bool = False
+    max_energy_error: float = 1000.0
+    store_divergences: bool = False
+    adapt_options: EuclideanAdaptOptions = field(default_factory=EuclideanAdaptOptions)
+    check_turning: bool = True
+    target_integration_time: Optional[float] = None
+    num_chains: int = 6
+    seed: int = 0
+    extra_doublings: int = 0
+
+    def to_c(self) -> NmSettings:
+        s = NmSettings()
+        _lib.load().nm_settings_default(C.byref(s))
+        a, st = self.adapt_options, self.adapt_options.step_size_settings
+        s.num_tune, s.num_draws, s.maxdepth, s.mindepth = self.num_tune, self.num_draws, self.maxdepth, self.mindepth
+        s.max_energy_error = self.max_energy_error
+        s.check_turning = int(self.check_turning)
+        s.extra_doublings, s.seed, s.num_chains = self.extra_doublings, self.seed, self.num_chains
+        s.store_gradient, s.store_unconstrained = int(self.store_gradient), int(self.store_unconstrained)
+        s.store_transformed, s.store_divergences = int(self.store_transformed), int(self.store_divergences)
+        s.has_target_integration_time = int(self.target_integration_time is not None)
+        s.target_integration_time = self.target_integration_time or 0.0
+        s.early_window, s.step_size_window = a.early_window, a.step_size_window
+        s.mass_matrix_switch_freq = a.mass_matrix_switch_freq
+        s.early_mass_matrix_switch_freq = a.early_mass_matrix_switch_freq
+        s.mass_matrix_update_freq = a.mass_matrix_update_freq
+        s.mass_matrix_window_growth = a.mass_matrix_window_growth
+        s.store_mass_matrix = int(a.mass_matrix_options.store_mass_matrix)
+        s.use_grad_based_estimate = int(a.mass_matrix_options.use_grad_based_estimate)
+        s.target_accept, s.initial_step = st.target_accept, st.initial_step
+        s.has_jitter, s.jitter = int(st.jitter is not None), st.jitter or 0.0
+        s.step_size_method, s.fixed_step_size = st.method, st.fixed_step_size
+        s.da_k, s.da_t0, s.da_gamma = st.dual_average.k, st.dual_average.t0, st.dual_average.gamma
+        s.da_max_step_size = st.dual_average.max_step_size
+        return s
+
+
+@dataclass
+class Progress:                    # src/sampler.rs:165-174, one per chain
+    draw: int
+    chain: int
+    diverging: bool
+    tuning: bool
+    step_size: float
+    num_steps: int
+
+
+@dataclass
+class LogpSpec:
+    """A registered device density (the device-side stand-in for a `CpuLogpFunc`, src/math/cpu_math.rs:885-891)."""
+    kind: int
+    dim: int
+    params: np.ndarray
+
+    @staticmethod
+    def iid_normal(dim, mu=3.0):
+        return LogpSpec(LOGP_IID_NORMAL, dim, np.array([mu], dtype=np.float64))
+
+    @staticmethod
+    def diag_normal(precision_diag):
+        p = np.ascontiguousarray(precision_diag, dtype=np.float64)
+        return LogpSpec(LOGP_DIAG_NORMAL, len(p), p)
+
+    def to_c(self):
+        self._keep = np.ascontiguousarray(self.params, dtype=np.float64)
+        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data)
+
+
+class ChainBatch:
+    """`n_chains` NUTS chains on one GPU: the batched `settings.new_chain(...)` of the reference."""
+
+    def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
+                 chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0):
+        self.settings = settings
+        self.logp = logp
+        self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
+        self.chain_id_offset = chain_id_offset
+        L = _lib.load()
+        cfg = NmEngineConfig()
+        L.nm_engine_config_default(C.byref(cfg))
+        cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
+        self._cs = settings.to_c()
+        self._cl = logp.to_c()
+        h = C.c_void_p()
+        check(L.nm_engine_create(C.byref(self._cs), C.byref(self._cl), self.n_chains, C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().nm_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def dim(self):
+        return self.logp.dim
+
+    def init_positions_uniform(self):
+        """x0 ~ U(-1,1) from each chain's outer generator: `CpuMath::init_position` in Sampler order."""
+        x0 = np.empty((self.n_chains, self.logp.dim))
+        check(_lib.load().nm_init_positions_uniform(self.settings.seed, self.chain_id_offset, self.n_chains,
+                                                    self.logp.dim, x0.ctypes.data))
+        return x0
+
+    def set_position(self, x0, raise_on_error=True):
+        """`Chain::set_position` for every chain; x0 is [n_chains, dim].  Returns per-chain status codes."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if x0.shape != (self.n_chains, self.logp.dim):
+            raise ValueError(f"x0 must have shape {(self.n_chains, self.logp.dim)}")
+        status = np.zeros(self.n_chains, dtype=np.uint64)
+        rc = _lib.load().nm_engine_set_positions(self._h, x0.ctypes.data, status.ctypes.data)
+        if rc != 0 and raise_on_error:
+            check(rc)
+        return status
+
+    def draw(self):
+        """One `Chain::draw` per chain -> (positions [n_chains, dim], [Progress])."""
+        pos, st = self.draw_many(1)
+        prog = [Progress(int(r["draw"]), int(r["chain"]), bool(r["diverging"]), bool(r["tuning"]),
+                         float(r["step_size"]), int(r["n_steps"])) for r in st[0]]
+        return pos[0], prog
+
+    def draw_many(self, n_draws, positions=True, stats=True):
+        """n_draws draws of every chain; returns host arrays ([n_draws, n_chains, dim], stats [n_draws, n_chains])."""
+        pos = np.empty((n_draws, self.n_chains, self.logp.dim)) if positions else None
+        st = np.zeros((n_draws, self.n_chains), dtype=STATS_DTYPE) if stats else None
+        check(_lib.load().nm_engine_draw_to_host(self._h, n_draws, pos.ctypes.data if positions else None,
+                                                 st.ctypes.data if stats else None))
+        return pos, st
+
+    def draw_device(self, n_draws, d_positions=0, d_stats=0, sync=True):
+        """n_draws draws with results left in caller-provided device buffers (raw pointers, e.g. tensor.data_ptr())."""
+        L = _lib.load()
+        fn = L.nm_engine_draw if sync else L.nm_engine_draw_async
+        check(fn(self._h, n_draws, C.c_void_p(d_positions or None), C.c_void_p(d_stats or None)))
+
+    def synchronize(self):
+        check(_lib.load().nm_engine_synchronize(self._h))
+
+    def positions(self):
+        out = np.empty((self.n_chains, self.logp.dim))
+        check(_lib.load().nm_engine_get_positions(self._h, out.ctypes.data))
+        return out
+
+    def gradients(self):
+        out = np.empty((self.n_chains, self.logp.dim))
+        check(_lib.load().nm_engine_get_gradients(self._h, out.ctypes.data))
+        return out
+
+    def mass_matrix(self):
+        sd, mu = np.empty((self.n_chains, self.logp.dim)), np.empty((self.n_chains, self.logp.dim))
+        check(_lib.load().nm_engine_get_mass_matrix(self._h, sd.ctypes.data, mu.ctypes.data))
+        return sd, mu
+
+    def step_sizes(self):
+        out = np.empty(self.n_chains)
+        check(_lib.load().nm_engine_get_step_sizes(self._h, out.ctypes.data))
+        return out
+
+    def counters(self):
+        steps, draws, launches = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ms = C.c_double()
+        check(_lib.load().nm_engine_get_counters(self._h, C.byref(steps), C.byref(draws), C.byref(ms),
+                                                 C.byref(launches)))
+        return dict(total_leapfrogs=steps.value, total_draws=draws.value, kernel_ms=ms.value,
+                    kernel_launches=launches.value)
+
+    def reset_counters(self):
+        check(_lib.load().nm_engine_reset_counters(self._h))
+
+    def stream(self):
+        return _lib.load().nm_engine_stream(self._h)
+
+
+def sample(settings: DiagNutsSettings, logp: LogpSpec, x0=None, chain_id_offset=0, device=-1):
+    """The reference's `Sampler` loop for every chain (src/sampler.rs:1120-1199): init, num_tune + num_draws draws.
+
+    Returns (positions [num_tune+num_draws, n_chains, dim], stats)."""
+    batch = ChainBatch(settings, logp, settings.num_chains, chain_id_offset, device)
+    if x0 is None:
+        x0 = batch.init_positions_uniform()
+    batch.set_position(x0)
+    out = batch.draw_many(settings.num_tune + settings.num_draws)
+    batch.close()
+    return out

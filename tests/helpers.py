@@ -1,0 +1,51 @@
+"""Shared helpers for the parity tests: run the same configuration on the HIP engine and on the CPU oracle."""
+import numpy as np
+
+import nuts_rs_amd as N
+
+STAT_FIELDS_EXACT = ["draw", "chain", "depth", "maxdepth_reached", "diverging", "tuning", "n_steps",
+                     "index_in_trajectory", "transformation_index", "chain_status"]
+STAT_FIELDS_FLOAT = ["step_size", "step_size_bar", "mean_tree_accept", "mean_tree_accept_sym", "max_energy_error",
+                     "logp", "energy", "energy_error", "fisher_distance"]
+
+
+def oracle_settings(O, settings: N.DiagNutsSettings):
+    """DiagNutsSettings -> the oracle's Settings struct (same field names)."""
+    c = settings.to_c()
+    s = O.Settings()
+    for name, _ in O.Settings._fields_:
+        setattr(s, name, getattr(c, name))
+    return s
+
+
+def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0):
+    b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane)
+    status = b.set_position(x0, raise_on_error=False)
+    pos, st = b.draw_many(n_draws) if (status == 0).all() else (None, None)
+    extra = dict(status=status)
+    if pos is not None:
+        sd, mu = b.mass_matrix()
+        extra.update(stds=sd, mean=mu, step_sizes=b.step_sizes(), x=b.positions(), gx=b.gradients(),
+                     counters=b.counters())
+    b.close()
+    return pos, st, extra
+
+
+def run_oracle(O, settings, logp, n_chains, x0, n_draws, chain_id_offset=0, gpu_threads=64, cfg=None, n_threads=8):
+    cfg = cfg or O.gpu_cfg(gpu_threads)
+    return O.run(oracle_settings(O, settings), logp.kind, logp.dim, logp.params, cfg, n_chains, x0, n_draws,
+                 chain_offset=chain_id_offset, n_threads=n_threads)
+
+
+def assert_bit_exact(pos_g, st_g, pos_o, st_o):
+    """Draw-for-draw, bit-for-bit: positions and every statistic."""
+    for f in STAT_FIELDS_EXACT:
+        bad = np.argwhere(st_g[f] != st_o[f])
+        assert bad.size == 0, f"stat {f} differs first at (draw, chain) = {bad[0]}: gpu {st_g[f][tuple(bad[0])]} oracle {st_o[f][tuple(bad[0])]}"
+    for f in STAT_FIELDS_FLOAT + ["divergence_energy_error"]:
+        a, b = st_g[f].view(np.uint64), st_o[f].view(np.uint64)
+        both_nan = np.isnan(st_g[f]) & np.isnan(st_o[f])
+        bad = np.argwhere((a != b) & ~both_nan)
+        assert bad.size == 0, f"stat {f} differs first at (draw, chain) = {bad[0]}: gpu {st_g[f][tuple(bad[0])]!r} oracle {st_o[f][tuple(bad[0])]!r}"
+    bad = np.argwhere(pos_g.view(np.uint64) != pos_o.view(np.uint64))
+    assert bad.size == 0, f"positions differ first at (draw, chain, dim) = {bad[0]}"
