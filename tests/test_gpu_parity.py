@@ -24,3 +24,148 @@ def test_k1_readme_config_bit_exact(oracle):
     # behavioural envelope of the reference's own tests (src/adapt_strategy.rs:367-435): converged, no divergences
     assert st_g["diverging"].sum() == 0
     assert abs(pos_g[s.num_tune:].mean() - 3.0) < 0.1
+
+
+def _diag_settings(**kw):
+    return N.DiagNutsSettings(**kw)
+
+
+PARITY_CASES = [
+    # (id, settings kwargs, dim, n_chains, n_draws, density, dims_per_lane)
+    ("dim100_defaults", dict(seed=1, num_tune=120, num_draws=60), 100, 6, 180, "iid", 0),
+    ("dim64_edge", dict(seed=2, num_tune=60), 64, 3, 90, "iid", 0),
+    ("dim65_pad", dict(seed=3, num_tune=60), 65, 3, 90, "iid", 0),
+    ("dim1_scalar", dict(seed=4, num_tune=60), 1, 5, 120, "iid", 0),
+    ("dim130_dpl4", dict(seed=5, num_tune=60), 130, 3, 90, "iid", 4),
+    ("dim10_dpl16", dict(seed=6, num_tune=60), 10, 3, 90, "iid", 16),
+    ("dim300_dpl8", dict(seed=7, num_tune=50), 300, 3, 70, "iid", 8),
+    ("dim1024_dpl16", dict(seed=8, num_tune=40), 1024, 4, 55, "iid", 16),
+    ("maxdepth3_readme", dict(seed=9, num_tune=100, maxdepth=3), 10, 4, 150, "iid", 0),
+    ("mindepth2", dict(seed=10, num_tune=50, mindepth=2), 20, 4, 80, "iid", 0),
+    ("extra_doublings", dict(seed=11, num_tune=50, extra_doublings=2, maxdepth=6), 20, 4, 80, "iid", 0),
+    ("no_check_turning", dict(seed=12, num_tune=30, check_turning=False, maxdepth=4), 12, 3, 50, "iid", 0),
+    ("target_time", dict(seed=13, num_tune=50, target_integration_time=2.0), 20, 4, 80, "iid", 0),
+    ("ragged_scales", dict(seed=14, num_tune=150), 40, 8, 220, "diag", 0),
+    ("low_energy_threshold", dict(seed=15, num_tune=50, max_energy_error=0.3), 30, 6, 80, "iid", 0),
+]
+
+
+@pytest.mark.parametrize("case", PARITY_CASES, ids=[c[0] for c in PARITY_CASES])
+def test_chain_parity_bit_exact(oracle, case):
+    """Draw-for-draw bit parity across register tilings, padding edges, tree options and ragged depths."""
+    _, kw, dim, n_chains, n_draws, dens, dpl = case
+    s = _diag_settings(num_chains=n_chains, **kw)
+    rng = np.random.default_rng(kw["seed"])
+    if dens == "iid":
+        logp = N.LogpSpec.iid_normal(dim, 3.0)
+    else:
+        logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-6, 6, dim)))        # scales e^-3 .. e^3: deep, ragged trees
+    x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
+    pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl)
+    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws)
+    assert failed == 0 and (ex["status"] == 0).all()
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    assert ex["counters"]["total_leapfrogs"] == steps
+    if case[0] == "low_energy_threshold":
+        assert st_g["diverging"].sum() > 0          # the divergence path was exercised
+    if case[0] == "ragged_scales":
+        assert len(np.unique(st_g["depth"])) >= 4   # ragged depths across chains/draws
+
+
+def test_step_size_options_parity(oracle):
+    """Fixed step size and jitter None (stepsize/adapt.rs:27, :259-266)."""
+    for st_kw in (dict(method=N.STEP_FIXED, fixed_step_size=0.4), dict(jitter=None), dict(target_accept=0.95)):
+        a = N.EuclideanAdaptOptions(step_size_settings=N.StepSizeSettings(**st_kw))
+        s = N.DiagNutsSettings(num_chains=3, seed=21, num_tune=60, adapt_options=a)
+        logp = N.LogpSpec.iid_normal(16, 3.0)
+        x0 = oracle.init_positions_uniform(21, 0, 3, 16)
+        pos_g, st_g, ex = run_engine(s, logp, 3, x0, 90)
+        pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, 3, x0, 90)
+        assert failed == 0
+        assert_bit_exact(pos_g, st_g, pos_o, st_o)
+
+
+def test_draw_variance_estimator_parity(oracle):
+    """use_grad_based_estimate = false (update_diag_draw, transform/diagonal.rs:85-105)."""
+    a = N.EuclideanAdaptOptions(mass_matrix_options=N.DiagAdaptExpSettings(use_grad_based_estimate=False))
+    s = N.DiagNutsSettings(num_chains=3, seed=22, num_tune=100, adapt_options=a)
+    logp = N.LogpSpec.diag_normal(np.array([1.0, 100.0, 0.01, 4.0, 1.0, 9.0]))
+    x0 = oracle.init_positions_uniform(22, 0, 3, 6)
+    pos_g, st_g, ex = run_engine(s, logp, 3, x0, 130)
+    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, 3, x0, 130)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+
+
+def test_chain_sharding_is_invisible(oracle):
+    """Chains are independent units: chain 5 gives the same draws whether it is local chain 5 of one
+    engine or local chain 1 of an engine that starts at global id 4 — the multi-GPU partition cannot change results."""
+    s = N.DiagNutsSettings(num_chains=8, seed=31, num_tune=40)
+    logp = N.LogpSpec.iid_normal(24, 3.0)
+    x0 = oracle.init_positions_uniform(31, 0, 8, 24)
+    pos_a, st_a, _ = run_engine(s, logp, 8, x0, 60)
+    pos_b, st_b, _ = run_engine(s, logp, 4, x0[4:], 60, chain_id_offset=4)
+    assert (pos_a[:, 4:].view(np.uint64) == pos_b.view(np.uint64)).all()
+    assert (st_a["chain"][:, 4:] == st_b["chain"]).all() and (st_a["n_steps"][:, 4:] == st_b["n_steps"]).all()
+
+
+def test_incremental_draw_calls_equal_one_call(oracle):
+    """nm_engine_draw(n) then (m) == nm_engine_draw(n+m): all chain state lives on the device between calls."""
+    s = N.DiagNutsSettings(num_chains=4, seed=32, num_tune=30)
+    logp = N.LogpSpec.iid_normal(12, 3.0)
+    x0 = oracle.init_positions_uniform(32, 0, 4, 12)
+    b = N.ChainBatch(s, logp, 4)
+    b.set_position(x0)
+    parts = [b.draw_many(k)[0] for k in (1, 7, 20, 22)]
+    p2, progress = b.draw()
+    assert progress[0].draw == 50 and not progress[0].tuning and progress[2].chain == 2
+    b.close()
+    pos, _, _ = run_engine(s, logp, 4, x0, 51)
+    assert (np.concatenate(parts + [p2[None]]).view(np.uint64) == pos.view(np.uint64)).all()
+
+
+def test_bad_init_reported_per_chain(oracle):
+    """BadInitGrad (src/nuts.rs:21): a chain started exactly at the mode has a zero gradient."""
+    s = N.DiagNutsSettings(num_chains=3, seed=33)
+    logp = N.LogpSpec.iid_normal(8, 3.0)
+    x0 = oracle.init_positions_uniform(33, 0, 3, 8)
+    x0[1] = 3.0
+    b = N.ChainBatch(s, logp, 3)
+    status = b.set_position(x0, raise_on_error=False)
+    assert list(status) == [0, 1, 0]
+    with pytest.raises(N.NutsAmdError) as e:
+        b.set_position(x0)
+    assert e.value.status == 5
+    x0[1, 0] = np.nan
+    assert list(b.set_position(x0, raise_on_error=False)) == [0, 1, 0]
+    b.close()
+
+
+def test_k2_full_size_properties():
+    """BASELINE configs[1] at full size (4096 chains x dim 1024): size-independent properties instead of the oracle —
+    stationarity of N(3, I) (mean, variance, per-chain energy), warm-up reaching the target acceptance, no
+    post-warm-up divergences, and invariance of every chain to the batch it runs in."""
+    C_, D = 4096, 1024
+    s = N.DiagNutsSettings(num_chains=C_, seed=20260928, num_tune=400, num_draws=50)
+    b = N.ChainBatch(s, N.LogpSpec.iid_normal(D, 3.0), C_)
+    x0 = b.init_positions_uniform()
+    assert (b.set_position(x0) == 0).all()
+    b.draw_device(400)
+    pos, st = b.draw_many(50)
+    assert st["diverging"].sum() == 0 and (st["tuning"] == 0).all() and (st["chain_status"] == 0).all()
+    assert abs(pos.mean() - 3.0) < 2e-3 and abs(pos.var() - 1.0) < 5e-3
+    assert np.abs(pos.mean(axis=(0, 2)) - 3.0).max() < 0.05            # every chain is centred
+    assert abs(st["mean_tree_accept"].mean() - 0.8) < 0.05
+    sd, mu = b.mass_matrix()
+    assert abs(np.median(sd) - 1.0) < 0.1 and abs(np.median(mu) - 3.0) < 0.1
+    # logp of a stationary N(3, I_D) draw is -chi2_D / 2
+    assert abs(st["logp"].mean() + D / 2) < 1.0
+    sub_pos = pos[:, 100:104]
+    b.close()
+    s2 = N.DiagNutsSettings(num_chains=4, seed=20260928, num_tune=400, num_draws=50)
+    b2 = N.ChainBatch(s2, N.LogpSpec.iid_normal(D, 3.0), 4, chain_id_offset=100)
+    b2.set_position(x0[100:104])
+    b2.draw_device(400)
+    pos2, _ = b2.draw_many(50)
+    b2.close()
+    assert (sub_pos.view(np.uint64) == pos2.view(np.uint64)).all()

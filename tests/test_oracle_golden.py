@@ -1,0 +1,307 @@
+"""CPU tests that pin the oracle: every golden vector / known-answer test the reference's own tests hold for
+the hot path, the published ChaCha keystream vectors, the reference's behavioural envelopes,
+and the bounds between the oracle's two arithmetic modes."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_kats.json")) as f:
+    KATS = json.load(f)
+with open(os.path.join(HERE, "golden", "oracle_k1_pins.json")) as f:
+    K1 = json.load(f)
+
+
+def ulps(a, b):
+    a, b = np.float64(a), np.float64(b)
+    if np.isnan(a) and (np.isnan(b) or np.isinf(b)):
+        return 0
+    if np.isnan(b) and (np.isnan(a) or np.isinf(a)):
+        return 0
+    if a == b:
+        return 0
+    ia, ib = np.int64(a.view(np.int64)), np.int64(b.view(np.int64))
+    if ia < 0:
+        ia = np.int64(-(2 ** 63)) - ia
+    if ib < 0:
+        ib = np.int64(-(2 ** 63)) - ib
+    return abs(int(ia) - int(ib))
+
+
+# ---- RNG -------------------------------------------------------------------------------------------
+def test_chacha_published_keystream(oracle):
+    k = KATS["chacha_zero_key_block0"]
+    key = (C.c_uint32 * 8)()
+    out = (C.c_uint32 * 16)()
+    for rounds, name in ((20, "rounds20"), (8, "rounds8")):
+        oracle.lib().nmo_chacha_block(key, 0, 0, rounds, out)
+        assert bytes(out).hex() == k[name]
+
+
+def test_rng_word_stream_and_distributions(oracle):
+    L = oracle.lib()
+    key = bytes(range(32))
+    kb = (C.c_uint8 * 32).from_buffer_copy(key)
+    words = (C.c_uint32 * 40)()
+    L.nmo_rng_words(kb, 0, 40, words)
+    # block b = words 16b..16b+15 with counter b
+    k32 = (C.c_uint32 * 8).from_buffer_copy(key)
+    blk = (C.c_uint32 * 16)()
+    for b in range(2):
+        L.nmo_chacha_block(k32, b, 0, 8, blk)
+        assert list(blk) == list(words[16 * b:16 * b + 16])
+    w = list(words)
+    out = np.empty(8)
+    L.nmo_rng_samples(kb, 0, 0.0, 0.0, 8, out)       # bool: sign bit of one u32
+    assert [int(v) for v in out] == [1 if x >> 31 else 0 for x in w[:8]]
+    L.nmo_rng_samples(kb, 1, 0.0, 0.0, 8, out)       # f64: 53 high bits of lo|hi<<32
+    exp = [((w[2 * i] | (w[2 * i + 1] << 32)) >> 11) * 2.0 ** -53 for i in range(8)]
+    assert list(out) == exp
+    L.nmo_rng_samples(kb, 2, 0.25, 0.0, 8, out)      # Bernoulli(0.25): u64 < p * 2^64
+    assert [int(v) for v in out] == [1 if (w[2 * i] | (w[2 * i + 1] << 32)) < 2 ** 62 else 0 for i in range(8)]
+    L.nmo_rng_samples(kb, 3, 0.9, 1.1, 8, out)       # Uniform(0.9, 1.1)
+    assert ((out >= 0.9) & (out < 1.1)).all()
+
+
+def test_standard_normal_ziggurat(oracle):
+    L = oracle.lib()
+    x, f = np.empty(257), np.empty(257)
+    L.nmo_zig_tables(x, f)
+    assert x[1] == 3.654152885361008796 and x[256] == 0.0
+    assert abs(x[0] - 3.910757959537090045) < 1e-12          # v / f(r), the published ZIG_NORM_X[0]
+    assert (np.diff(x) < 0).all() and abs(f[256] - 1.0) < 1e-15
+    key = (C.c_uint8 * 32).from_buffer_copy(bytes(range(32)))
+    n = 200000
+    out = np.empty(n)
+    for cfg in (oracle.ref_cfg(), oracle.gpu_cfg()):
+        words = L.nmo_standard_normal_stream(C.byref(cfg), key, n, out)
+        assert 2 * n < words < 2.1 * n                       # ~1.2 % of samples take extra words
+        assert abs(out.mean()) < 0.01 and abs(out.std() - 1.0) < 0.01
+        assert abs((np.abs(out) > 3.0).mean() - 0.0027) < 0.0006
+        from scipy import stats
+        assert stats.kstest(out, "norm").pvalue > 1e-3
+
+
+def test_seed_from_u64_and_chain_keys(oracle):
+    k0, k1 = oracle.chain_key(0, 0), oracle.chain_key(0, 1)
+    assert k0 != k1 and len(k0) == 32
+    assert oracle.chain_key(0, 0) == k0 and oracle.chain_key(1, 0) != k0
+    x = oracle.init_positions_uniform(7, 3, 2, 5)
+    assert x.shape == (2, 5) and ((x >= -1) & (x < 1)).all()
+    # invariant to how chains are sharded over GPUs: position of chain 4 does not depend on offset
+    assert (oracle.init_positions_uniform(7, 4, 1, 5)[0] == x[1]).all()
+
+
+# ---- scalar math -----------------------------------------------------------------------------------
+def test_logaddexp_reference_kats(oracle):
+    k = KATS["logaddexp"]
+    for cfg in (oracle.ref_cfg(), oracle.gpu_cfg()):
+        la = lambda a, b: oracle.lib().nmo_logaddexp(C.byref(cfg), a, b)
+        for a, b, e in k["neginf_cases"]:
+            assert la(a, b) == e
+        assert la(-math.inf, -math.inf) == -math.inf
+        rng = np.random.default_rng(0)
+        pts = list(map(tuple, k["regression_xy"])) + [tuple(p) for p in rng.uniform(-10, 10, size=(2000, 2))]
+        for x, y in pts:
+            b = la(x, y)
+            assert abs(math.log(math.exp(x) + math.exp(y)) - b) < k["abs_tol_vs_naive"]
+            assert b == la(y, x)
+            assert la(x, -math.inf) == x
+            assert math.isnan(la(math.nan, x))
+
+
+def test_detmath_within_ulps_of_libm(oracle):
+    """The restated exp/ln (what the GPU runs) against this box's libm (what the reference would call)."""
+    L = oracle.lib()
+    det, ref = oracle.gpu_cfg(), oracle.ref_cfg()
+    rng = np.random.default_rng(1)
+    worst = {0: 0, 1: 0, 2: 0}
+    for x in np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-2, 2, 20000), rng.normal(0, 1e-5, 2000)]):
+        worst[0] = max(worst[0], ulps(L.nmo_scalar_fn(C.byref(det), 0, x, 0), L.nmo_scalar_fn(C.byref(ref), 0, x, 0)))
+    for x in np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.5, 2, 20000), [1.0, 2.0, 0.5]]):
+        worst[1] = max(worst[1], ulps(L.nmo_scalar_fn(C.byref(det), 1, x, 0), L.nmo_scalar_fn(C.byref(ref), 1, x, 0)))
+    for x in np.concatenate([np.exp(rng.uniform(-40, 0, 20000)), [1.0, 0.0]]):
+        worst[2] = max(worst[2], ulps(L.nmo_scalar_fn(C.byref(det), 2, x, 0), L.nmo_scalar_fn(C.byref(ref), 2, x, 0)))
+    assert worst[0] <= 1 and worst[1] <= 1 and worst[2] <= 4, worst
+    for x, e in ((0.0, 1.0), (-math.inf, 0.0), (math.inf, math.inf)):
+        assert L.nmo_scalar_fn(C.byref(det), 0, x, 0) == e
+    assert L.nmo_scalar_fn(C.byref(det), 1, 0.0, 0) == -math.inf and math.isnan(L.nmo_scalar_fn(C.byref(det), 1, -1.0, 0))
+    assert L.nmo_scalar_fn(C.byref(det), 1, 1.0, 0) == 0.0
+    # count^-k of dual averaging (dual_avg.rs:60) for the counts that occur
+    for c in range(1, 2000):
+        a, b = L.nmo_scalar_fn(C.byref(det), 6, float(c), -0.75), L.nmo_scalar_fn(C.byref(ref), 6, float(c), -0.75)
+        assert abs(a - b) <= 4e-15 * b   # exp(-k ln c): a few ulp of libm powf, far inside 1e-9
+
+
+# ---- vector primitives (reference src/math/util.rs:893-961, max_ulps = 32) ---------------------------
+def test_primitive_formulas_and_regressions(oracle):
+    L = oracle.lib()
+    R = KATS["primitive_regressions"]
+    rng = np.random.default_rng(2)
+    cases = [(np.array(c["x"]), np.array(c["y"]), c["a"]) for c in R["axpy"]]
+    for n in (0, 1, 3, 4, 7, 16, 17, 33):
+        cases.append((rng.normal(size=n), rng.normal(size=n), float(rng.normal())))
+    for x, y, a in cases:
+        y2 = y.copy()
+        L.nmo_axpy(np.ascontiguousarray(x), y2, a, len(x))
+        out = np.empty(len(x))
+        L.nmo_axpy_out(np.ascontiguousarray(x), np.ascontiguousarray(y), a, out, len(x))
+        for i in range(len(x)):
+            e = math.fma(a, x[i], y[i]) if hasattr(math, "fma") else float(np.float64(a) * x[i] + y[i])
+            assert ulps(y2[i], e) <= R["max_ulps"] and ulps(out[i], e) <= R["max_ulps"]
+    for c in R["axpy_out"]:
+        x, y = np.array(c["x"]), np.array(c["y"])
+        out = np.empty(len(x))
+        L.nmo_axpy_out(x, y, c["a"], out, len(x))
+        with np.errstate(all="ignore"):
+            exp = y + c["a"] * x
+        for i in range(len(x)):
+            assert ulps(out[i], exp[i]) <= R["max_ulps"]
+    for lanes in (1, 2, 4, 8):
+        for cfg in (oracle.ref_cfg(lanes), oracle.gpu_cfg()):
+            for c in R["vector_dot"]:
+                with np.errstate(all="ignore"):
+                    got = L.nmo_vector_dot(C.byref(cfg), np.array(c["x"]), np.array(c["y"]), len(c["x"]))
+                    exp = float(np.sum(np.array(c["x"]) * np.array(c["y"])))
+                assert ulps(got, exp) <= R["max_ulps"]
+            for c in R["scalar_prods3"]:
+                o = np.empty(2)
+                a = [np.array(c[k]) for k in ("x1", "x2", "x3", "y1", "y2")]
+                L.nmo_scalar_prods3(C.byref(cfg), *a, len(a[0]), o)
+                with np.errstate(all="ignore"):
+                    s = a[0] - a[1] + a[2]
+                    assert ulps(o[0], float(s @ a[3])) <= R["max_ulps"] and ulps(o[1], float(s @ a[4])) <= R["max_ulps"]
+            for n in (0, 1, 5, 16, 17, 100, 1024):
+                x, y = rng.normal(size=n), rng.normal(size=n)
+                got = L.nmo_vector_dot(C.byref(cfg), x, y, n)
+                assert abs(got - math.fsum(x * y)) <= 1e-12 * max(1.0, float(np.abs(x * y).sum()))
+                p1, n1, p2 = rng.normal(size=n), rng.normal(size=n), rng.normal(size=n)
+                o = np.empty(2)
+                L.nmo_scalar_prods3(C.byref(cfg), p1, n1, p2, x, y, n, o)
+                s = p1 - n1 + p2
+                assert abs(o[0] - math.fsum(s * x)) <= 1e-12 * max(1.0, float(np.abs(s * x).sum()))
+                assert abs(o[1] - math.fsum(s * y)) <= 1e-12 * max(1.0, float(np.abs(s * y).sum()))
+
+
+# ---- DiagMassMatrix known answers (reference src/transform/mod.rs:175-377) ---------------------------
+def _diag_kat(oracle, cfg, case):
+    s2 = np.array(case["sigma2"])
+    n = len(s2)
+    z, gz, xrt, sd, isd, mean = (np.empty(n) for _ in range(6))
+    logp, logdet, logp_rt, logdet_rt = (C.c_double() for _ in range(4))
+    rc = oracle.lib().nmo_diag_kat(C.byref(cfg), n, 1.0 / s2, np.array(case["draw_mean"]), np.array(case["grad_mean"]),
+                                   s2, 1.0 / s2, np.array(case["x"]), z, gz, C.byref(logp), C.byref(logdet), xrt,
+                                   C.byref(logp_rt), C.byref(logdet_rt), sd, isd, mean)
+    assert rc == 0
+    return dict(z=z, gz=gz, logp=logp.value, logdet=logdet.value, x_rt=xrt, logp_rt=logp_rt.value,
+                logdet_rt=logdet_rt.value, stds=sd, s2=s2)
+
+
+@pytest.mark.parametrize("mode", ["ref", "gpu"])
+def test_diag_mass_matrix_reference_kats(oracle, mode):
+    cfg = oracle.ref_cfg() if mode == "ref" else oracle.gpu_cfg()
+    c = KATS["diag_transform_position_and_gradient"]
+    r = _diag_kat(oracle, cfg, c)
+    assert np.abs(r["z"] - c["expect_z"]).max() <= c["tol"] and np.abs(r["gz"] - c["expect_gz"]).max() <= c["tol"]
+    assert abs(r["logdet"] - sum(-(0.5 * math.log(s)) for s in c["sigma2"])) < c["tol"]
+    std_normal_logp = -0.5 * (len(r["z"]) * math.log(math.tau) + float((r["z"] ** 2).sum()))
+    assert abs((r["logp"] - r["logdet"]) - std_normal_logp) < c["tol"]
+    c = KATS["diag_round_trip"]
+    r = _diag_kat(oracle, cfg, c)
+    assert np.abs(r["x_rt"] - c["x"]).max() <= c["tol"]
+    assert abs(r["logp"] - r["logp_rt"]) < c["tol"] and abs(r["logdet"] - r["logdet_rt"]) < c["tol"]
+    c = KATS["diag_nonzero_mean"]
+    r = _diag_kat(oracle, cfg, c)
+    assert np.abs(r["z"] - c["expect_z"]).max() <= c["tol"]
+
+
+def test_default_settings_match_reference(oracle):
+    s = oracle.default_settings()
+    for k, v in KATS["default_settings"].items():
+        if k != "source":
+            assert getattr(s, k) == v, k
+
+
+# ---- chain level -------------------------------------------------------------------------------------
+def test_k1_oracle_pins(oracle):
+    """Seeded K1 draws are stable (regression pin of the restatement; see make_golden.py for what this is not)."""
+    s = oracle.default_settings(seed=0, num_chains=4)
+    pos, st, steps, failed = oracle.run(s, oracle.LOGP_IID_NORMAL, 10, [3.0], oracle.gpu_cfg(64), 4,
+                                        np.zeros((4, 10)), 1400)
+    assert failed == 0 and steps == K1["total_steps"]
+    for i, t in enumerate(K1["draws"]):
+        for c in range(4):
+            assert [float(v).hex() for v in pos[t, c]] == K1["positions_hex"][i][c]
+            assert float(st["step_size"][t, c]).hex() == K1["step_size_hex"][i][c]
+            assert int(st["depth"][t, c]) == K1["depth"][i][c] and int(st["n_steps"][t, c]) == K1["n_steps"][i][c]
+
+
+def test_reference_behavioural_envelopes(oracle):
+    """The reference's own statistical tests, on the oracle in reference arithmetic (libm + SIMD-order sums):
+    src/adapt_strategy.rs:367-435 (N(30,1) x 10 from x0 = 1.5, num_tune 100: draw 201 within 5 of 30 and not diverging),
+    src/nuts.rs:399-419 (10 draws, not diverging), tests/sample_normal.rs:359-364 (6 chains x dim 100 defaults)."""
+    cfg = oracle.ref_cfg()
+    s = oracle.default_settings(num_tune=100, num_draws=100, seed=42)
+    ch = oracle.Chain(s, oracle.LOGP_IID_NORMAL, 10, [30.0], cfg, 0)
+    assert ch.set_position(np.full(10, 1.5)) == 0
+    for t in range(201):
+        pos, st, rc = ch.draw()
+        assert rc == 0
+    assert (np.abs(pos - 30.0) < 5).all() and not st["diverging"]      # exactly what the reference asserts
+    s = oracle.default_settings(seed=1)
+    pos, st, steps, failed = oracle.run(s, oracle.LOGP_IID_NORMAL, 100, [3.0], cfg, 6, np.zeros((6, 100)), 600)
+    assert failed == 0 and st["diverging"][400:].sum() == 0 and st["diverging"][:20].sum() == st["diverging"].sum()
+    post = pos[400:]
+    assert abs(post.mean() - 3.0) < 0.05 and abs(post.std() - 1.0) < 0.05
+    assert abs(st["mean_tree_accept"][400:].mean() - 0.8) < 0.08
+    assert (st["tuning"][:400] == 1).all() and (st["tuning"][400:] == 0).all()
+    assert (st["draw"][:, 0] == np.arange(600)).all()
+
+
+def test_oracle_modes_agree_within_north_star_tolerance(oracle):
+    """libm/SIMD-order (reference arithmetic) vs restated-exp/lane-order (GPU arithmetic): same trees, same draws
+    to 1e-9 relative on a seeded run (north_star's tolerance)."""
+    s = oracle.default_settings(seed=3)
+    x0 = oracle.init_positions_uniform(3, 0, 4, 50)
+    a = oracle.run(s, oracle.LOGP_IID_NORMAL, 50, [3.0], oracle.ref_cfg(), 4, x0, 500)
+    b = oracle.run(s, oracle.LOGP_IID_NORMAL, 50, [3.0], oracle.gpu_cfg(), 4, x0, 500)
+    assert (a[1]["depth"] == b[1]["depth"]).all() and (a[1]["n_steps"] == b[1]["n_steps"]).all()
+    assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(a[0]).max()
+    assert np.abs(a[1]["step_size"] - b[1]["step_size"]).max() <= 1e-9
+
+
+def test_bad_initial_gradient_is_rejected(oracle):
+    """init_state rejects a zero whitened gradient: starting iid normal at its mean."""
+    s = oracle.default_settings()
+    ch = oracle.Chain(s, oracle.LOGP_IID_NORMAL, 5, [3.0], oracle.gpu_cfg(), 0)
+    assert ch.set_position(np.full(5, 3.0)) == 1
+    ch2 = oracle.Chain(s, oracle.LOGP_IID_NORMAL, 5, [3.0], oracle.gpu_cfg(), 0)
+    assert ch2.set_position(np.array([0.0, np.nan, 0, 0, 0])) == 1
+
+
+def test_other_densities_gradients(oracle):
+    """finite-difference check of the densities this repo defines (funnel, 8 schools)."""
+    cfg = oracle.ref_cfg()
+    rng = np.random.default_rng(5)
+    y = [28., 8., -3., 7., -1., 1., 18., 12.]
+    sig = [15., 10., 16., 11., 9., 11., 10., 18.]
+    for kind, dim, params in ((oracle.LOGP_FUNNEL, 11, [0.0]), (oracle.LOGP_EIGHT_SCHOOLS, 10, y + sig),
+                              (oracle.LOGP_DIAG_NORMAL, 4, [1.0, 0.25, 4.0, 2.0])):
+        p = np.array(params)
+        x = rng.normal(size=dim) * 0.5
+        g = np.empty(dim)
+        lp = C.c_double()
+        assert oracle.lib().nmo_logp(C.byref(cfg), kind, dim, p, len(p), x, g, C.byref(lp)) == 0
+        for i in range(dim):
+            h = 1e-6
+            xp, xm = x.copy(), x.copy()
+            xp[i] += h
+            xm[i] -= h
+            lpp, lpm, gg = C.c_double(), C.c_double(), np.empty(dim)
+            oracle.lib().nmo_logp(C.byref(cfg), kind, dim, p, len(p), xp, gg, C.byref(lpp))
+            oracle.lib().nmo_logp(C.byref(cfg), kind, dim, p, len(p), xm, gg, C.byref(lpm))
+            assert abs((lpp.value - lpm.value) / (2 * h) - g[i]) < 1e-5 * max(1.0, abs(g[i]))
