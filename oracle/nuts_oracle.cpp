@@ -3,6 +3,7 @@
 // never contracts a*b+c; FMAs appear only where src/math/util.rs writes mul_add).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <thread>
 #include "nmo_nuts.hpp"
@@ -113,6 +114,53 @@ int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params,
         for (auto& t : th) t.join();
     }
     if (out_total_steps) *out_total_steps = steps.load();
+    return failed.load();
+}
+
+// Same as nmo_run but separates the first `n_warm` draws of every chain (warm-up) from the rest and reports the
+// CPU seconds and leapfrog steps of the post-warm-up part summed over chains (bench.py's cpu_baseline leg).
+int nmo_run_timed(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+                  const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_warm,
+                  uint64_t n_draws, uint64_t n_threads, double* out_warm_cpu_seconds, uint64_t* out_warm_steps,
+                  double* out_cpu_seconds, uint64_t* out_steps) {
+    std::atomic<uint64_t> next{0}, steps{0}, wsteps{0};
+    std::atomic<int> failed{0};
+    std::vector<double> secs(n_threads ? n_threads : 1, 0.0), wsecs(n_threads ? n_threads : 1, 0.0);
+    auto work = [&](uint64_t tid) {
+        for (;;) {
+            uint64_t c = next.fetch_add(1);
+            if (c >= n_chains) break;
+            uint8_t key[32];
+            nmo_chain_key(s->seed, chain_offset + c, key);
+            Density d = make_density(kind, dim, params, n_params);
+            Chain ch(*s, d, *cfg, chain_offset + c, key);
+            if (ch.set_position(x0 + c * dim) != ST_OK) { failed++; continue; }
+            DrawStats st;
+            auto t0 = std::chrono::steady_clock::now();
+            uint64_t w = 0;
+            for (uint64_t t = 0; t < n_warm; ++t) { if (ch.draw(nullptr, &st) != ST_OK) { failed++; break; } w += st.n_steps; }
+            auto t1 = std::chrono::steady_clock::now();
+            uint64_t local = 0;
+            for (uint64_t t = 0; t < n_draws; ++t) { if (ch.draw(nullptr, &st) != ST_OK) { failed++; break; } local += st.n_steps; }
+            auto t2 = std::chrono::steady_clock::now();
+            wsecs[tid] += std::chrono::duration<double>(t1 - t0).count();
+            secs[tid] += std::chrono::duration<double>(t2 - t1).count();
+            steps += local; wsteps += w;
+        }
+    };
+    if (n_threads <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint64_t i = 0; i < n_threads; ++i) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    double tot = 0, wtot = 0;
+    for (double v : secs) tot += v;
+    for (double v : wsecs) wtot += v;
+    if (out_cpu_seconds) *out_cpu_seconds = tot;
+    if (out_warm_cpu_seconds) *out_warm_cpu_seconds = wtot;
+    if (out_steps) *out_steps = steps.load();
+    if (out_warm_steps) *out_warm_steps = wsteps.load();
     return failed.load();
 }
 

@@ -97,6 +97,11 @@ def lib():
     L.nmo_run.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                           C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_uint64), C.c_uint64]
+    L.nmo_run_timed.restype = C.c_int
+    L.nmo_run_timed.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
+                                C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_uint64, C.c_uint64,
+                                C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                C.POINTER(C.c_uint64)]
     L.nmo_logaddexp.restype = C.c_double
     L.nmo_logaddexp.argtypes = [C.POINTER(MathCfg), C.c_double, C.c_double]
     L.nmo_scalar_fn.restype = C.c_double
@@ -204,3 +209,16 @@ def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0,
                            x0, n_draws, pos.ctypes.data if pos is not None else None,
                            st.ctypes.data if st is not None else None, C.byref(steps), n_threads)
     return pos, st, steps.value, failed
+
+
+def run_timed(settings, kind, dim, params, cfg, n_chains, x0, n_warm, n_draws, chain_offset=0, n_threads=1):
+    """CPU-baseline leg: per-chain tasks on n_threads host threads; returns post-warm-up (cpu_seconds_sum, steps)."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    ws, secs = C.c_double(), C.c_double()
+    wsteps, steps = C.c_uint64(), C.c_uint64()
+    failed = lib().nmo_run_timed(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains,
+                                 chain_offset, x0, n_warm, n_draws, n_threads, C.byref(ws), C.byref(wsteps),
+                                 C.byref(secs), C.byref(steps))
+    return dict(failed=failed, warm_cpu_seconds=ws.value, warm_steps=wsteps.value, cpu_seconds=secs.value,
+                steps=steps.value)
