@@ -136,29 +136,32 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 // ---------------------------------------------------------------------------------------------
 // kernel dispatch
 // ---------------------------------------------------------------------------------------------
-enum KernelKind { K_INIT, K_DRAW };
 
+enum KernelKind { K_INIT, K_DRAW, K_QUERY };   // K_QUERY: resident blocks per CU of the draw kernel
+
+// grid = number of waves; for K_QUERY *occ receives hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
 template <int DPL, class Dens>
-static hipError_t launch_t(KernelKind kind, const KParams& P, hipStream_t stream) {
-    dim3 grid((unsigned)P.n_chains), block(64);
+static hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_waves, hipStream_t stream, int* occ) {
+    if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, Dens>, 64, 0);
+    dim3 grid(grid_waves), block(64);
     if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, Dens>), grid, block, 0, stream, P);
     else hipLaunchKernelGGL((nuts_draw_kernel<DPL, Dens>), grid, block, 0, stream, P);
     return hipGetLastError();
 }
 template <class Dens>
-static hipError_t launch_d(int dpl, KernelKind kind, const KParams& P, hipStream_t stream) {
+static hipError_t launch_d(int dpl, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
     switch (dpl) {
-    case 2: return launch_t<2, Dens>(kind, P, stream);
-    case 4: return launch_t<4, Dens>(kind, P, stream);
-    case 8: return launch_t<8, Dens>(kind, P, stream);
-    case 16: return launch_t<16, Dens>(kind, P, stream);
+    case 2: return launch_t<2, Dens>(kind, P, grid, stream, occ);
+    case 4: return launch_t<4, Dens>(kind, P, grid, stream, occ);
+    case 8: return launch_t<8, Dens>(kind, P, grid, stream, occ);
+    case 16: return launch_t<16, Dens>(kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }
-static hipError_t launch(uint64_t logp_kind, int dpl, KernelKind kind, const KParams& P, hipStream_t stream) {
+static hipError_t launch(uint64_t logp_kind, int dpl, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr) {
     switch (logp_kind) {
-    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, kind, P, stream);
-    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, kind, P, stream);
+    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, kind, P, grid, stream, occ);
+    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }
@@ -212,7 +215,9 @@ struct nm_engine {
     int device = 0;
     bool positioned = false;
     KParams P;
-    double* d_vec = nullptr;
+    double* d_pvec = nullptr;     // [n_chains][NUM_PSLOT][dpad]
+    double* d_svec = nullptr;     // [n_waves][nsslot][dpad]
+    unsigned n_waves = 0;         // resident waves of the draw kernel = its grid
     ChainScalars* d_sc = nullptr;
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
@@ -227,7 +232,8 @@ struct nm_engine {
 
 static void engine_free(nm_engine* e) {
     if (!e) return;
-    if (e->d_vec) (void)hipFree(e->d_vec);
+    if (e->d_pvec) (void)hipFree(e->d_pvec);
+    if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
     if (e->d_zig) (void)hipFree(e->d_zig);
     if (e->d_params) (void)hipFree(e->d_params);
@@ -271,7 +277,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl;
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl;
-    const uint64_t nslot = (uint64_t)num_slots((int)s.maxdepth);
+    const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
 #define E_TRY(expr)                                                                                 \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
@@ -280,9 +286,22 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     E_TRY(hipEventCreate(&e->ev0));
     E_TRY(hipEventCreate(&e->ev1));
-    const size_t vec_bytes = (size_t)n_chains * nslot * dpad * sizeof(double);
-    E_TRY(hipMalloc(&e->d_vec, vec_bytes));
-    E_TRY(hipMemsetAsync(e->d_vec, 0, vec_bytes, e->stream));
+    {   // one wave per resident slot of the chip (waves stride over the chains); tree scratch belongs to the wave
+        int occ = 0, cus = 0;
+        KParams dummy;
+        memset(&dummy, 0, sizeof dummy);
+        E_TRY(launch(logp->kind, dpl, K_QUERY, dummy, 0, nullptr, &occ));
+        E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
+        if (cfg.reserved[0]) resident = cfg.reserved[0];          // test/tuning override: waves in the grid
+        e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
+    }
+    const size_t pvec_bytes = (size_t)n_chains * NUM_PSLOT * dpad * sizeof(double);
+    const size_t svec_bytes = (size_t)e->n_waves * nsslot * dpad * sizeof(double);
+    E_TRY(hipMalloc(&e->d_pvec, pvec_bytes));
+    E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));
+    E_TRY(hipMalloc(&e->d_svec, svec_bytes));
+    E_TRY(hipMemsetAsync(e->d_svec, 0, svec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_sc, n_chains * sizeof(ChainScalars)));
     E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
     E_TRY(hipMalloc(&e->d_params, logp->n_params * sizeof(double)));
@@ -320,8 +339,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     KParams& P = e->P;
     memset(&P, 0, sizeof P);
     P.s = s;
-    P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nslot = nslot;
-    P.vec = e->d_vec; P.sc = e->d_sc; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
+    P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nsslot = nsslot;
+    P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
     P.early_end = early_end;
     P.final_step_size_window = s.num_tune >= step_size_window ? s.num_tune - step_size_window : 0;   // saturating_sub
     P.ln_max_step = dlog(s.da_max_step_size);
@@ -354,7 +373,7 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     KParams P = e->P;
-    HIP_TRY(launch(e->logp_kind, e->dpl, K_INIT, P, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, K_INIT, P, e->n_waves, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
@@ -380,7 +399,7 @@ extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double
     KParams P = e->P;
     P.n_draws = n_draws; P.out_positions = d_positions; P.out_stats = d_stats;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(launch(e->logp_kind, e->dpl, K_DRAW, P, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, K_DRAW, P, e->n_waves, e->stream));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
     e->kernel_launches += 1;
@@ -432,8 +451,8 @@ static nm_status read_slot(nm_engine* e, int slot, double* h_out) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     const KParams& P = e->P;
     // strided copy: row c = vec[c][slot][0..dim)
-    HIP_TRY(hipMemcpy2D(h_out, e->dim * sizeof(double), e->d_vec + (size_t)slot * P.dpad,
-                        P.nslot * P.dpad * sizeof(double), e->dim * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(h_out, e->dim * sizeof(double), e->d_pvec + (size_t)slot * P.dpad,
+                        (size_t)NUM_PSLOT * P.dpad * sizeof(double), e->dim * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
     return NM_OK;
 }
 extern "C" nm_status nm_engine_get_positions(nm_engine* e, double* h_x) { return read_slot(e, P_X, h_x); }
@@ -510,15 +529,15 @@ __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
     C.dens.init(A.P.logp_params, dim);
     load_row(C.sig, A.sigma + i * dim, dim);
     load_row(C.mu, A.mu + i * dim, dim);
-    Live<DPL> s;
-    load_row(s.z, A.z + i * dim, dim);
-    load_row(s.v, A.v + i * dim, dim);
-    load_row(s.g, A.gz + i * dim, dim);
-    Tile<DPL> x;
-    leapfrog(C, s, A.eps[i], &x);
+    Pt<DPL> s0, s;
+    load_row(s0.z, A.z + i * dim, dim);
+    load_row(s0.v, A.v + i * dim, dim);
+    load_row(s0.g, A.gz + i * dim, dim);
+    Tile<DPL> x, gx;
+    leapfrog(C, s0, s, A.eps[i], &x, &gx);
     store_row(s.z, A.z_out + i * dim, dim); store_row(s.v, A.v_out + i * dim, dim);
     store_row(s.g, A.gz_out + i * dim, dim); store_row(x, A.x_out + i * dim, dim);
-    store_row(s.gx, A.gx_out + i * dim, dim);
+    store_row(gx, A.gx_out + i * dim, dim);
     if (lane_id() == 0) {
         A.logp_out[i] = s.logp;
         A.ke_out[i] = s.ke;

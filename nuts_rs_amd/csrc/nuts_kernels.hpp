@@ -1,14 +1,17 @@
 // nuts_kernels.hpp — the many-chain NUTS kernels for gfx950 (MI355X).
 //
-// ONE WAVEFRONT = ONE CHAIN.  A wave keeps the live phase-space point (z, v, g_z, g_x) and the chain's mass
-// matrix (sigma, mu) in VGPRs (DPL doubles per lane per vector), runs the whole NUTS transition — momentum
-// refresh, every doubling of the tree with the fused leapfrog + logp/grad, the U-turn / divergence tests, the
-// multinomial merges, then the per-draw adaptation — and loops over draws without returning to the host.
+// ONE WAVEFRONT = ONE CHAIN AT A TIME.  A wave keeps two live phase-space points (ping-pong: even leaf E,
+// odd leaf O; each z, v, g_z) and the chain's mass matrix (sigma, mu) in VGPRs (DPL doubles per lane per
+// vector), runs the whole NUTS transition — momentum refresh, every doubling of the tree with the fused
+// leapfrog + logp/grad, the U-turn / divergence tests, the multinomial merges, then the per-draw adaptation —
+// and loops over draws and over its share of the chains without returning to the host.
 // All per-chain control flow (tree depth, termination, RNG consumption) is wave-uniform, so ragged trees cost
-// no lane divergence: a chain that stops early simply frees its wave for the next chain (hardware dispatch
-// replaces the host-side active mask + stream compaction of a lockstep design).
-// HBM is touched only for what the tree must remember: sub-tree end points (for U-turn tests between
-// non-adjacent states), multinomial candidates and the two edges of the main tree.
+// no lane divergence, and a chain that stops early lets its wave move on (no host-side active mask, no stream
+// compaction between doublings).
+// HBM is touched only for what the tree must remember: sub-tree end points that are needed again after the
+// next leaf (U-turn tests between non-adjacent states), one z-vector per multinomial candidate, and the two
+// edges of the main tree.  That scratch belongs to the WAVE, not to the chain (a launch uses one wave per
+// resident slot and strides over the chains), so its footprint is small enough to live in L2 / Infinity Cache.
 //
 // Everything here is force-inlined into the kernels: the register tiles are passed by reference, and a real
 // call would force them through scratch memory.
@@ -26,21 +29,23 @@ namespace nm {
 constexpr int MAX_MAXDEPTH = 20;
 
 // ---------------------------------------------------------------------------------------------
-// HBM layout.  vec[chain][slot][DP] doubles.  Persistent slots first, then tree scratch.
+// HBM layout.
+//   pvec[chain][PSlot][DP]  : what a chain owns between draws
+//   svec[wave][scratch][DP] : tree scratch of a resident wave
 // ---------------------------------------------------------------------------------------------
-enum Slot : int {
+enum PSlot : int {
     P_X = 0, P_GX, P_Z, P_GZ,          // current point (TransformedPoint, transformed_hamiltonian.rs:56-77)
     P_SIG, P_ISIG, P_MU,               // DiagMassMatrix stds / inv_stds / mean (transform/diagonal.rs:9-17)
     E_DM, E_DV, E_GM, E_GV,            // foreground RunningVariance of draws / grads (adapt/diagonal.rs:108-115)
     B_DM, B_DV, B_GM, B_GV,            // background
-    ML_Z, ML_V, ML_G, MR_Z, MR_V, MR_G,// main tree: left / right edge (z, v, g_z)
-    S_DYN                              // first dynamic slot
+    NUM_PSLOT
 };
-// dynamic slots: F[k] (z,v), L[k] (z,v) for k in 0..=maxdepth, then candidate pool C[p] (z, g_x), p in 0..maxdepth+2
+enum SSlot : int { ML_Z = 0, ML_V, ML_G, MR_Z, MR_V, MR_G, S_DYN };   // main tree: left / right edge (z, v, g_z)
+// dynamic scratch: F[k] (z,v), L[k] (z,v) for k in 0..=maxdepth, then the candidate pool C[p] (z), p in 0..maxdepth+2
 __host__ __device__ inline int slot_F(int k) { return S_DYN + 2 * k; }
 __host__ __device__ inline int slot_L(int maxdepth, int k) { return S_DYN + 2 * (maxdepth + 1) + 2 * k; }
-__host__ __device__ inline int slot_C(int maxdepth, int p) { return S_DYN + 4 * (maxdepth + 1) + 2 * p; }
-__host__ __device__ inline int num_slots(int maxdepth) { return S_DYN + 4 * (maxdepth + 1) + 2 * (maxdepth + 3); }
+__host__ __device__ inline int slot_C(int maxdepth, int p) { return S_DYN + 4 * (maxdepth + 1) + p; }
+__host__ __device__ inline int num_sslots(int maxdepth) { return S_DYN + 4 * (maxdepth + 1) + (maxdepth + 3); }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
 struct ChainScalars {
@@ -70,8 +75,9 @@ struct ChainScalars {
 
 struct KParams {
     nm_settings s;
-    uint64_t n_chains, dim, dpad, chain_id_offset, nslot;
-    double* vec;
+    uint64_t n_chains, dim, dpad, chain_id_offset, nsslot;
+    double* pvec;
+    double* svec;
     ChainScalars* sc;
     const double* zig_x;
     const double* zig_f;
@@ -174,7 +180,7 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
     double log_size;
     double cand_logp, cand_ke;
     int64_t cand_idx;
-    int cand_slot;        // -2: live registers, -1: the trajectory's initial point, >=0: pool slot C[slot]
+    int cand_slot;        // >= 0: pool slot C[slot]
     int pad;
 };
 
@@ -191,24 +197,27 @@ struct ChainCtx {
     Dens dens;
     DevRng rng;
     ZigTables zig;
-    double* vec;        // this chain's slot array
+    double* pv;         // this chain's persistent slots
+    double* sv;         // this wave's tree scratch
     double* stage;      // LDS [64*DPL] staging for normals
     PendEntry* pend;    // LDS
     int dim;
     int maxdepth_cfg;
     ChainScalars sc;
-    Tile<DPL> sig, mu;  // mass matrix in registers for the whole kernel
+    Tile<DPL> sig, mu;  // mass matrix in registers while the chain is resident
 
     __device__ ChainCtx(const KParams& p) : P(p) {}
-    NM_DEV double* slot(int s) const { return vec + (size_t)s * P.dpad; }
+    NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
+    NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
 };
 
 template <int DPL, class Dens>
-NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chain) {
+NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chain, uint64_t wave) {
     const KParams& P = C.P;
     C.dim = (int)P.dim;
     C.maxdepth_cfg = (int)P.s.maxdepth;
-    C.vec = P.vec + (size_t)chain * P.nslot * P.dpad;
+    C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
+    C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.stage = sh.stage;
     C.pend = sh.pend;
     C.zig = {P.zig_x, P.zig_f};
@@ -222,38 +231,40 @@ NM_DEV void ctx_end(ChainCtx<DPL, Dens>& C, uint64_t chain) {
     if (lane_id() == 0) C.P.sc[chain] = C.sc;
 }
 
-// the live phase-space point
+// a phase-space point in registers
 template <int DPL>
-struct Live {
-    Tile<DPL> z, v, g, gx;   // g = transformed gradient g_z, gx = untransformed gradient
+struct Pt {
+    Tile<DPL> z, v, g;   // g = transformed gradient g_z
     double logp, ke;
     int64_t idx;
 };
 
-// One leapfrog in registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
+// One leapfrog, registers to registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
 //   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
 template <int DPL, class Dens>
-NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, Live<DPL>& s, double epsilon, Tile<DPL>* x_out) {
+NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     const double half = epsilon / 2.;
-    Tile<DPL> x;
+    Tile<DPL> x, gx;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-        s.v.a[k] = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-        s.z.a[k] = __builtin_fma(epsilon, s.v.a[k], s.z.a[k]);
-        double t = s.z.a[k] * C.sig.a[k];
+        double vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+        o.v.a[k] = vh;
+        o.z.a[k] = __builtin_fma(epsilon, vh, s.z.a[k]);
+        double t = o.z.a[k] * C.sig.a[k];
         x.a[k] = __builtin_fma(1.0, C.mu.a[k], t);
     }
-    s.logp = C.dens.template eval<DPL>(x, s.gx, C.dim);
+    o.logp = C.dens.template eval<DPL>(x, gx, C.dim);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-        s.g.a[k] = s.gx.a[k] * C.sig.a[k];
-        s.v.a[k] = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-        acc = __builtin_fma(s.v.a[k], s.v.a[k], acc);
+        o.g.a[k] = gx.a[k] * C.sig.a[k];
+        o.v.a[k] = __builtin_fma(half, o.g.a[k], o.v.a[k]);
+        acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
     }
-    s.ke = 0.5 * wave_sum(acc);
+    o.ke = 0.5 * wave_sum(acc);
     if (x_out) *x_out = x;
+    if (gx_out) *gx_out = gx;
 }
 
 // AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:112-166)
@@ -327,10 +338,10 @@ NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // Dua
 }
 
 // Hamiltonian::init_state at x with the current mass matrix (reference transformed_hamiltonian.rs:640-661,
-// check_all :310-324).  Fills st.z, st.g, st.gx, st.logp; returns false for BadInitGrad.
+// check_all :310-324).  Fills st.z, st.g, gx, st.logp; returns false for BadInitGrad.
 template <int DPL, class Dens>
-NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Live<DPL>& st) {
-    st.logp = C.dens.template eval<DPL>(x, st.gx, C.dim);
+NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
+    st.logp = C.dens.template eval<DPL>(x, gx, C.dim);
     Tile<DPL> isig;
     load_tile(isig, C.slot(P_ISIG));
     bool ok = true;
@@ -338,10 +349,10 @@ NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Live<DPL>& st
     for (int k = 0; k < DPL; ++k) {
         double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);     // compute_transformed_position diagonal.rs:233-246
         st.z.a[k] = isig.a[k] * t;
-        st.g.a[k] = st.gx.a[k] * C.sig.a[k];                  // compute_transformed_gradient :258-265
+        st.g.a[k] = gx.a[k] * C.sig.a[k];                     // compute_transformed_gradient :258-265
         bool valid = elem_index(k) < C.dim;
         ok = ok && (!valid || (is_finite(st.z.a[k]) && is_finite(st.g.a[k]) && st.g.a[k] != 0.0 &&
-                               is_finite(st.gx.a[k]) && is_finite(x.a[k])));
+                               is_finite(gx.a[k]) && is_finite(x.a[k])));
     }
     return wave_all(ok);
 }
@@ -351,8 +362,11 @@ template <int DPL, class Dens>
 NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
     const nm_settings& s = C.P.s;
     if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
-    Live<DPL> st;
-    if (!init_state(C, x, st)) return NM_CHAIN_BAD_INIT;
+    Pt<DPL> st;
+    {
+        Tile<DPL> gx;
+        if (!init_state(C, x, st, gx)) return NM_CHAIN_BAD_INIT;
+    }
     const double logdet = C.sc.mm_logdet;
     sample_velocity(C, st.v);                                   // initialize_trajectory(resample) :687-736
     const double ke0 = kinetic(st.v);
@@ -361,11 +375,10 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
     C.sc.step_size = s.initial_step;
     int dir = 0;
     for (int it = 0; it < 101; ++it) {
-        Live<DPL> o;
-        o.z = st.z; o.v = st.v; o.g = st.g;
+        Pt<DPL> o;
         const int sign = it == 0 ? 1 : dir;
         col.register_init(e0);
-        leapfrog(C, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr);
+        leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
         const double energy = o.ke - (o.logp + logdet);
         const double err = energy - e0;
         if ((err > 1000.0) | !is_finite(err)) {                 // hard-coded 1000.0 (adapt.rs:118, :142)
@@ -598,14 +611,19 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, Dens>& C, const AcceptCollector& col, bool i
 //
 // A doubling of the main tree at depth j generates 2^j leaves in one direction.  Leaf n (0-based) closes
 // the sub-trees of levels 1..t, t = number of trailing one bits of n; each closing is a merge of the pending
-// level-(k-1) sub-tree A with the just-completed level-(k-1) sub-tree B (whose last leaf is the live point).
-// The end points the U-turn tests need are addressed by level, with no copies:
-//   even leaf n  -> F[tz(n)]  (F[j] for n = 0): first leaf of every sub-tree that starts at n
-//   odd  leaf n  -> L[to(n)]                  : last leaf of the pending level-to(n) sub-tree
-//   merge at level k at leaf n: A.first = F[tz(n+1-2^k)] (F[j] if that leaf is 0), A.last = L[k-1], B.first = F[k-1].
-// Candidates are renamed, never copied: a pool slot index travels with the (log_size, candidate) scalars.
+// level-(k-1) sub-tree A with the just-completed level-(k-1) sub-tree B (whose last leaf is the newest point).
+// Leaves are produced in pairs into two register-resident points, E (even leaf) and O (odd leaf), so the
+// level-1 merge and the B.first operand of the level-2 merge never touch memory.  What must survive longer is
+// addressed by level, with no copies:
+//   leaf n = 0 mod 4 -> F[tz(n)] (F[j] for n = 0): first leaf of sub-trees of level >= 2 that start at n
+//   odd  leaf n      -> L[to(n)]                  : last leaf of the pending level-to(n) sub-tree
+//   merge at level k >= 2 at odd leaf n: A.first = F[tz(n+1-2^k)] (F[j] if that leaf is 0), A.last = L[k-1],
+//                                        B.first = E (k = 2) or F[k-1] (k > 2), B.last = O.
+// Candidates are renamed, never copied: a pool slot index travels with the (log_size, candidate) scalars, and a
+// candidate is written (its z only; g_x is recomputed once per draw for the winner) when its registers are
+// about to be reused.
 // ---------------------------------------------------------------------------------------------
-struct CandRef { int slot; double logp, ke; int64_t idx; };
+struct CandRef { int slot; double logp, ke; int64_t idx; };   // slot: -3 live in E, -2 live in O, -1 initial point, >=0 pool
 enum TreeStop { STOP_NONE = 0, STOP_TURNING = 1, STOP_DIVERGING = 2, STOP_FATAL = 3 };
 
 // multinomial merge weights (reference merge_into, src/nuts.rs:172-207).  Returns take_B.
@@ -627,45 +645,67 @@ struct DrawResult {
     double e0;
 };
 
-template <int DPL>
 NM_DEV const double2* lane_ptr(const double* base) { return reinterpret_cast<const double2*>(base) + lane_id(); }
 
-// nuts::draw (reference src/nuts.rs:281-388).  On entry the chain's current point is in HBM slots P_*.
-// On exit, if R.chosen.slot != -1, cur.z / cur.gx hold the chosen point's z and g_x.
+// is_turning(first-generated a, later-generated b) for two register points; fwd decides which is `start`
+template <int DPL>
+NM_DEV bool turning_regs(const Pt<DPL>& a, const Pt<DPL>& b, bool fwd) {
+    double s1 = 0., s2 = 0.;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        if (fwd) turn_acc(a.z.a[k], a.v.a[k], b.z.a[k], b.v.a[k], s1, s2);
+        else turn_acc(b.z.a[k], b.v.a[k], a.z.a[k], a.v.a[k], s1, s2);
+    }
+    wave_sum2(s1, s2);
+    return (s1 < 0.) | (s2 < 0.);
+}
+
+// the candidate's z goes to a fresh pool slot
 template <int DPL, class Dens>
-NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, DrawResult& R, Live<DPL>& cur) {
+NM_DEV int cand_to_pool(ChainCtx<DPL, Dens>& C, uint32_t& used, const Tile<DPL>& z) {
+    const int p = (int)__builtin_ctz(~used);
+    used |= 1u << p;
+    store_tile(z, C.sslot(slot_C(C.maxdepth_cfg, p)));
+    return p;
+}
+
+// nuts::draw (reference src/nuts.rs:281-388).  On entry the chain's current point is in its slots P_*.
+// On exit, if R.chosen.slot >= 0, zc holds the chosen point's z.
+template <int DPL, class Dens>
+NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, DrawResult& R, Tile<DPL>& zc) {
     const nm_settings& s = C.P.s;
     ChainScalars& sc = C.sc;
     const int MD = C.maxdepth_cfg;
+    Pt<DPL> E, O;
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
-    sample_velocity(C, cur.v);
+    sample_velocity(C, E.v);
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
-        Tile<DPL> x, isig;
+        Tile<DPL> x, gx, isig;
         load_tile(x, C.slot(P_X));
-        load_tile(cur.gx, C.slot(P_GX));
+        load_tile(gx, C.slot(P_GX));
         load_tile(isig, C.slot(P_ISIG));
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);
-            cur.z.a[k] = isig.a[k] * t;
-            cur.g.a[k] = cur.gx.a[k] * C.sig.a[k];
+            E.z.a[k] = isig.a[k] * t;
+            E.g.a[k] = gx.a[k] * C.sig.a[k];
         }
-        store_tile(cur.z, C.slot(P_Z));
-        store_tile(cur.g, C.slot(P_GZ));
+        store_tile(E.z, C.slot(P_Z));
+        store_tile(E.g, C.slot(P_GZ));
         sc.logdet = sc.mm_logdet;
         sc.transform_id = sc.mm_id;
     } else {
-        load_tile(cur.z, C.slot(P_Z));
-        load_tile(cur.g, C.slot(P_GZ));
+        load_tile(E.z, C.slot(P_Z));
+        load_tile(E.g, C.slot(P_GZ));
     }
     const double logdet = sc.logdet;
-    const double ke_init = kinetic(cur.v);
+    const double ke_init = kinetic(E.v);
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
-    store_tile(cur.z, C.slot(ML_Z)); store_tile(cur.v, C.slot(ML_V)); store_tile(cur.g, C.slot(ML_G));
-    store_tile(cur.z, C.slot(MR_Z)); store_tile(cur.v, C.slot(MR_V)); store_tile(cur.g, C.slot(MR_G));
+    store_tile(E.z, C.sslot(ML_Z)); store_tile(E.v, C.sslot(ML_V)); store_tile(E.g, C.sslot(ML_G));
+    store_tile(E.z, C.sslot(MR_Z)); store_tile(E.v, C.sslot(MR_V)); store_tile(E.g, C.sslot(MR_G));
     uint64_t depth = 0;
     double log_size = 0.;
     int64_t left_idx = 0, right_idx = 0;
@@ -701,114 +741,161 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
             check = false;
         }
         const bool fwd = sign > 0;
-        // ---- one doubling: build `other` with 2^depth leaves from the edge
-        load_tile(cur.z, C.slot(fwd ? MR_Z : ML_Z));
-        load_tile(cur.v, C.slot(fwd ? MR_V : ML_V));
-        load_tile(cur.g, C.slot(fwd ? MR_G : ML_G));
         const int64_t edge_idx = fwd ? right_idx : left_idx;
         const uint64_t nleaf = 1ull << depth;
         const uint32_t used_before = used;
+        const double epsilon = (double)sign * sc.step_size * 1.0;
         int stop = STOP_NONE;
         double sub_log_size = 0.;
         CandRef sub_cand = {-2, 0., 0., 0};
-        const double epsilon = (double)sign * sc.step_size * 1.0;
-        for (uint64_t n = 0; n < nleaf; ++n) {
-            leapfrog(C, cur, epsilon, (Tile<DPL>*)nullptr);
-            cur.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
-            const double energy = cur.ke - (cur.logp + logdet);
-            const double err = energy - e0;
-            if ((err > s.max_energy_error) | !is_finite(err)) {   // transformed_hamiltonian.rs:590-610
-                col.register_divergent();
-                R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err;
-                stop = STOP_DIVERGING;
-                break;
-            }
-            col.register_ok(energy);
-            sub_log_size = -err;                                  // single_step, src/nuts.rs:235
-            sub_cand = {-2, cur.logp, cur.ke, cur.idx};
-            const int t = (int)__builtin_ctzll(~n);               // trailing ones of n: merges at levels 1..t
-            for (int k = 1; k <= t; ++k) {
-                const PendEntry A = C.pend[k - 1];
-                bool turning = false;
-                if (check) {
-                    const uint64_t a_first = n + 1 - (1ull << k);
-                    const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                    const double2* afz = lane_ptr<DPL>(C.slot(slot_F(fa)));
-                    const double2* afv = lane_ptr<DPL>(C.slot(slot_F(fa) + 1));
-                    double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-                    if (k == 1) {
-                        // depth-0 siblings: the single test is_turning(A, B = live point)
-#pragma unroll
-                        for (int m = 0; m < DPL / 2; ++m) {
-                            double2 az = afz[m * 64], av = afv[m * 64];
-                            if (fwd) {
-                                turn_acc(az.x, av.x, cur.z.a[2 * m], cur.v.a[2 * m], s1, s2);
-                                turn_acc(az.y, av.y, cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], s1, s2);
-                            } else {
-                                turn_acc(cur.z.a[2 * m], cur.v.a[2 * m], az.x, av.x, s1, s2);
-                                turn_acc(cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], az.y, av.y, s1, s2);
-                            }
-                        }
-                        wave_sum2(s1, s2);
-                        turning = (s1 < 0.) | (s2 < 0.);
-                    } else {
+
+        // divergence test + collector for a fresh leaf (transformed_hamiltonian.rs:590-612); returns -energy_error
+#define NM_LEAF_ACCOUNT(PT, WOUT)                                                                         \
+        {                                                                                                 \
+            const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
+            const double err_ = energy_ - e0;                                                             \
+            if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
+                col.register_divergent();                                                                 \
+                R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
+                stop = STOP_DIVERGING;                                                                    \
+            } else {                                                                                      \
+                col.register_ok(energy_);                                                                 \
+                WOUT = -err_;                                                                             \
+            }                                                                                             \
+        }
+
+        if (depth == 0) {
+            // a single leaf: edge -> E -> O
+            load_tile(E.z, C.sslot(fwd ? MR_Z : ML_Z));
+            load_tile(E.v, C.sslot(fwd ? MR_V : ML_V));
+            load_tile(E.g, C.sslot(fwd ? MR_G : ML_G));
+            leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+            O.idx = edge_idx + (int64_t)sign;
+            NM_LEAF_ACCOUNT(O, sub_log_size)
+            sub_cand = {-2, O.logp, O.ke, O.idx};
+        } else {
+            load_tile(O.z, C.sslot(fwd ? MR_Z : ML_Z));
+            load_tile(O.v, C.sslot(fwd ? MR_V : ML_V));
+            load_tile(O.g, C.sslot(fwd ? MR_G : ML_G));
+            for (uint64_t n = 0; n < nleaf; n += 2) {
+                // ---- even leaf n
+                double wE = 0., wO = 0.;
+                leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
+                NM_LEAF_ACCOUNT(E, wE)
+                if (stop != STOP_NONE) break;
+                if ((n & 3) == 0) {
+                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
+                    store_tile(E.z, C.sslot(fs));
+                    store_tile(E.v, C.sslot(fs + 1));
+                }
+                // ---- odd leaf n + 1
+                leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
+                NM_LEAF_ACCOUNT(O, wO)
+                if (stop != STOP_NONE) break;
+                // ---- level-1 merge: A = {E}, B = {O}, everything in registers
+                {
+                    const bool turning = check ? turning_regs(E, O, fwd) : false;
+                    double total;
+                    const bool take = merge_weights(C, wE, wO, false, total, fatal);
+                    sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if (turning) { stop = STOP_TURNING; break; }
+                }
+                const uint64_t nn = n + 1;
+                const int t = (int)__builtin_ctzll(~nn);           // trailing ones of the odd leaf: merges up to level t
+                for (int k = 2; k <= t; ++k) {
+                    const PendEntry A = C.pend[k - 1];
+                    bool turning = false;
+                    if (check) {
                         // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
-                        const double2* alz = lane_ptr<DPL>(C.slot(slot_L(MD, k - 1)));
-                        const double2* alv = lane_ptr<DPL>(C.slot(slot_L(MD, k - 1) + 1));
-                        const double2* bfz = lane_ptr<DPL>(C.slot(slot_F(k - 1)));
-                        const double2* bfv = lane_ptr<DPL>(C.slot(slot_F(k - 1) + 1));
+                        const uint64_t a_first = nn + 1 - (1ull << k);
+                        const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
+                        const double2* afz = lane_ptr(C.sslot(slot_F(fa)));
+                        const double2* afv = lane_ptr(C.sslot(slot_F(fa) + 1));
+                        const double2* alz = lane_ptr(C.sslot(slot_L(MD, k - 1)));
+                        const double2* alv = lane_ptr(C.sslot(slot_L(MD, k - 1) + 1));
+                        double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+                        if (k == 2) {
 #pragma unroll
-                        for (int m = 0; m < DPL / 2; ++m) {
-                            double2 az = afz[m * 64], av = afv[m * 64];
-                            double2 lz = alz[m * 64], lv = alv[m * 64];
-                            double2 bz = bfz[m * 64], bv = bfv[m * 64];
-                            const double cz0 = cur.z.a[2 * m], cz1 = cur.z.a[2 * m + 1];
-                            const double cv0 = cur.v.a[2 * m], cv1 = cur.v.a[2 * m + 1];
-                            if (fwd) {
-                                turn_acc(az.x, av.x, cz0, cv0, s1, s2); turn_acc(az.y, av.y, cz1, cv1, s1, s2);
-                                turn_acc(lz.x, lv.x, cz0, cv0, s3, s4); turn_acc(lz.y, lv.y, cz1, cv1, s3, s4);
-                                turn_acc(az.x, av.x, bz.x, bv.x, s5, s6); turn_acc(az.y, av.y, bz.y, bv.y, s5, s6);
-                            } else {
-                                turn_acc(cz0, cv0, az.x, av.x, s1, s2); turn_acc(cz1, cv1, az.y, av.y, s1, s2);
-                                turn_acc(cz0, cv0, lz.x, lv.x, s3, s4); turn_acc(cz1, cv1, lz.y, lv.y, s3, s4);
-                                turn_acc(bz.x, bv.x, az.x, av.x, s5, s6); turn_acc(bz.y, bv.y, az.y, av.y, s5, s6);
+                            for (int m = 0; m < DPL / 2; ++m) {
+                                const double2 az = afz[m * 64], av = afv[m * 64];
+                                const double2 lz = alz[m * 64], lv = alv[m * 64];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
+                                    const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
+                                    const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
+                                    const double bz = E.z.a[2 * m + j], bv = E.v.a[2 * m + j];
+                                    if (fwd) {
+                                        turn_acc(azj, avj, cz, cv, s1, s2);
+                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                        turn_acc(azj, avj, bz, bv, s5, s6);
+                                    } else {
+                                        turn_acc(cz, cv, azj, avj, s1, s2);
+                                        turn_acc(cz, cv, lzj, lvj, s3, s4);
+                                        turn_acc(bz, bv, azj, avj, s5, s6);
+                                    }
+                                }
+                            }
+                        } else {
+                            const double2* bfz = lane_ptr(C.sslot(slot_F(k - 1)));
+                            const double2* bfv = lane_ptr(C.sslot(slot_F(k - 1) + 1));
+#pragma unroll
+                            for (int m = 0; m < DPL / 2; ++m) {
+                                const double2 az = afz[m * 64], av = afv[m * 64];
+                                const double2 lz = alz[m * 64], lv = alv[m * 64];
+                                const double2 bz2 = bfz[m * 64], bv2 = bfv[m * 64];
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
+                                    const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
+                                    const double bz = j ? bz2.y : bz2.x, bv = j ? bv2.y : bv2.x;
+                                    const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
+                                    if (fwd) {
+                                        turn_acc(azj, avj, cz, cv, s1, s2);
+                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                        turn_acc(azj, avj, bz, bv, s5, s6);
+                                    } else {
+                                        turn_acc(cz, cv, azj, avj, s1, s2);
+                                        turn_acc(cz, cv, lzj, lvj, s3, s4);
+                                        turn_acc(bz, bv, azj, avj, s5, s6);
+                                    }
+                                }
                             }
                         }
                         wave_sum2(s1, s2); wave_sum2(s3, s4); wave_sum2(s5, s6);
                         turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
                     }
+                    double total;
+                    const bool take = merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
+                    if (take) {
+                        used &= ~(1u << A.cand_slot);
+                    } else {
+                        if (sub_cand.slot >= 0) used &= ~(1u << sub_cand.slot);
+                        sub_cand = {A.cand_slot, A.cand_logp, A.cand_ke, A.cand_idx};
+                    }
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if (turning) { stop = STOP_TURNING; break; }
                 }
-                double total;
-                const bool take = merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
-                if (take) {
-                    if (A.cand_slot >= 0) used &= ~(1u << A.cand_slot);
-                } else {
-                    if (sub_cand.slot >= 0) used &= ~(1u << sub_cand.slot);
-                    sub_cand = {A.cand_slot, A.cand_logp, A.cand_ke, A.cand_idx};
+                if (stop != STOP_NONE) break;
+                if (n + 2 < nleaf) {
+                    // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
+                    store_tile(O.z, C.sslot(slot_L(MD, t)));
+                    store_tile(O.v, C.sslot(slot_L(MD, t) + 1));
+                    if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
+                    else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
+                    PendEntry e;
+                    e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
+                    e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
+                    C.pend[t] = e;
                 }
-                sub_log_size = total;
-                if (fatal) { stop = STOP_FATAL; break; }
-                if (turning) { stop = STOP_TURNING; break; }
-            }
-            if (stop != STOP_NONE) break;
-            if (n + 1 < nleaf) {
-                // this leaf's (z, v) is an end point of the pending level-t sub-tree
-                const int zslot = t == 0 ? slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n)) : slot_L(MD, t);
-                store_tile(cur.z, C.slot(zslot));
-                store_tile(cur.v, C.slot(zslot + 1));
-                if (sub_cand.slot == -2) {
-                    const int p = (int)__builtin_ctz(~used);
-                    used |= 1u << p;
-                    store_tile(cur.z, C.slot(slot_C(MD, p)));
-                    store_tile(cur.gx, C.slot(slot_C(MD, p) + 1));
-                    sub_cand.slot = p;
-                }
-                PendEntry e;
-                e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
-                e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
-                C.pend[t] = e;
             }
         }
+#undef NM_LEAF_ACCOUNT
         if (stop == STOP_FATAL) { fatal = true; break; }
         if (stop == STOP_DIVERGING) { used = used_before; break; }     // tree unchanged (src/nuts.rs:123, :134-136)
         if (stop == STOP_TURNING) {                                    // `other` discarded (src/nuts.rs:131-133)
@@ -816,46 +903,46 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
             if (!in_extra) { in_extra = true; extra_left = s.extra_doublings; }
             continue;
         }
-        // ---- `other` is complete: top-level turning tests, then merge into the main tree
+        // ---- `other` is complete (its last leaf is O): top-level turning tests, then merge into the main tree
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const double2* mlz = lane_ptr<DPL>(C.slot(ML_Z));
-            const double2* mlv = lane_ptr<DPL>(C.slot(ML_V));
-            const double2* mrz = lane_ptr<DPL>(C.slot(MR_Z));
-            const double2* mrv = lane_ptr<DPL>(C.slot(MR_V));
+            const double2* mlz = lane_ptr(C.sslot(ML_Z));
+            const double2* mlv = lane_ptr(C.sslot(ML_V));
+            const double2* mrz = lane_ptr(C.sslot(MR_Z));
+            const double2* mrv = lane_ptr(C.sslot(MR_V));
             if (depth == 0) {
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
                     if (fwd) {
                         double2 az = mlz[m * 64], av = mlv[m * 64];
-                        turn_acc(az.x, av.x, cur.z.a[2 * m], cur.v.a[2 * m], s1, s2);
-                        turn_acc(az.y, av.y, cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], s1, s2);
+                        turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2);
+                        turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2);
                     } else {
                         double2 az = mrz[m * 64], av = mrv[m * 64];
-                        turn_acc(cur.z.a[2 * m], cur.v.a[2 * m], az.x, av.x, s1, s2);
-                        turn_acc(cur.z.a[2 * m + 1], cur.v.a[2 * m + 1], az.y, av.y, s1, s2);
+                        turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2);
+                        turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2);
                     }
                 }
                 wave_sum2(s1, s2);
                 turning = (s1 < 0.) | (s2 < 0.);
             } else {
-                const double2* ofz = lane_ptr<DPL>(C.slot(slot_F((int)depth)));
-                const double2* ofv = lane_ptr<DPL>(C.slot(slot_F((int)depth) + 1));
+                const double2* ofz = lane_ptr(C.sslot(slot_F((int)depth)));
+                const double2* ofv = lane_ptr(C.sslot(slot_F((int)depth) + 1));
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
                     double2 lz = mlz[m * 64], lv = mlv[m * 64];
                     double2 rz = mrz[m * 64], rv = mrv[m * 64];
                     double2 oz = ofz[m * 64], ov = ofv[m * 64];
-                    const double cz0 = cur.z.a[2 * m], cz1 = cur.z.a[2 * m + 1];
-                    const double cv0 = cur.v.a[2 * m], cv1 = cur.v.a[2 * m + 1];
+                    const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
+                    const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                     if (fwd) {
-                        // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = live
+                        // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
                         turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
                         turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
                         turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6);
                     } else {
-                        // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = live
+                        // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
                         turn_acc(cz0, cv0, rz.x, rv.x, s1, s2); turn_acc(cz1, cv1, rz.y, rv.y, s1, s2);
                         turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
                         turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
@@ -870,21 +957,16 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
         if (fatal) break;
         if (take) {
             if (mc.slot >= 0) used &= ~(1u << mc.slot);
-            if (sub_cand.slot == -2) {
-                const int p = (int)__builtin_ctz(~used);
-                used |= 1u << p;
-                store_tile(cur.z, C.slot(slot_C(MD, p)));
-                store_tile(cur.gx, C.slot(slot_C(MD, p) + 1));
-                sub_cand.slot = p;
-            }
+            if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
+            else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
             mc = sub_cand;
         } else if (sub_cand.slot >= 0) {
             used &= ~(1u << sub_cand.slot);
         }
-        store_tile(cur.z, C.slot(fwd ? MR_Z : ML_Z));
-        store_tile(cur.v, C.slot(fwd ? MR_V : ML_V));
-        store_tile(cur.g, C.slot(fwd ? MR_G : ML_G));
-        if (fwd) right_idx = cur.idx; else left_idx = cur.idx;
+        store_tile(O.z, C.sslot(fwd ? MR_Z : ML_Z));
+        store_tile(O.v, C.sslot(fwd ? MR_V : ML_V));
+        store_tile(O.g, C.sslot(fwd ? MR_G : ML_G));
+        if (fwd) right_idx = O.idx; else left_idx = O.idx;
         depth += 1;
         log_size = total;
         if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
@@ -892,10 +974,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
     R.depth = depth;
     R.chosen = mc;
     if (fatal) return NM_CHAIN_LOGP_FATAL;
-    if (mc.slot >= 0) {
-        load_tile(cur.z, C.slot(slot_C(MD, mc.slot)));
-        load_tile(cur.gx, C.slot(slot_C(MD, mc.slot) + 1));
-    }
+    if (mc.slot >= 0) load_tile(zc, C.sslot(slot_C(MD, mc.slot)));
     return NM_CHAIN_OK;
 }
 
@@ -908,31 +987,32 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
     ChainScalars& sc = C.sc;
     AcceptCollector col;
     DrawResult R;
-    Live<DPL> cur;
-    uint64_t st = nuts_transition(C, col, R, cur);
+    Tile<DPL> x, gx, z, gz;
+    uint64_t st = nuts_transition(C, col, R, z);
     nm_draw_stats out;
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     if (st != NM_CHAIN_OK) {
         sc.status = st;
         if (P.out_stats && lane_id() == 0) {
-            nm_draw_stats z = {};
-            z.draw = sc.draw_count; z.chain = P.chain_id_offset + chain; z.chain_status = st;
-            P.out_stats[t_out * P.n_chains + chain] = z;
+            nm_draw_stats zz = {};
+            zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = st;
+            P.out_stats[t_out * P.n_chains + chain] = zz;
         }
         return;
     }
-    Tile<DPL> x, gx, z, gz;
     if (R.chosen.slot == -1) {                                   // the draw is the trajectory's initial point
         load_tile(x, C.slot(P_X)); load_tile(gx, C.slot(P_GX));
         load_tile(z, C.slot(P_Z)); load_tile(gz, C.slot(P_GZ));
     } else {
-        z = cur.z; gx = cur.gx;
+        // the winner's x, g_x, g_z from its z: the same operations as inside the leapfrog => the same bits
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            double tt = z.a[k] * C.sig.a[k];                      // same operations as inside the leapfrog => same bits
+            double tt = z.a[k] * C.sig.a[k];
             x.a[k] = __builtin_fma(1.0, C.mu.a[k], tt);
-            gz.a[k] = gx.a[k] * C.sig.a[k];
         }
+        (void)C.dens.template eval<DPL>(x, gx, C.dim);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) gz.a[k] = gx.a[k] * C.sig.a[k];
         store_tile(x, C.slot(P_X)); store_tile(gx, C.slot(P_GX));
         store_tile(z, C.slot(P_Z)); store_tile(gz, C.slot(P_GZ));
         sc.logp = R.chosen.logp;
@@ -973,68 +1053,71 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernels: one block = one wave = one chain
+// kernels: one block = one wave; a wave strides over the chains
 // ---------------------------------------------------------------------------------------------
 template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void nuts_draw_kernel(const KParams P) {
     __shared__ WaveShared<DPL> sh;
-    const uint64_t chain = blockIdx.x;
-    if (chain >= P.n_chains) return;
-    ChainCtx<DPL, Dens> C(P);
-    ctx_begin(C, sh, chain);
-    if (C.sc.status == NM_CHAIN_OK) {
-        load_tile(C.sig, C.slot(P_SIG));
-        load_tile(C.mu, C.slot(P_MU));
-        for (uint64_t t = 0; t < P.n_draws; ++t) {
-            chain_draw(C, chain, t);
-            if (C.sc.status != NM_CHAIN_OK) break;
+    for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
+        ChainCtx<DPL, Dens> C(P);
+        ctx_begin(C, sh, chain, blockIdx.x);
+        if (C.sc.status == NM_CHAIN_OK) {
+            load_tile(C.sig, C.slot(P_SIG));
+            load_tile(C.mu, C.slot(P_MU));
+            for (uint64_t t = 0; t < P.n_draws; ++t) {
+                chain_draw(C, chain, t);
+                if (C.sc.status != NM_CHAIN_OK) break;
+            }
         }
+        ctx_end(C, chain);
+        __syncthreads();
     }
-    ctx_end(C, chain);
 }
 
 // NutsChain::set_position (reference src/chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119)
 template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void nuts_init_kernel(const KParams P) {
     __shared__ WaveShared<DPL> sh;
-    const uint64_t chain = blockIdx.x;
-    if (chain >= P.n_chains) return;
-    ChainCtx<DPL, Dens> C(P);
-    ctx_begin(C, sh, chain);
-    ChainScalars& sc = C.sc;
-    dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
-    Tile<DPL> x, gx;
+    for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
+        ChainCtx<DPL, Dens> C(P);
+        ctx_begin(C, sh, chain, blockIdx.x);
+        ChainScalars& sc = C.sc;
+        dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
+        Tile<DPL> x, gx;
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-        int d = elem_index(k);
-        x.a[k] = d < C.dim ? P.x0[chain * P.dim + d] : 0.0;
-    }
-    // init_state_untransformed (transformed_hamiltonian.rs:663-685)
-    (void)C.dens.template eval<DPL>(x, gx, C.dim);
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) ok = ok && is_finite(gx.a[k]) && is_finite(x.a[k]);
-    uint64_t status = NM_CHAIN_OK;
-    if (!wave_all(ok)) status = NM_CHAIN_BAD_INIT;
-    if (status == NM_CHAIN_OK) {
-        // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
-        store_tile(x, C.slot(E_DM)); store_tile(x, C.slot(B_DM));
-        store_tile(gx, C.slot(E_GM)); store_tile(gx, C.slot(B_GM));
-        sc.cnt_fg = 1; sc.cnt_bg = 1;
-        mass_matrix_from_grad(C, x, gx);
-        status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
-    }
-    if (status == NM_CHAIN_OK) {
-        Live<DPL> st;                                             // hamiltonian.init_state (chain.rs:147)
-        if (!init_state(C, x, st)) status = NM_CHAIN_BAD_INIT;
-        else {
-            store_tile(x, C.slot(P_X)); store_tile(st.gx, C.slot(P_GX));
-            store_tile(st.z, C.slot(P_Z)); store_tile(st.g, C.slot(P_GZ));
-            sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            x.a[k] = d < C.dim ? P.x0[chain * P.dim + d] : 0.0;
         }
+        // init_state_untransformed (transformed_hamiltonian.rs:663-685)
+        (void)C.dens.template eval<DPL>(x, gx, C.dim);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) ok = ok && is_finite(gx.a[k]) && is_finite(x.a[k]);
+        uint64_t status = NM_CHAIN_OK;
+        if (!wave_all(ok)) status = NM_CHAIN_BAD_INIT;
+        if (status == NM_CHAIN_OK) {
+            // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
+            store_tile(x, C.slot(E_DM)); store_tile(x, C.slot(B_DM));
+            store_tile(gx, C.slot(E_GM)); store_tile(gx, C.slot(B_GM));
+            sc.cnt_fg = 1; sc.cnt_bg = 1;
+            mass_matrix_from_grad(C, x, gx);
+            status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
+        }
+        if (status == NM_CHAIN_OK) {
+            Pt<DPL> st;                                               // hamiltonian.init_state (chain.rs:147)
+            Tile<DPL> g2;
+            if (!init_state(C, x, st, g2)) status = NM_CHAIN_BAD_INIT;
+            else {
+                store_tile(x, C.slot(P_X)); store_tile(g2, C.slot(P_GX));
+                store_tile(st.z, C.slot(P_Z)); store_tile(st.g, C.slot(P_GZ));
+                sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
+            }
+        }
+        sc.status = status;
+        ctx_end(C, chain);
+        __syncthreads();
     }
-    sc.status = status;
-    ctx_end(C, chain);
 }
 
 }  // namespace nm
