@@ -24,19 +24,42 @@ NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 
 // ---- wavefront reductions ---------------------------------------------------------------------
-NM_DEV double wave_sum(double x) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) x = x + __shfl_xor(x, s, 64);
-    return x;
+// Sum over the 64 lanes, result identical in every lane.  Pairing = xor butterfly with offsets 1,2,4,8,16,32
+// (the documented reduction order; oracle/nmo_math.hpp gpu_reduce).  Implemented without LDS traffic:
+// offsets 1,2 are DPP quad permutes; for 4 and 8 every lane of a quad / of an 8-group already holds the same
+// partial sum, so the DPP half-mirror / mirror (lane i <- 7-i / 15-i) pairs exactly the groups that xor 4 /
+// xor 8 would, with identical bits; the four row sums are then combined as (r0+r1)+(r2+r3) from readlanes,
+// which is what the xor 16 / xor 32 steps compute in every lane.
+template <int CTRL>
+NM_DEV double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-// two sums at once (independent butterflies interleave in the issue stream)
+NM_DEV double readlane_f64(double x, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+NM_DEV double wave_sum(double x) {
+    x = x + dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]  : xor 1
+    x = x + dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]  : xor 2
+    x = x + dpp_mov<0x141>(x);   // row_half_mirror      : pairs the two quads of each 8 (= xor 4)
+    x = x + dpp_mov<0x140>(x);   // row_mirror           : pairs the two halves of each row of 16 (= xor 8)
+    const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+// two sums at once (independent chains interleave in the issue stream)
 NM_DEV void wave_sum2(double& a, double& b) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        double ta = __shfl_xor(a, s, 64), tb = __shfl_xor(b, s, 64);
-        a = a + ta;
-        b = b + tb;
-    }
+    a = a + dpp_mov<0xB1>(a);  b = b + dpp_mov<0xB1>(b);
+    a = a + dpp_mov<0x4E>(a);  b = b + dpp_mov<0x4E>(b);
+    a = a + dpp_mov<0x141>(a); b = b + dpp_mov<0x141>(b);
+    a = a + dpp_mov<0x140>(a); b = b + dpp_mov<0x140>(b);
+    const double a0 = readlane_f64(a, 0), a1 = readlane_f64(a, 16), a2 = readlane_f64(a, 32), a3 = readlane_f64(a, 48);
+    const double b0 = readlane_f64(b, 0), b1 = readlane_f64(b, 16), b2 = readlane_f64(b, 32), b3 = readlane_f64(b, 48);
+    a = (a0 + a1) + (a2 + a3);
+    b = (b0 + b1) + (b2 + b3);
 }
 NM_DEV double wave_bcast(double x, int src) { return __shfl(x, src, 64); }
 NM_DEV uint64_t wave_bcast_u64(uint64_t x, int src) {
