@@ -45,6 +45,26 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic(args):
+    """HBM bytes per timed launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    this same command, tools/pmc_run.sh; gfx950 correction: FETCH_SIZE x2 for 16 B/lane streams, per
+    MI355X_MICROARCH.md).  Counters cannot be collected from inside an un-profiled run, so the latest committed
+    summary under profiles/ is reported when it was taken on the same workload; otherwise null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k2.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", {"chains": 4096, "dim": 1024, "steps": 200}) == {"chains": args.chains, "dim": args.dim, "steps": args.steps}:
+            best = (f, d)
+    if not best:
+        return None, None
+    f, d = best
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT)
+
+
 def cpu_baseline(args, cores):
     """The CPU restatement of nuts-rs (oracle/, reference arithmetic: libm + SIMD-order sums) on this box's host
     cores: one chain per task over `cores` threads (the reference's Rayon structure, src/sampler.rs:1116), same
@@ -139,6 +159,7 @@ def main():
         kern_s = c["kernel_ms"] * 1e-3
         algo_bytes = steps_local * D * ALGO_BYTES_PER_STEP_DIM
         achieved = algo_bytes / kern_s / 1e9
+        traffic, traffic_src = pmc_traffic(args)
         out = {
             "metric": "leapfrog-steps*dims/sec at 4096 chains x dim 1024 (post-warm-up NUTS draws)",
             "value": value, "unit": "leapfrog-steps*dims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +174,7 @@ def main():
             "adaptation": {"value": tune_steps_total * D / t_tune_max, "unit": "leapfrog-steps*dims/s",
                            "draws": args.num_tune, "seconds": t_tune_max},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "nuts_draw_kernel", "kernel_ms_per_launch": c["kernel_ms"] / max(1, c["kernel_launches"]),
                          "launches": c["kernel_launches"], "algorithmic_bytes_per_launch": algo_bytes / max(1, c["kernel_launches"]),
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS},

@@ -61,11 +61,19 @@ NM_DEV void wave_sum2(double& a, double& b) {
     a = (a0 + a1) + (a2 + a3);
     b = (b0 + b1) + (b2 + b3);
 }
-NM_DEV double wave_bcast(double x, int src) { return __shfl(x, src, 64); }
+// value of lane `src` (wave-uniform lane index) as a wave-uniform value
 NM_DEV uint64_t wave_bcast_u64(uint64_t x, int src) {
-    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src, 64);
-    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src, 64);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src);
     return ((uint64_t)hi << 32) | lo;
+}
+// Tell the compiler a value is wave-uniform (it is: every lane computed it from uniform inputs).  Results of
+// real calls (dexp/dlog are not inlined) count as divergent otherwise, which would turn all the scalar tree
+// logic into exec-masked control flow held in VGPRs.
+NM_DEV double uniform_f64(double x) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
 }
 
 // ---- deterministic exp / ln (Sun fdlibm e_exp.c / e_log.c algorithms) ---------------------------
@@ -161,13 +169,29 @@ NM_DEV double dlog1p(double x) {
     if (!(u == u) || __builtin_isinf(u)) return dlog(u);
     return dlog(u) * (x / (u - 1.0));
 }
-
-// reference src/math/util.rs:6-19
-NM_DEV double logaddexp(double a, double b) {
+// per-lane logaddexp (reference src/math/util.rs:6-19)
+NM_DEV double logaddexp_lane(double a, double b) {
     if (a == b) return a + dlog(2.0);
     double diff = a - b;
     if (diff > 0.) return a + dlog1p(dexp(-diff));
     if (diff < 0.) return b + dlog1p(dexp(diff));
+    return diff;
+}
+// wave-uniform variants: same arithmetic, result marked uniform
+NM_DEV double uexp(double x) { return uniform_f64(dexp(x)); }
+NM_DEV double ulog(double x) { return uniform_f64(dlog(x)); }
+NM_DEV double ulog1p(double x) {
+    double u = 1.0 + x;
+    if (u == 1.0) return x;
+    if (!(u == u) || __builtin_isinf(u)) return ulog(u);
+    return ulog(u) * (x / (u - 1.0));
+}
+// reference src/math/util.rs:6-19
+NM_DEV double logaddexp(double a, double b) {
+    if (a == b) return a + ulog(2.0);
+    double diff = a - b;
+    if (diff > 0.) return a + ulog1p(uexp(-diff));
+    if (diff < 0.) return b + ulog1p(uexp(diff));
     return diff;
 }
 
@@ -181,7 +205,7 @@ NM_DEV double clampd(double v, double lo, double hi) {   // f64::clamp: NaN stay
 NM_DEV double fmin_rs(double a, double b) { return __builtin_fmin(a, b); }
 
 // ---- ChaCha8 word stream (rand's ChaCha8Rng semantics; see oracle/nmo_rng.hpp for the restated spec) -----
-NM_DEV void chacha8_block(const uint32_t (&key)[8], uint64_t counter, uint64_t stream, uint32_t (&out)[16]) {
+NM_DEV void chacha8_block(const uint32_t* key, uint64_t counter, uint64_t stream, uint32_t (&out)[16]) {
     uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
                       key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
                       (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
@@ -205,16 +229,15 @@ NM_DEV void chacha8_block(const uint32_t (&key)[8], uint64_t counter, uint64_t s
 
 // Wave-uniform generator.  The 64 lanes produce 64 consecutive blocks (1024 words) into an LDS cache; every
 // lane then reads the same word (LDS broadcast), so all scalar control flow driven by the stream is uniform.
-constexpr int RNG_CACHE_WORDS = 1024;
+constexpr int RNG_CACHE_WORDS = 512;    // 32 ChaCha blocks, produced by lanes 0..31
 struct DevRng {
-    uint32_t key[8];
+    const uint32_t* key;   // 8 words (LDS)
     uint64_t pos;      // next u32 word of the stream
     uint64_t base;     // stream position of cache word 0 (multiple of 16)
     uint32_t* cache;   // LDS, RNG_CACHE_WORDS words, private to this wave
 
     NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* lds) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) key[i] = k[i];
+        key = k;
         pos = p;
         base = p + 16;   // invalid: forces a refill on first use
         cache = lds;
@@ -223,13 +246,15 @@ struct DevRng {
     NM_DEV void refill() {
         __syncthreads();
         base = pos & ~15ull;
-        uint32_t out[16];
-        chacha8_block(key, (base >> 4) + (uint64_t)lane_id(), 0ull, out);
-        uint4* dst = reinterpret_cast<uint4*>(cache + lane_id() * 16);
-        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-        dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
-        dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+        if (lane_id() < RNG_CACHE_WORDS / 16) {
+            uint32_t out[16];
+            chacha8_block(key, (base >> 4) + (uint64_t)lane_id(), 0ull, out);
+            uint4* dst = reinterpret_cast<uint4*>(cache + lane_id() * 16);
+            dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+            dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+            dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+        }
         __syncthreads();
     }
     NM_DEV uint32_t next_u32() {
@@ -270,17 +295,17 @@ NM_DEV double normal_slow_path(DevRng& rng, uint64_t bits, ZigTables T) {
             while (-2.0 * yy < xx * xx) {
                 double a = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
                 double b = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
-                xx = dlog(a) / ZIG_R;
-                yy = dlog(b);
+                xx = ulog(a) / ZIG_R;
+                yy = ulog(b);
             }
             return u < 0.0 ? xx - ZIG_R : ZIG_R - xx;
         }
-        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * rng.random_f64() < dexp(-x * x / 2.0)) return x;
+        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * rng.random_f64() < uexp(-x * x / 2.0)) return x;
         bits = rng.next_u64();
     }
 }
 
-// `count` StandardNormal variates of the stream, in stream order, into stage[0..count) (LDS).
+// `count` StandardNormal variates of the stream, in stream order, into stage[0..count) (LDS or global scratch).
 // 64 samples are attempted per pass from 64 consecutive u64 of the stream (one per lane); the samples before
 // the first lane whose fast-path test fails are exactly what the sequential algorithm would have produced;
 // that lane's sample is finished on the slow path and the pass restarts behind it.

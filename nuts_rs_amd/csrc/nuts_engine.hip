@@ -524,11 +524,17 @@ template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
     const uint64_t i = blockIdx.x;
     const int dim = (int)A.P.dim;
-    ChainCtx<DPL, Dens> C(A.P);
+    __shared__ double lsig[64 * DPL], lmu[64 * DPL];
+    __shared__ ChainScalars lsc;
+    ChainCtx<DPL, Dens> C(A.P, lsc);
     C.dim = dim;
     C.dens.init(A.P.logp_params, dim);
-    load_row(C.sig, A.sigma + i * dim, dim);
-    load_row(C.mu, A.mu + i * dim, dim);
+    C.lsig = lsig; C.lmu = lmu;
+    {
+        Tile<DPL> t;
+        load_row(t, A.sigma + i * dim, dim); store_tile(t, C.lsig);
+        load_row(t, A.mu + i * dim, dim); store_tile(t, C.lmu);
+    }
     Pt<DPL> s0, s;
     load_row(s0.z, A.z + i * dim, dim);
     load_row(s0.v, A.v + i * dim, dim);
@@ -565,7 +571,7 @@ __global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, con
     case 0: r = dexp(x); break;
     case 1: r = dlog(x); break;
     case 2: r = dlog1p(x); break;
-    case 3: r = logaddexp(x, y); break;
+    case 3: r = logaddexp_lane(x, y); break;
     case 4: r = __builtin_sqrt(x); break;
     case 5: r = x / y; break;
     default: r = __builtin_nan("");
@@ -575,7 +581,7 @@ __global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, con
 __global__ __launch_bounds__(64) void normal_batch_kernel(uint64_t count, const uint32_t* keys, const double* zig_x,
                                                           const double* zig_f, double* out, uint64_t* words) {
     __shared__ uint32_t cache[RNG_CACHE_WORDS];
-    __shared__ double stage[1024];
+    __shared__ double stage[1024];   // LDS staging in this test kernel (the engine stages through its HBM scratch)
     const uint64_t i = blockIdx.x;
     DevRng rng;
     rng.init(keys + 8 * i, 0, cache);

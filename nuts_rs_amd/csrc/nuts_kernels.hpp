@@ -154,7 +154,7 @@ struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/t
                 acc = acc + (d < dim ? dlog(params[d < dim ? d : 0]) : 0.0);
             }
         double log_det_p = wave_sum(acc);
-        norm = -0.5 * ((double)dim * dlog(6.283185307179586) - log_det_p);
+        norm = -0.5 * ((double)dim * ulog(6.283185307179586) - log_det_p);
     }
     template <int DPL>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
@@ -187,8 +187,10 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
 template <int DPL>
 struct WaveShared {       // LDS of one wave (one block = one wave)
     uint32_t rng_cache[RNG_CACHE_WORDS];
-    double stage[64 * DPL];
+    double sig[64 * DPL];     // DiagMassMatrix stds of the resident chain, tile order
+    double mu[64 * DPL];      // DiagMassMatrix mean
     PendEntry pend[MAX_MAXDEPTH + 1];
+    ChainScalars sc;          // the resident chain's scalars (copied in at ctx_begin, back at ctx_end)
 };
 
 template <int DPL, class Dens>
@@ -199,14 +201,14 @@ struct ChainCtx {
     ZigTables zig;
     double* pv;         // this chain's persistent slots
     double* sv;         // this wave's tree scratch
-    double* stage;      // LDS [64*DPL] staging for normals
+    double* lsig;       // LDS [64*DPL]: sigma of the resident chain (tile order: lane l reads its own elements)
+    double* lmu;        // LDS [64*DPL]: mu
     PendEntry* pend;    // LDS
     int dim;
     int maxdepth_cfg;
-    ChainScalars sc;
-    Tile<DPL> sig, mu;  // mass matrix in registers while the chain is resident
+    ChainScalars& sc;   // LDS
 
-    __device__ ChainCtx(const KParams& p) : P(p) {}
+    __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
     NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
 };
@@ -218,17 +220,32 @@ NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chai
     C.maxdepth_cfg = (int)P.s.maxdepth;
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
-    C.stage = sh.stage;
+    C.lsig = sh.sig;
+    C.lmu = sh.mu;
     C.pend = sh.pend;
     C.zig = {P.zig_x, P.zig_f};
-    C.sc = P.sc[chain];
+    {   // chain scalars: HBM -> LDS
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&P.sc[chain]);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc);
+        constexpr int NW = (int)(sizeof(ChainScalars) / 8);
+        static_assert(sizeof(ChainScalars) % 8 == 0 && NW <= 64, "ChainScalars must be <= 64 u64 words");
+        __syncthreads();
+        if (lane_id() < NW) dst[lane_id()] = src[lane_id()];
+        __syncthreads();
+    }
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
     C.dens.init(P.logp_params, C.dim);
 }
 template <int DPL, class Dens>
 NM_DEV void ctx_end(ChainCtx<DPL, Dens>& C, uint64_t chain) {
     C.sc.rng_pos = C.rng.pos;
-    if (lane_id() == 0) C.P.sc[chain] = C.sc;
+    __syncthreads();
+    {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&C.sc);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&C.P.sc[chain]);
+        constexpr int NW = (int)(sizeof(ChainScalars) / 8);
+        if (lane_id() < NW) dst[lane_id()] = src[lane_id()];
+    }
 }
 
 // a phase-space point in registers
@@ -246,21 +263,33 @@ template <int DPL, class Dens>
 NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     const double half = epsilon / 2.;
     Tile<DPL> x, gx;
+    const double2* sg2 = reinterpret_cast<const double2*>(C.lsig) + lane_id();
+    const double2* mu2 = reinterpret_cast<const double2*>(C.lmu) + lane_id();
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-        double vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-        o.v.a[k] = vh;
-        o.z.a[k] = __builtin_fma(epsilon, vh, s.z.a[k]);
-        double t = o.z.a[k] * C.sig.a[k];
-        x.a[k] = __builtin_fma(1.0, C.mu.a[k], t);
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64], mm = mu2[m * 64];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * m + j;
+            double vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+            o.v.a[k] = vh;
+            o.z.a[k] = __builtin_fma(epsilon, vh, s.z.a[k]);
+            double t = o.z.a[k] * (j ? sg.y : sg.x);
+            x.a[k] = __builtin_fma(1.0, (j ? mm.y : mm.x), t);
+        }
     }
     o.logp = C.dens.template eval<DPL>(x, gx, C.dim);
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-        o.g.a[k] = gx.a[k] * C.sig.a[k];
-        o.v.a[k] = __builtin_fma(half, o.g.a[k], o.v.a[k]);
-        acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * m + j;
+            o.g.a[k] = gx.a[k] * (j ? sg.y : sg.x);
+            o.v.a[k] = __builtin_fma(half, o.g.a[k], o.v.a[k]);
+            acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
+        }
     }
     o.ke = 0.5 * wave_sum(acc);
     if (x_out) *x_out = x;
@@ -275,9 +304,9 @@ struct AcceptCollector {
     NM_DEV void register_divergent() { sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf(); }
     NM_DEV void register_ok(double end_energy) {
         double diff = initial_energy - end_energy;
-        double e = dexp(fmin_rs(diff, 0.));
+        double e = uexp(fmin_rs(diff, 0.));
         sum = sum + e;
-        sum_sym = sum_sym + 2. * e / (1. + dexp(diff));
+        sum_sym = sum_sym + 2. * e / (1. + uexp(diff));
         count += 1;
         if (__builtin_fabs(diff) > __builtin_fabs(max_energy_error)) max_energy_error = diff;
     }
@@ -293,11 +322,12 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
     t2 = __builtin_fma(s, ve, t2);
 }
 
-// momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577)
+// momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577).  The stream-ordered samples are
+// staged through `stage` (a [64*DPL] scratch vector in HBM/L2 owned by this wave) and re-read in tile order.
 template <int DPL, class Dens>
-NM_DEV void sample_velocity(ChainCtx<DPL, Dens>& C, Tile<DPL>& v) {
-    fill_standard_normals(C.rng, C.stage, C.dim, C.zig);
-    const double2* st = reinterpret_cast<const double2*>(C.stage) + lane_id();
+NM_DEV void sample_velocity(ChainCtx<DPL, Dens>& C, Tile<DPL>& v, double* stage) {
+    fill_standard_normals(C.rng, stage, C.dim, C.zig);
+    const double2* st = reinterpret_cast<const double2*>(stage) + lane_id();
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
         double2 q = st[m * 64];
@@ -330,10 +360,10 @@ NM_DEV double sum_ln_tile(const ChainCtx<DPL, Dens>& C, const Tile<DPL>& t) {
 NM_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
 
 NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // DualAverage::new dual_avg.rs:44-53
-    sc.log_step = dlog(initial_step);
-    sc.log_step_adapted = dlog(initial_step);
+    sc.log_step = ulog(initial_step);
+    sc.log_step_adapted = ulog(initial_step);
     sc.hbar = 0.;
-    sc.mu = dlog(10. * initial_step);
+    sc.mu = ulog(10. * initial_step);
     sc.da_count = 1;
 }
 
@@ -342,14 +372,16 @@ NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // Dua
 template <int DPL, class Dens>
 NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
     st.logp = C.dens.template eval<DPL>(x, gx, C.dim);
-    Tile<DPL> isig;
+    Tile<DPL> isig, sig, mu;
     load_tile(isig, C.slot(P_ISIG));
+    load_tile(sig, C.lsig);
+    load_tile(mu, C.lmu);
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-        double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);     // compute_transformed_position diagonal.rs:233-246
+        double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);       // compute_transformed_position diagonal.rs:233-246
         st.z.a[k] = isig.a[k] * t;
-        st.g.a[k] = gx.a[k] * C.sig.a[k];                     // compute_transformed_gradient :258-265
+        st.g.a[k] = gx.a[k] * sig.a[k];                       // compute_transformed_gradient :258-265
         bool valid = elem_index(k) < C.dim;
         ok = ok && (!valid || (is_finite(st.z.a[k]) && is_finite(st.g.a[k]) && st.g.a[k] != 0.0 &&
                                is_finite(gx.a[k]) && is_finite(x.a[k])));
@@ -368,7 +400,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
         if (!init_state(C, x, st, gx)) return NM_CHAIN_BAD_INIT;
     }
     const double logdet = C.sc.mm_logdet;
-    sample_velocity(C, st.v);                                   // initialize_trajectory(resample) :687-736
+    sample_velocity(C, st.v, C.sslot(ML_V));                    // initialize_trajectory(resample) :687-736
     const double ke0 = kinetic(st.v);
     const double e0 = ke0 - (st.logp + logdet);
     AcceptCollector col;
@@ -405,7 +437,7 @@ template <int DPL, class Dens>
 NM_DEV void update_stepsize(ChainCtx<DPL, Dens>& C, bool use_best_guess) {
     const nm_settings& s = C.P.s;
     double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
-                                                      : (use_best_guess ? dexp(C.sc.log_step_adapted) : dexp(C.sc.log_step));
+                                                      : (use_best_guess ? uexp(C.sc.log_step_adapted) : uexp(C.sc.log_step));
     if (s.has_jitter) {
         double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
         double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
@@ -425,7 +457,7 @@ NM_DEV void update_estimator(ChainCtx<DPL, Dens>& C, bool late) {
     sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
     sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
     sc.log_step = fmin_rs(sc.log_step, C.P.ln_max_step);
-    const double mk = dexp(-s.da_k * dlog((double)sc.da_count));
+    const double mk = uexp(-s.da_k * ulog((double)sc.da_count));
     sc.log_step_adapted = mk * sc.log_step + (1. - mk) * sc.log_step_adapted;
     sc.da_count += 1;
 }
@@ -448,12 +480,14 @@ NM_DEV void running_variance_add(ChainCtx<DPL, Dens>& C, int slot_mean, int slot
     store_tile(var, C.slot(slot_var));
 }
 
-// writes sigma/inv_sigma/mu (registers + HBM), logdet, id
+// writes sigma / inv_sigma / mu (HBM + the LDS copy of the resident chain), logdet, id
 template <int DPL, class Dens>
-NM_DEV void commit_mass_matrix(ChainCtx<DPL, Dens>& C, const Tile<DPL>& isig) {
-    store_tile(C.sig, C.slot(P_SIG));
+NM_DEV void commit_mass_matrix(ChainCtx<DPL, Dens>& C, const Tile<DPL>& sig, const Tile<DPL>& isig, const Tile<DPL>& mu) {
+    store_tile(sig, C.slot(P_SIG));
     store_tile(isig, C.slot(P_ISIG));
-    store_tile(C.mu, C.slot(P_MU));
+    store_tile(mu, C.slot(P_MU));
+    store_tile(sig, C.lsig);
+    store_tile(mu, C.lmu);
     C.sc.mm_logdet = sum_ln_tile(C, isig);
     C.sc.mm_id += 1;
 }
@@ -461,7 +495,7 @@ NM_DEV void commit_mass_matrix(ChainCtx<DPL, Dens>& C, const Tile<DPL>& isig) {
 // DiagMassMatrix::update_diag_grad (reference diagonal.rs:133-154, cpu_math.rs:710-738)
 template <int DPL, class Dens>
 NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, const Tile<DPL>& gx) {
-    Tile<DPL> isig;
+    Tile<DPL> sig, isig, mu;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         bool valid = elem_index(k) < C.dim;
@@ -471,11 +505,11 @@ NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, co
         double var = sd * sd;
         double mean = var * gx.a[k];
         mean = __builtin_fma(1.0, x.a[k], mean);
-        C.sig.a[k] = valid ? sd : 0.0;
+        sig.a[k] = valid ? sd : 0.0;
         isig.a[k] = valid ? isd : 0.0;
-        C.mu.a[k] = valid ? mean : 0.0;
+        mu.a[k] = valid ? mean : 0.0;
     }
-    commit_mass_matrix(C, isig);
+    commit_mass_matrix(C, sig, isig, mu);
 }
 
 // Strategy::adapt -> update_diag_draw_grad / update_diag_draw (reference adapt/diagonal.rs:161-196,
@@ -483,7 +517,8 @@ NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, co
 template <int DPL, class Dens>
 NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
     if (C.sc.cnt_fg < 3) return false;
-    Tile<DPL> isig, dm, dv;
+    Tile<DPL> sig, isig, mu, dm, dv;
+    load_tile(sig, C.lsig);
     load_tile(isig, C.slot(P_ISIG));
     load_tile(dm, C.slot(E_DM));
     load_tile(dv, C.slot(E_DV));
@@ -495,7 +530,7 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
         for (int k = 0; k < DPL; ++k) {
             bool valid = elem_index(k) < C.dim;
             double val = __builtin_sqrt(dv.a[k] / gv.a[k]);
-            double sd = C.sig.a[k], isd = isig.a[k];
+            double sd = sig.a[k], isd = isig.a[k];
             if (!(!is_finite(val) | (val == 0.0))) {
                 val = clampd(val, 1e-20, 1e20);
                 sd = __builtin_sqrt(val);
@@ -504,9 +539,9 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
             double var = sd * sd;
             double mean = var * gm.a[k];
             mean = __builtin_fma(1.0, dm.a[k], mean);
-            C.sig.a[k] = valid ? sd : 0.0;
+            sig.a[k] = valid ? sd : 0.0;
             isig.a[k] = valid ? isd : 0.0;
-            C.mu.a[k] = valid ? mean : 0.0;
+            mu.a[k] = valid ? mean : 0.0;
         }
     } else {
         const double scale = 1.0 / (double)C.sc.cnt_fg;
@@ -514,18 +549,18 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
         for (int k = 0; k < DPL; ++k) {
             bool valid = elem_index(k) < C.dim;
             double d = dv.a[k] * scale;
-            double sd = C.sig.a[k], isd = isig.a[k];
+            double sd = sig.a[k], isd = isig.a[k];
             if (!(!is_finite(d) | (d == 0.0))) {
                 double val = clampd(d, 1e-20, 1e20);
                 sd = __builtin_sqrt(val);
                 isd = __builtin_sqrt(1.0 / val);
             }
-            C.sig.a[k] = valid ? sd : 0.0;
+            sig.a[k] = valid ? sd : 0.0;
             isig.a[k] = valid ? isd : 0.0;
-            C.mu.a[k] = valid ? dm.a[k] : 0.0;
+            mu.a[k] = valid ? dm.a[k] : 0.0;
         }
     }
-    commit_mass_matrix(C, isig);
+    commit_mass_matrix(C, sig, isig, mu);
     return true;
 }
 
@@ -632,7 +667,7 @@ NM_DEV bool merge_weights(ChainCtx<DPL, Dens>& C, double a_log_size, double b_lo
     total = logaddexp(a_log_size, b_log_size);
     const double self_log_size = is_main ? a_log_size : total;
     if (b_log_size >= self_log_size) return true;
-    int b = C.rng.random_bool(dexp(b_log_size - self_log_size));
+    int b = C.rng.random_bool(uexp(b_log_size - self_log_size));
     if (b < 0) { fatal = true; return false; }
     return b == 1;
 }
@@ -678,17 +713,19 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
-    sample_velocity(C, E.v);
+    sample_velocity(C, E.v, C.sslot(ML_V));
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
-        Tile<DPL> x, gx, isig;
+        Tile<DPL> x, gx, isig, sig, mu;
         load_tile(x, C.slot(P_X));
         load_tile(gx, C.slot(P_GX));
         load_tile(isig, C.slot(P_ISIG));
+        load_tile(sig, C.lsig);
+        load_tile(mu, C.lmu);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            double t = __builtin_fma(-1.0, C.mu.a[k], x.a[k]);
+            double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
             E.z.a[k] = isig.a[k] * t;
-            E.g.a[k] = gx.a[k] * C.sig.a[k];
+            E.g.a[k] = gx.a[k] * sig.a[k];
         }
         store_tile(E.z, C.slot(P_Z));
         store_tile(E.g, C.slot(P_GZ));
@@ -1005,14 +1042,17 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
         load_tile(z, C.slot(P_Z)); load_tile(gz, C.slot(P_GZ));
     } else {
         // the winner's x, g_x, g_z from its z: the same operations as inside the leapfrog => the same bits
+        Tile<DPL> sig, mu;
+        load_tile(sig, C.lsig);
+        load_tile(mu, C.lmu);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            double tt = z.a[k] * C.sig.a[k];
-            x.a[k] = __builtin_fma(1.0, C.mu.a[k], tt);
+            double tt = z.a[k] * sig.a[k];
+            x.a[k] = __builtin_fma(1.0, mu.a[k], tt);
         }
         (void)C.dens.template eval<DPL>(x, gx, C.dim);
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) gz.a[k] = gx.a[k] * C.sig.a[k];
+        for (int k = 0; k < DPL; ++k) gz.a[k] = gx.a[k] * sig.a[k];
         store_tile(x, C.slot(P_X)); store_tile(gx, C.slot(P_GX));
         store_tile(z, C.slot(P_Z)); store_tile(gz, C.slot(P_GZ));
         sc.logp = R.chosen.logp;
@@ -1041,7 +1081,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
     out.index_in_trajectory = idx; out.transformation_index = tid;
     out.step_size = sc.step_size;
-    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size : dexp(sc.log_step_adapted);
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size : uexp(sc.log_step_adapted);
     out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
     out.max_energy_error = sc.last_max_energy_error;
     out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
@@ -1059,11 +1099,14 @@ template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void nuts_draw_kernel(const KParams P) {
     __shared__ WaveShared<DPL> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, Dens> C(P);
+        ChainCtx<DPL, Dens> C(P, sh.sc);
         ctx_begin(C, sh, chain, blockIdx.x);
         if (C.sc.status == NM_CHAIN_OK) {
-            load_tile(C.sig, C.slot(P_SIG));
-            load_tile(C.mu, C.slot(P_MU));
+            {
+                Tile<DPL> t;
+                load_tile(t, C.slot(P_SIG)); store_tile(t, C.lsig);
+                load_tile(t, C.slot(P_MU)); store_tile(t, C.lmu);
+            }
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
                 if (C.sc.status != NM_CHAIN_OK) break;
@@ -1079,7 +1122,7 @@ template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void nuts_init_kernel(const KParams P) {
     __shared__ WaveShared<DPL> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, Dens> C(P);
+        ChainCtx<DPL, Dens> C(P, sh.sc);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
         dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)

@@ -1,40 +1,62 @@
-"""Summarise a rocprofv3 rocpd database (--kernel-trace --stats [--pmc ...]) into a small text file for profiles/."""
+"""Summarise rocprofv3 rocpd databases into small text/JSON files for profiles/.
+
+  python tools/rocprof_summary.py trace <trace_results.db> <out.txt>
+  python tools/rocprof_summary.py pmc <dir with fetch/write/tcc/trace _results.db> <out.json> [kernel substring]
+"""
+import json
+import os
 import sqlite3
 import sys
 
 
-def main(db, out):
+def trace(db, out):
     c = sqlite3.connect(db)
-    lines = []
-    lines.append("# per-kernel stats (rocprofv3 --kernel-trace --stats): name, calls, total_ns, average_ns, percent")
+    lines = ["# rocprofv3 --kernel-trace --stats : per-kernel totals (top_kernels view; durations in microseconds)"]
     for r in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-        lines.append("%s | calls=%d | total_ns=%.0f | avg_ns=%.0f | pct=%.3f" % r)
-    lines.append("")
-    lines.append("# per-dispatch: kernel, grid, workgroup, duration_ns, vgpr, accum_vgpr, sgpr, lds, scratch")
+        lines.append("%s | calls=%d | total_us=%.1f | avg_us=%.1f | pct=%.3f" % r)
+    lines += ["", "# per dispatch (durations in ns): kernel | grid | wg | dur_ns | vgpr | agpr | sgpr | lds | scratch"]
     for r in c.execute("select name, grid_x, workgroup_x, duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, "
                        "scratch_size from kernels order by start"):
         lines.append("%s | grid=%d | wg=%d | dur_ns=%d | vgpr=%d | agpr=%d | sgpr=%d | lds=%d | scratch=%d" % r)
-    try:
-        rows = list(c.execute("select * from counters_collection"))
-        if rows:
-            cur = c.execute("select * from counters_collection limit 1")
-            cols = [d[0] for d in cur.description]
-            lines.append("")
-            lines.append("# counters_collection columns: " + ", ".join(cols))
-            ki, ci, vi = cols.index("kernel_name") if "kernel_name" in cols else None, None, None
-            for name in ("counter_name", "name"):
-                if name in cols:
-                    ci = cols.index(name)
-            for name in ("value", "counter_value"):
-                if name in cols:
-                    vi = cols.index(name)
-            for r in rows:
-                lines.append(" | ".join(str(x) for x in r))
-    except sqlite3.Error as e:
-        lines.append("# no counters: %s" % e)
     open(out, "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:40]))
+    print("\n".join(lines))
+
+
+def counters(db, sub):
+    c = sqlite3.connect(db)
+    res = {}
+    for name, cname, val in c.execute("select kernel_name, counter_name, value from counters_collection order by start"):
+        if sub in name:
+            res.setdefault(cname, []).append(val)
+    return res
+
+
+def pmc(d, out, sub="nuts_draw_kernel"):
+    """The LAST dispatch of the kernel is bench.py's timed launch (tune, warm-up, timed)."""
+    c = sqlite3.connect(os.path.join(d, "trace_results.db"))
+    durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + sub + "%",))]
+    res = {"kernel": sub, "dispatches": len(durs), "timed_launch_duration_ns": durs[-1] if durs else None}
+    for f in ("fetch", "write", "tcc"):
+        p = os.path.join(d, f + "_results.db")
+        if os.path.exists(p):
+            for k, v in counters(p, sub).items():
+                res[k] = v[-1]
+    if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+        # MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+        # (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE has no documented correction.
+        res["fetch_bytes_corrected"] = res["FETCH_SIZE"] * 1024 * 2
+        res["write_bytes"] = res["WRITE_SIZE"] * 1024
+        res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
+        if res["timed_launch_duration_ns"]:
+            res["hbm_GBps_over_kernel"] = res["hbm_bytes_per_launch"] / res["timed_launch_duration_ns"]
+    if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res:
+        res["l2_hit_rate"] = res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
