@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--dims-per-lane", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-chains", type=int, default=0, help="chains of the bounded CPU sample (0 = 2 per host core)")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     return p.parse_args()
 
 
@@ -98,12 +99,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist_mod.init_process_group(args.dist_backend)
         dist = dist_mod
 
     def barrier():
@@ -115,7 +125,7 @@ def main():
     settings = N.DiagNutsSettings(num_chains=C_ * world, seed=args.seed, num_tune=args.num_tune,
                                   num_draws=args.steps + args.warmup)
     batch = N.ChainBatch(settings, N.LogpSpec.iid_normal(D, 3.0), C_, chain_id_offset=rank * C_,
-                         device=local_rank, dims_per_lane=args.dims_per_lane)
+                         device=device_index, dims_per_lane=args.dims_per_lane)
     x0 = batch.init_positions_uniform()
     status = batch.set_position(x0)
     assert (status == 0).all()
@@ -141,10 +151,10 @@ def main():
     steps_local = c["total_leapfrogs"]
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
-        sv = torch.tensor([float(steps_local), float(c_tune["total_leapfrogs"]), t_tune], dtype=torch.float64, device="cuda")
+        sv = torch.tensor([float(steps_local), float(c_tune["total_leapfrogs"]), t_tune], dtype=torch.float64, device=red_dev)
         sv_max = sv.clone()
         dist.all_reduce(sv, op=dist.ReduceOp.SUM)
         dist.all_reduce(sv_max, op=dist.ReduceOp.MAX)

@@ -162,6 +162,8 @@ static hipError_t launch(uint64_t logp_kind, int dpl, KernelKind kind, const KPa
     switch (logp_kind) {
     case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, kind, P, grid, stream, occ);
     case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, kind, P, grid, stream, occ);
+    case NM_LOGP_FUNNEL: return launch_d<Funnel>(dpl, kind, P, grid, stream, occ);
+    case NM_LOGP_EIGHT_SCHOOLS: return dpl == 2 ? launch_t<2, EightSchools>(kind, P, grid, stream, occ) : hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -185,8 +187,11 @@ static nm_status check_logp(const nm_logp_spec* l) {
         if (l->n_params != l->dim || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_DIAG_NORMAL takes dim parameters");
         return NM_OK;
     case NM_LOGP_FUNNEL:
+        if (l->dim < 2) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_FUNNEL needs dim >= 2 (v plus at least one x)");
+        return NM_OK;
     case NM_LOGP_EIGHT_SCHOOLS:
-        return fail(NM_ERR_UNSUPPORTED, "logp kind %llu is declared but not implemented in this build", (unsigned long long)l->kind);
+        if (l->dim != 10 || l->n_params != 16 || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_EIGHT_SCHOOLS: dim 10, params = y[8], sigma[8]");
+        return NM_OK;
     }
     return fail(NM_ERR_INVALID_ARG, "unknown logp kind %llu", (unsigned long long)l->kind);
 }
@@ -266,7 +271,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (s.has_jitter && !(1.0 - s.jitter < 1.0 + s.jitter)) return fail(NM_ERR_INVALID_ARG, "invalid jitter");
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
-    const int dpl = pick_dpl(logp->dim, cfg.dims_per_lane);
+    const int dpl = logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : pick_dpl(logp->dim, cfg.dims_per_lane);
     if (!dpl) return fail(NM_ERR_UNSUPPORTED, "dim %llu needs more than 16 doubles per lane (or dims_per_lane %llu invalid); max dim is 1024 in this build",
                           (unsigned long long)logp->dim, (unsigned long long)cfg.dims_per_lane);
     st = ensure_device(cfg.device);
@@ -304,9 +309,9 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMemsetAsync(e->d_svec, 0, svec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_sc, n_chains * sizeof(ChainScalars)));
     E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
-    E_TRY(hipMalloc(&e->d_params, logp->n_params * sizeof(double)));
+    E_TRY(hipMalloc(&e->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
-    E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     {   // ziggurat tables of rand_distr's StandardNormal (Marsaglia & Tsang, 256 layers)
         std::vector<double> t(2 * 257);
         double* x = t.data();
@@ -627,16 +632,21 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
     if (!dpl) return fail(NM_ERR_UNSUPPORTED, "unsupported dim / dims_per_lane");
     if (n == 0) return NM_OK;
     double* d_params = nullptr;
-    HIP_TRY(hipMalloc(&d_params, logp->n_params * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
+    if (logp->n_params) HIP_TRY(hipMemcpy(d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     LfArgs A;
     memset(&A, 0, sizeof A);
     A.P.dim = logp->dim; A.P.dpad = 64ull * dpl; A.P.logp_params = d_params; A.P.n_chains = n;
     A.z = d_z; A.v = d_v; A.gz = d_gz; A.sigma = d_sigma; A.mu = d_mu; A.eps = d_eps; A.logdet = d_logdet; A.e0 = d_initial_energy;
     A.z_out = d_z_out; A.v_out = d_v_out; A.gz_out = d_gz_out; A.x_out = d_x_out; A.gx_out = d_gx_out;
     A.logp_out = d_logp_out; A.ke_out = d_kinetic_out; A.err_out = d_energy_error_out;
-    hipError_t er = logp->kind == NM_LOGP_IID_NORMAL ? launch_lf_d<IidNormal>(dpl, A, n, (hipStream_t)stream)
-                                                     : launch_lf_d<DiagNormal>(dpl, A, n, (hipStream_t)stream);
+    hipError_t er;
+    switch (logp->kind) {
+    case NM_LOGP_IID_NORMAL: er = launch_lf_d<IidNormal>(dpl, A, n, (hipStream_t)stream); break;
+    case NM_LOGP_DIAG_NORMAL: er = launch_lf_d<DiagNormal>(dpl, A, n, (hipStream_t)stream); break;
+    case NM_LOGP_FUNNEL: er = launch_lf_d<Funnel>(dpl, A, n, (hipStream_t)stream); break;
+    default: er = launch_lf_d<EightSchools>(2, A, n, (hipStream_t)stream); break;
+    }
     if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d_params);
     if (er != hipSuccess) return fail(NM_ERR_HIP, "leapfrog_batch: %s", hipGetErrorString(er));

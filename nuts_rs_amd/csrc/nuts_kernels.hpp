@@ -173,6 +173,87 @@ struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/t
     }
 };
 
+// Neal's funnel (defined by this repo, absent from the reference): x[0] = v ~ N(0, 3^2),
+// x[i] | v ~ N(0, e^v), i = 1..dim-1.  logp = -v^2/18 - (k/2) v - e^{-v}/2 * sum x_i^2  (k = dim - 1).
+// Same operation order as oracle/nmo_nuts.hpp LOGP_FUNNEL.
+struct Funnel {
+    NM_DEV void init(const double*, int) {}
+    template <int DPL>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+        const double v = readlane_f64(x.a[0], 0);                 // element 0 lives in lane 0, register 0
+        const double kk = (double)(dim - 1);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            bool in = d >= 1 && d < dim;
+            acc = acc + (in ? x.a[k] * x.a[k] : 0.0);
+        }
+        const double ss = wave_sum(acc);
+        const double ev = uexp(-v);
+        const double g0 = -v / 9.0 - 0.5 * kk + 0.5 * ev * ss;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            gx.a[k] = d == 0 ? g0 : (d < dim ? -ev * x.a[k] : 0.0);
+        }
+        return -v * v / 18.0 - 0.5 * kk * v - 0.5 * ev * ss;
+    }
+};
+
+// Non-centered eight schools (defined by this repo): x = (mu, log tau, theta~[8]), params = y[8], sigma[8].
+// mu ~ N(0,5^2), tau ~ HalfCauchy(5) (+ log-Jacobian), theta~ ~ N(0,1), y_i ~ N(mu + tau theta~_i, sigma_i^2).
+// Same operation order as oracle/nmo_nuts.hpp LOGP_EIGHT_SCHOOLS (dim = 10: elements 2l, 2l+1 in lane l).
+struct EightSchools {
+    const double* par;
+    NM_DEV void init(const double* params, int) { par = params; }
+    template <int DPL>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+        const double mu = readlane_f64(x.a[0], 0), lt = readlane_f64(x.a[1], 0);
+        const double tau = uexp(lt);
+        const double t5 = (tau / 5.0) * (tau / 5.0);
+        const double prior_tau = lt - ulog1p(t5);
+        // per-lane school terms: lane l (1..4) holds theta~_{2l-2}, theta~_{2l-1}
+        double term[2], dr[2], drth[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int d = elem_index(j);
+            bool school = d >= 2 && d < 10;
+            int i = school ? d - 2 : 0;
+            double th = x.a[j];
+            double sg = par[8 + i];
+            double r = (par[i] - (mu + tau * th)) / sg;
+            term[j] = -0.5 * th * th - 0.5 * r * r;
+            dr[j] = r / sg;
+            drth[j] = dr[j] * th;
+            if (!school) { term[j] = 0.0; dr[j] = 0.0; drth[j] = 0.0; }
+        }
+        // gmu = sum_i dr_i and gtau_lin = sum_i dr_i theta_i, sequentially in i (the oracle's loop order)
+        double gmu = 0.0, gtl = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = (2 + i) >> 1, j = (2 + i) & 1;
+            gmu = gmu + readlane_f64(j ? dr[1] : dr[0], l);
+            gtl = gtl + readlane_f64(j ? drth[1] : drth[0], l);
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            int d = elem_index(k);
+            double t = 0.0, g = 0.0;
+            if (k < 2) {
+                if (d == 0) { t = -mu * mu / 50.0; g = -mu / 25.0 + gmu; }
+                else if (d == 1) { t = prior_tau; g = 1.0 - 2.0 * t5 / (1.0 + t5) + gtl * tau; }
+                else if (d < 10) { t = term[k]; g = -x.a[k] + dr[k] * tau; }
+            }
+            gx.a[k] = g;
+            acc = acc + t;
+        }
+        (void)dim;
+        return wave_sum(acc);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Per-wave context: everything a chain keeps in registers / SGPRs while its kernel runs
 // ---------------------------------------------------------------------------------------------

@@ -129,9 +129,19 @@ class LogpSpec:
         p = np.ascontiguousarray(precision_diag, dtype=np.float64)
         return LogpSpec(LOGP_DIAG_NORMAL, len(p), p)
 
+    @staticmethod
+    def funnel(dim=101):
+        """Neal's funnel: x[0] = v ~ N(0, 9), x[1:] | v ~ N(0, e^v) (BASELINE config K3, defined by this repo)."""
+        return LogpSpec(LOGP_FUNNEL, dim, np.zeros(0))
+
+    @staticmethod
+    def eight_schools(y=(28., 8., -3., 7., -1., 1., 18., 12.), sigma=(15., 10., 16., 11., 9., 11., 10., 18.)):
+        """Non-centered 8 schools (mu, log tau, theta~[8]) (BASELINE config K4, defined by this repo)."""
+        return LogpSpec(LOGP_EIGHT_SCHOOLS, 10, np.array(list(y) + list(sigma), dtype=np.float64))
+
     def to_c(self):
         self._keep = np.ascontiguousarray(self.params, dtype=np.float64)
-        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data)
+        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data if len(self._keep) else None)
 
 
 class ChainBatch:

@@ -47,6 +47,9 @@ PARITY_CASES = [
     ("target_time", dict(seed=13, num_tune=50, target_integration_time=2.0), 20, 4, 80, "iid", 0),
     ("ragged_scales", dict(seed=14, num_tune=150), 40, 8, 220, "diag", 0),
     ("low_energy_threshold", dict(seed=15, num_tune=50, max_energy_error=0.3), 30, 6, 80, "iid", 0),
+    ("funnel_k3_dim101", dict(seed=16, num_tune=150), 101, 12, 230, "funnel", 0),
+    ("funnel_dim11", dict(seed=17, num_tune=100), 11, 10, 200, "funnel", 0),
+    ("eight_schools_k4", dict(seed=18, num_tune=200), 10, 16, 320, "schools", 0),
 ]
 
 
@@ -58,6 +61,10 @@ def test_chain_parity_bit_exact(oracle, case):
     rng = np.random.default_rng(kw["seed"])
     if dens == "iid":
         logp = N.LogpSpec.iid_normal(dim, 3.0)
+    elif dens == "funnel":
+        logp = N.LogpSpec.funnel(dim)
+    elif dens == "schools":
+        logp = N.LogpSpec.eight_schools()
     else:
         logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-6, 6, dim)))        # scales e^-3 .. e^3: deep, ragged trees
     x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
@@ -68,6 +75,9 @@ def test_chain_parity_bit_exact(oracle, case):
     assert ex["counters"]["total_leapfrogs"] == steps
     if case[0] == "low_energy_threshold":
         assert st_g["diverging"].sum() > 0          # the divergence path was exercised
+    if dens == "funnel":
+        # BASELINE config K3's purpose: divergences and ragged tree depths (chains stop at different depths)
+        assert st_g["diverging"].sum() > 0 and len(np.unique(st_g["depth"])) >= 5
     if case[0] == "ragged_scales":
         assert len(np.unique(st_g["depth"])) >= 4   # ragged depths across chains/draws
 
@@ -169,3 +179,45 @@ def test_k2_full_size_properties():
     pos2, _ = b2.draw_many(50)
     b2.close()
     assert (sub_pos.view(np.uint64) == pos2.view(np.uint64)).all()
+
+
+def test_k3_funnel_full_size_properties():
+    """BASELINE configs[2]: Neal's funnel dim 101 x 8192 chains — the ragged/divergent stress at full size.
+    Properties: every chain survives, depths are ragged, divergences happen, v stays in a sane range and the
+    conditional scale of x follows e^{v/2} (sign + rough magnitude), independent of the oracle."""
+    C_, D = 8192, 101
+    s = N.DiagNutsSettings(num_chains=C_, seed=3, num_tune=200, num_draws=50)
+    b = N.ChainBatch(s, N.LogpSpec.funnel(D), C_)
+    assert (b.set_position(b.init_positions_uniform()) == 0).all()
+    b.draw_device(200)
+    pos, st = b.draw_many(50)
+    c = b.counters()
+    b.close()
+    assert (st["chain_status"] == 0).all() and np.isfinite(pos).all()
+    depth_hist = np.bincount(st["depth"].ravel().astype(int), minlength=11)
+    assert (depth_hist > 0).sum() >= 5 and st["diverging"].mean() > 1e-4
+    v = pos[..., 0]
+    assert -9 < v.mean() < 3 and 1.0 < v.std() < 4.0
+    hi, lo = v > 1.0, v < -1.0
+    assert np.abs(pos[..., 1:][hi]).mean() > 3 * np.abs(pos[..., 1:][lo]).mean()
+    # lane-utilisation figure of merit of a lockstep design (SURVEY §8(d) K3); this engine does not lock-step
+    util = st["n_steps"].sum() / (st["n_steps"].max(axis=1).sum() * C_)
+    assert 0 < util <= 1.0
+
+
+def test_k4_eight_schools_posterior():
+    """BASELINE configs[3] (one GPU's share: 8192 chains x dim 10): posterior summaries of the classic 8-schools
+    model agree with the known values (mu ~ 4.4 +- 3.3, tau median ~ 2.7) — independent of the oracle."""
+    C_ = 8192
+    s = N.DiagNutsSettings(num_chains=C_, seed=4, num_tune=300, num_draws=40)
+    b = N.ChainBatch(s, N.LogpSpec.eight_schools(), C_)
+    assert (b.set_position(b.init_positions_uniform()) == 0).all()
+    b.draw_device(300)
+    pos, st = b.draw_many(40)
+    b.close()
+    assert (st["chain_status"] == 0).all()
+    mu, tau = pos[..., 0], np.exp(pos[..., 1])
+    assert abs(mu.mean() - 4.4) < 0.3 and abs(mu.std() - 3.3) < 0.3
+    assert 2.0 < np.median(tau) < 3.6
+    assert abs(pos[..., 2:].mean()) < 0.15 and abs(pos[..., 2:].std() - 1.0) < 0.1      # theta~ close to N(0,1)
+    assert st["diverging"].mean() < 0.02

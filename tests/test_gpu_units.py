@@ -130,3 +130,37 @@ def test_turning_batch_bit_exact(oracle, dim, dpl):
         o2 = np.empty(2)
         oracle.lib().nmo_scalar_prods3(C.byref(oracle.ref_cfg()), ze[i].copy(), zs[i].copy(), zeros, vs[i].copy(), ve[i].copy(), dim, o2)
         assert np.abs(o - o2).max() <= 1e-12 * max(1.0, np.abs(o2).max()) * dim ** 0.5
+
+
+@pytest.mark.parametrize("kind,dim,dpl", [("funnel", 2, 2), ("funnel", 101, 2), ("funnel", 700, 16), ("schools", 10, 2)])
+def test_leapfrog_batch_other_densities(oracle, kind, dim, dpl):
+    """The densities this repo defines for BASELINE configs K3/K4 (funnel, non-centered 8 schools): fused leapfrog
+    == oracle, bit for bit (same operation order on both sides)."""
+    L = N.load_library()
+    rng = np.random.default_rng(dim)
+    n = 11
+    z, v, gz = rng.normal(size=(n, dim)) * 0.7, rng.normal(size=(n, dim)), rng.normal(size=(n, dim))
+    sigma, mu = np.exp(rng.normal(size=(n, dim)) * 0.3), rng.normal(size=(n, dim)) * 0.5
+    eps = rng.uniform(0.01, 0.3, n) * rng.choice([-1.0, 1.0], n)
+    logdet, e0 = rng.normal(size=n), rng.normal(size=n) * 10
+    logp = N.LogpSpec.funnel(dim) if kind == "funnel" else N.LogpSpec.eight_schools()
+    spec = logp.to_c()
+    d = [dev(a) for a in (z, v, gz, sigma, mu, eps, logdet, e0)]
+    outs = [torch.empty((n, dim), dtype=torch.float64, device="cuda") for _ in range(5)]
+    souts = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    rc = L.nm_leapfrog_batch(C.byref(spec), n, dpl, *[ptr(t) for t in d], *[ptr(t) for t in outs],
+                             *[ptr(t) for t in souts], None)
+    assert rc == 0, L.nm_last_error()
+    cfg = oracle.gpu_cfg()
+    params = np.ascontiguousarray(logp.params if len(logp.params) else np.zeros(1))
+    for i in range(n):
+        eo = [np.empty(dim) for _ in range(5)]
+        so = [C.c_double() for _ in range(3)]
+        rc = oracle.lib().nmo_leapfrog(C.byref(cfg), logp.kind, dim, params, len(logp.params), z[i].copy(), v[i].copy(),
+                                       gz[i].copy(), sigma[i].copy(), mu[i].copy(), eps[i], logdet[i], e0[i],
+                                       *eo, *[C.byref(x) for x in so])
+        assert rc == 0
+        for name, g, e in zip(("z", "v", "gz", "x", "gx"), outs, eo):
+            assert (bits(g[i].cpu().numpy()) == bits(e)).all(), (name, i)
+        for name, g, e in zip(("logp", "ke", "energy_error"), souts, so):
+            assert bits(g[i].item()) == bits(e.value), (name, i, g[i].item(), e.value)
