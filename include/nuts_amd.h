@@ -156,8 +156,10 @@ typedef struct nm_engine nm_engine;
 typedef struct nm_engine_config {
     int64_t  device;               /* HIP device ordinal; -1 = current device */
     uint64_t chain_id_offset;      /* global id of local chain 0 (multi-GPU sharding: rank*r n_local) */
-    uint64_t dims_per_lane;        /* 0 = auto.  Register tile per lane, one wavefront per chain */
-    uint64_t reserved[5];
+    uint64_t dims_per_lane;        /* 0 = auto.  doubles per lane of every live vector: 2, 4, 8 or 16 */
+    uint64_t waves_per_chain;      /* 0 = auto.  1, 2 or 4 wavefronts cooperate on one chain (dim <= 64*waves*dims_per_lane) */
+    uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
+    uint64_t reserved[3];
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 
@@ -209,6 +211,11 @@ nm_status nm_engine_reset_counters(nm_engine* e);
 
 uint64_t  nm_engine_dim(const nm_engine* e);
 uint64_t  nm_engine_num_chains(const nm_engine* e);
+/* The tiling the engine chose: threads cooperating on one chain (64 * waves_per_chain) and doubles per lane.
+ * The reduction order over dim (and so the last bits of every sum) is a function of threads_per_chain;
+ * the oracle reproduces it with gpu_cfg(threads_per_chain). */
+uint64_t  nm_engine_threads_per_chain(const nm_engine* e);
+uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
 /* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */
 void*     nm_engine_stream(nm_engine* e);
 

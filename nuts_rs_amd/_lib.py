@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "nm_engine_set_positions", "nm_init_positions_uniform", "nm_engine_draw", "nm_engine_draw_async",
     "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
-    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
+    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
 ]
 
@@ -51,7 +51,7 @@ class NmLogpSpec(C.Structure):
 
 class NmEngineConfig(C.Structure):
     _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
-                ("reserved", C.c_uint64 * 5)]
+                ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 STATS_DTYPE = np.dtype([
@@ -106,6 +106,10 @@ def load():
     L.nm_engine_dim.restype = u64
     L.nm_engine_num_chains.argtypes = [vp]
     L.nm_engine_num_chains.restype = u64
+    L.nm_engine_threads_per_chain.argtypes = [vp]
+    L.nm_engine_threads_per_chain.restype = u64
+    L.nm_engine_dims_per_lane.argtypes = [vp]
+    L.nm_engine_dims_per_lane.restype = u64
     L.nm_engine_stream.argtypes = [vp]
     L.nm_engine_stream.restype = vp
     L.nm_leapfrog_batch.argtypes = [C.POINTER(NmLogpSpec), u64, u64] + [vp] * 16 + [vp]

@@ -22,6 +22,8 @@ namespace nm {
 NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+NM_DEV int tid() { return (int)threadIdx.x; }          // thread within the chain's block (64*W threads)
+NM_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
 
 // ---- wavefront reductions ---------------------------------------------------------------------
 // Sum over the 64 lanes, result identical in every lane.  Pairing = xor butterfly with offsets 1,2,4,8,16,32
@@ -61,6 +63,50 @@ NM_DEV void wave_sum2(double& a, double& b) {
     a = (a0 + a1) + (a2 + a3);
     b = (b0 + b1) + (b2 + b3);
 }
+// Block-wide sums for a chain that spans W waves.  Each wave reduces with DPP, lane 0 of every wave publishes its
+// total in LDS, one barrier, then every thread adds the W totals in wave order (w = 0 first) — the documented
+// cross-wave order (oracle gpu_reduce).  Two LDS buffers alternate so one barrier per reduction is enough.
+constexpr int RED_MAX_VALUES = 6;
+template <int W>
+struct Reducer {
+    double* buf;   // LDS [2][RED_MAX_VALUES][W]
+    int par;
+    NM_DEV void init(double* lds) { buf = lds; par = 0; }
+    template <int N>
+    NM_DEV void sum_n(double (&v)[N]) {
+        static_assert(N <= RED_MAX_VALUES, "too many values");
+        if (N == 1) v[0] = wave_sum(v[0]);
+        else {
+#pragma unroll
+            for (int i = 0; i + 1 < N; i += 2) wave_sum2(v[i], v[i + 1]);
+            if (N & 1) v[N - 1] = wave_sum(v[N - 1]);
+        }
+        if (W == 1) return;
+        double* b = buf + par * (RED_MAX_VALUES * W);
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) b[i * W + wave_id()] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = b[i * W];
+#pragma unroll
+            for (int w = 1; w < W; ++w) t = t + b[i * W + w];
+            v[i] = t;
+        }
+        par ^= 1;
+    }
+    NM_DEV double sum(double x) { double v[1] = {x}; sum_n(v); return v[0]; }
+    NM_DEV void sum2(double& a, double& b) { double v[2] = {a, b}; sum_n(v); a = v[0]; b = v[1]; }
+    // true iff `ok` holds in every thread of the block
+    NM_DEV bool all(bool ok) {
+        const bool wave_ok = __ballot(!ok) == 0ull;
+        if (W == 1) return wave_ok;
+        return sum(wave_ok ? 0.0 : 1.0) == 0.0;
+    }
+};
+
 // value of lane `src` (wave-uniform lane index) as a wave-uniform value
 NM_DEV uint64_t wave_bcast_u64(uint64_t x, int src) {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src);
@@ -246,10 +292,10 @@ struct DevRng {
     NM_DEV void refill() {
         __syncthreads();
         base = pos & ~15ull;
-        if (lane_id() < RNG_CACHE_WORDS / 16) {
+        if (tid() < RNG_CACHE_WORDS / 16) {
             uint32_t out[16];
-            chacha8_block(key, (base >> 4) + (uint64_t)lane_id(), 0ull, out);
-            uint4* dst = reinterpret_cast<uint4*>(cache + lane_id() * 16);
+            chacha8_block(key, (base >> 4) + (uint64_t)tid(), 0ull, out);
+            uint4* dst = reinterpret_cast<uint4*>(cache + tid() * 16);
             dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
             dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
             dst[2] = make_uint4(out[8], out[9], out[10], out[11]);

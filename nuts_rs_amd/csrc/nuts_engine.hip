@@ -139,42 +139,53 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 
 enum KernelKind { K_INIT, K_DRAW, K_QUERY };   // K_QUERY: resident blocks per CU of the draw kernel
 
-// grid = number of waves; for K_QUERY *occ receives hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
-template <int DPL, class Dens>
-static hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_waves, hipStream_t stream, int* occ) {
-    if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, Dens>, 64, 0);
-    dim3 grid(grid_waves), block(64);
-    if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, Dens>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((nuts_draw_kernel<DPL, Dens>), grid, block, 0, stream, P);
+// grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
+// hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
+template <int DPL, int W, class Dens>
+static hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
+    if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
+    dim3 grid(grid_blocks), block(64 * W);
+    if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((nuts_draw_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
     return hipGetLastError();
 }
+// supported tilings: W = 1: DPL 2,4,8,16 (dim <= 1024); W = 2: DPL 8,16 (dim <= 2048); W = 4: DPL 4,16 (dim <= 4096)
 template <class Dens>
-static hipError_t launch_d(int dpl, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
-    switch (dpl) {
-    case 2: return launch_t<2, Dens>(kind, P, grid, stream, occ);
-    case 4: return launch_t<4, Dens>(kind, P, grid, stream, occ);
-    case 8: return launch_t<8, Dens>(kind, P, grid, stream, occ);
-    case 16: return launch_t<16, Dens>(kind, P, grid, stream, occ);
+static hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
+    switch (w * 100 + dpl) {
+    case 102: return launch_t<2, 1, Dens>(kind, P, grid, stream, occ);
+    case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
+    case 108: return launch_t<8, 1, Dens>(kind, P, grid, stream, occ);
+    case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
+    case 208: return launch_t<8, 2, Dens>(kind, P, grid, stream, occ);
+    case 216: return launch_t<16, 2, Dens>(kind, P, grid, stream, occ);
+    case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
+    case 416: return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }
-static hipError_t launch(uint64_t logp_kind, int dpl, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr) {
+static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr) {
     switch (logp_kind) {
-    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, kind, P, grid, stream, occ);
-    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, kind, P, grid, stream, occ);
-    case NM_LOGP_FUNNEL: return launch_d<Funnel>(dpl, kind, P, grid, stream, occ);
-    case NM_LOGP_EIGHT_SCHOOLS: return dpl == 2 ? launch_t<2, EightSchools>(kind, P, grid, stream, occ) : hipErrorInvalidValue;
+    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_FUNNEL: return launch_d<Funnel>(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_EIGHT_SCHOOLS: return (dpl == 2 && w == 1) ? launch_t<2, 1, EightSchools>(kind, P, grid, stream, occ) : hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
+}
+// choose (DPL, W) for a dim; requested_dpl / requested_w = 0 means automatic (fewest waves, then smallest tile)
+static bool pick_tiling(uint64_t dim, uint64_t requested_dpl, uint64_t requested_w, int* dpl_out, int* w_out) {
+    static const int combos[8][2] = {{2, 1}, {4, 1}, {8, 1}, {16, 1}, {8, 2}, {16, 2}, {4, 4}, {16, 4}};   // {DPL, W}
+    for (auto& c : combos) {
+        if (requested_dpl && (uint64_t)c[0] != requested_dpl) continue;
+        if (requested_w && (uint64_t)c[1] != requested_w) continue;
+        if ((uint64_t)c[0] * 64 * c[1] >= dim) { *dpl_out = c[0]; *w_out = c[1]; return true; }
+    }
+    return false;
 }
 static int pick_dpl(uint64_t dim, uint64_t requested) {
-    const int opts[4] = {2, 4, 8, 16};
-    if (requested) {
-        for (int o : opts) if ((uint64_t)o == requested && (uint64_t)o * 64 >= dim) return o;
-        return 0;
-    }
-    for (int o : opts) if ((uint64_t)o * 64 >= dim) return o;
-    return 0;
+    int dpl = 0, w = 0;
+    return pick_tiling(dim, requested, 1, &dpl, &w) ? dpl : 0;
 }
 static nm_status check_logp(const nm_logp_spec* l) {
     if (!l) return fail(NM_ERR_INVALID_ARG, "logp spec is null");
@@ -216,7 +227,7 @@ struct nm_engine {
     nm_settings s;
     nm_engine_config cfg;
     uint64_t logp_kind = 0, dim = 0, n_chains = 0;
-    int dpl = 0;
+    int dpl = 0, wpc = 1;         // doubles per lane, waves per chain
     int device = 0;
     bool positioned = false;
     KParams P;
@@ -271,17 +282,19 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (s.has_jitter && !(1.0 - s.jitter < 1.0 + s.jitter)) return fail(NM_ERR_INVALID_ARG, "invalid jitter");
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
-    const int dpl = logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : pick_dpl(logp->dim, cfg.dims_per_lane);
-    if (!dpl) return fail(NM_ERR_UNSUPPORTED, "dim %llu needs more than 16 doubles per lane (or dims_per_lane %llu invalid); max dim is 1024 in this build",
-                          (unsigned long long)logp->dim, (unsigned long long)cfg.dims_per_lane);
+    int dpl = 0, wv = 0;
+    if (!pick_tiling(logp->dim, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : cfg.dims_per_lane,
+                     logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 1 : cfg.waves_per_chain, &dpl, &wv))
+        return fail(NM_ERR_UNSUPPORTED, "no tiling for dim %llu with dims_per_lane %llu / waves_per_chain %llu (max dim 4096 = 16 doubles x 64 lanes x 4 waves)",
+                    (unsigned long long)logp->dim, (unsigned long long)cfg.dims_per_lane, (unsigned long long)cfg.waves_per_chain);
     st = ensure_device(cfg.device);
     if (st != NM_OK) return st;
 
     nm_engine* e = new (std::nothrow) nm_engine();
     if (!e) return fail(NM_ERR_HIP, "out of host memory");
-    e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl;
+    e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl; e->wpc = wv;
     (void)hipGetDevice(&e->device);
-    const uint64_t dpad = 64ull * (uint64_t)dpl;
+    const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;
     const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
 #define E_TRY(expr)                                                                                 \
     do {                                                                                            \
@@ -295,10 +308,10 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         int occ = 0, cus = 0;
         KParams dummy;
         memset(&dummy, 0, sizeof dummy);
-        E_TRY(launch(logp->kind, dpl, K_QUERY, dummy, 0, nullptr, &occ));
+        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ));
         E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
-        if (cfg.reserved[0]) resident = cfg.reserved[0];          // test/tuning override: waves in the grid
+        if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
     }
     const size_t pvec_bytes = (size_t)n_chains * NUM_PSLOT * dpad * sizeof(double);
@@ -378,7 +391,7 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     KParams P = e->P;
-    HIP_TRY(launch(e->logp_kind, e->dpl, K_INIT, P, e->n_waves, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
@@ -404,7 +417,7 @@ extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double
     KParams P = e->P;
     P.n_draws = n_draws; P.out_positions = d_positions; P.out_stats = d_stats;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(launch(e->logp_kind, e->dpl, K_DRAW, P, e->n_waves, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
     e->kernel_launches += 1;
@@ -504,6 +517,8 @@ extern "C" nm_status nm_engine_reset_counters(nm_engine* e) {
 }
 extern "C" uint64_t nm_engine_dim(const nm_engine* e) { return e ? e->dim : 0; }
 extern "C" uint64_t nm_engine_num_chains(const nm_engine* e) { return e ? e->n_chains : 0; }
+extern "C" uint64_t nm_engine_threads_per_chain(const nm_engine* e) { return e ? 64ull * (uint64_t)e->wpc : 0; }
+extern "C" uint64_t nm_engine_dims_per_lane(const nm_engine* e) { return e ? (uint64_t)e->dpl : 0; }
 extern "C" void* nm_engine_stream(nm_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,27 +533,28 @@ struct LfArgs {
 template <int DPL>
 NM_DEV void load_row(Tile<DPL>& t, const double* row, int dim) {
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) { int d = elem_index(k); t.a[k] = d < dim ? row[d] : 0.0; }
+    for (int k = 0; k < DPL; ++k) { int d = elem_index<1>(k); t.a[k] = d < dim ? row[d] : 0.0; }
 }
 template <int DPL>
 NM_DEV void store_row(const Tile<DPL>& t, double* row, int dim) {
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) { int d = elem_index(k); if (d < dim) row[d] = t.a[k]; }
+    for (int k = 0; k < DPL; ++k) { int d = elem_index<1>(k); if (d < dim) row[d] = t.a[k]; }
 }
 template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
     const uint64_t i = blockIdx.x;
     const int dim = (int)A.P.dim;
-    __shared__ double lsig[64 * DPL], lmu[64 * DPL];
+    __shared__ double lsig[64 * DPL], lmu[64 * DPL], lred[2 * RED_MAX_VALUES];
     __shared__ ChainScalars lsc;
-    ChainCtx<DPL, Dens> C(A.P, lsc);
+    ChainCtx<DPL, 1, Dens> C(A.P, lsc);
     C.dim = dim;
-    C.dens.init(A.P.logp_params, dim);
+    C.red.init(lred);
+    C.dens.init(A.P.logp_params, dim, C.red);
     C.lsig = lsig; C.lmu = lmu;
     {
         Tile<DPL> t;
-        load_row(t, A.sigma + i * dim, dim); store_tile(t, C.lsig);
-        load_row(t, A.mu + i * dim, dim); store_tile(t, C.lmu);
+        load_row(t, A.sigma + i * dim, dim); C.store(t, C.lsig);
+        load_row(t, A.mu + i * dim, dim); C.store(t, C.lmu);
     }
     Pt<DPL> s0, s;
     load_row(s0.z, A.z + i * dim, dim);

@@ -1,6 +1,6 @@
 // nuts_kernels.hpp — the many-chain NUTS kernels for gfx950 (MI355X).
 //
-// ONE WAVEFRONT = ONE CHAIN AT A TIME.  A wave keeps two live phase-space points (ping-pong: even leaf E,
+// ONE BLOCK OF W WAVEFRONTS (W = 1, 2 or 4) = ONE CHAIN AT A TIME.  The block keeps two live phase-space points (ping-pong: even leaf E,
 // odd leaf O; each z, v, g_z) and the chain's mass matrix (sigma, mu) in VGPRs (DPL doubles per lane per
 // vector), runs the whole NUTS transition — momentum refresh, every doubling of the tree with the fused
 // leapfrog + logp/grad, the U-turn / divergence tests, the multinomial merges, then the per-draw adaptation —
@@ -101,24 +101,27 @@ struct Tile {
     double a[DPL];
 };
 
-template <int DPL>
+// Tiling of a chain vector over the T = 64*W threads of its block: thread t holds, for m = 0..DPL/2-1, the PAIR of
+// elements d = 2*(m*T + t) + {0,1} (16 B per thread, consecutive threads contiguous).
+template <int DPL, int W>
 NM_DEV void load_tile(Tile<DPL>& t, const double* base) {
-    const double2* p = reinterpret_cast<const double2*>(base) + lane_id();
+    const double2* p = reinterpret_cast<const double2*>(base) + tid();
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
-        double2 q = p[m * 64];
+        double2 q = p[m * 64 * W];
         t.a[2 * m] = q.x;
         t.a[2 * m + 1] = q.y;
     }
 }
-template <int DPL>
+template <int DPL, int W>
 NM_DEV void store_tile(const Tile<DPL>& t, double* base) {
-    double2* p = reinterpret_cast<double2*>(base) + lane_id();
+    double2* p = reinterpret_cast<double2*>(base) + tid();
 #pragma unroll
-    for (int m = 0; m < DPL / 2; ++m) p[m * 64] = make_double2(t.a[2 * m], t.a[2 * m + 1]);
+    for (int m = 0; m < DPL / 2; ++m) p[m * 64 * W] = make_double2(t.a[2 * m], t.a[2 * m + 1]);
 }
-// element index held in register k of this lane
-NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 + lane_id()) + (k & 1); }
+// element index held in register k of this thread
+template <int W>
+NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 * W + tid()) + (k & 1); }
 
 // ---------------------------------------------------------------------------------------------
 // densities: eval(x, gx, dim) -> logp (wave-uniform), fills gx; padded elements (index >= dim) must give
@@ -126,49 +129,51 @@ NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 + lane_id()) + (k & 1);
 // ---------------------------------------------------------------------------------------------
 struct IidNormal {   // reference benches/sample.rs:49-62
     double mu;
-    NM_DEV void init(const double* params, int) { mu = params[0]; }
-    template <int DPL>
-    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+    template <int W>
+    NM_DEV void init(const double* params, int, Reducer<W>&) { mu = params[0]; }
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            bool valid = elem_index(k) < dim;
+            bool valid = elem_index<W>(k) < dim;
             double diff = x.a[k] - mu;
             double term = -0.5 * diff * diff;
             gx.a[k] = valid ? -diff : 0.0;
             acc = acc + (valid ? term : 0.0);
         }
-        return wave_sum(acc);
+        return R.sum(acc);
     }
 };
 
 struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/transform/mod.rs:98-112
     const double* prec;
     double norm;
-    NM_DEV void init(const double* params, int dim) {
+    template <int W>
+    NM_DEV void init(const double* params, int dim, Reducer<W>& R) {
         prec = params;
         double acc = 0.0;
-        for (int m = 0; m < (dim + 127) / 128; ++m)
+        for (int m = 0; m < (dim + 128 * W - 1) / (128 * W); ++m)
             for (int j = 0; j < 2; ++j) {
-                int d = 2 * (m * 64 + lane_id()) + j;
+                int d = 2 * (m * 64 * W + tid()) + j;
                 acc = acc + (d < dim ? dlog(params[d < dim ? d : 0]) : 0.0);
             }
-        double log_det_p = wave_sum(acc);
+        double log_det_p = R.sum(acc);
         norm = -0.5 * ((double)dim * ulog(6.283185307179586) - log_det_p);
     }
-    template <int DPL>
-    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = elem_index<W>(k);
             bool valid = d < dim;
             double p = valid ? prec[d] : 0.0;
             double px = p * x.a[k];
             gx.a[k] = valid ? -px : 0.0;
             acc = acc + (valid ? x.a[k] * px : 0.0);
         }
-        double quad = -0.5 * wave_sum(acc);
+        double quad = -0.5 * R.sum(acc);
         return quad + norm;
     }
 };
@@ -177,24 +182,26 @@ struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/t
 // x[i] | v ~ N(0, e^v), i = 1..dim-1.  logp = -v^2/18 - (k/2) v - e^{-v}/2 * sum x_i^2  (k = dim - 1).
 // Same operation order as oracle/nmo_nuts.hpp LOGP_FUNNEL.
 struct Funnel {
-    NM_DEV void init(const double*, int) {}
-    template <int DPL>
-    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
-        const double v = readlane_f64(x.a[0], 0);                 // element 0 lives in lane 0, register 0
+    template <int W>
+    NM_DEV void init(const double*, int, Reducer<W>&) {}
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
+        // element 0 lives in thread 0, register 0; for W > 1 it reaches the other waves as a sum with zeros (exact)
+        const double v = W == 1 ? readlane_f64(x.a[0], 0) : R.sum(tid() == 0 ? x.a[0] : 0.0);
         const double kk = (double)(dim - 1);
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = elem_index<W>(k);
             bool in = d >= 1 && d < dim;
             acc = acc + (in ? x.a[k] * x.a[k] : 0.0);
         }
-        const double ss = wave_sum(acc);
+        const double ss = R.sum(acc);
         const double ev = uexp(-v);
         const double g0 = -v / 9.0 - 0.5 * kk + 0.5 * ev * ss;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = elem_index<W>(k);
             gx.a[k] = d == 0 ? g0 : (d < dim ? -ev * x.a[k] : 0.0);
         }
         return -v * v / 18.0 - 0.5 * kk * v - 0.5 * ev * ss;
@@ -206,9 +213,11 @@ struct Funnel {
 // Same operation order as oracle/nmo_nuts.hpp LOGP_EIGHT_SCHOOLS (dim = 10: elements 2l, 2l+1 in lane l).
 struct EightSchools {
     const double* par;
-    NM_DEV void init(const double* params, int) { par = params; }
-    template <int DPL>
-    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim) const {
+    template <int W>
+    NM_DEV void init(const double* params, int, Reducer<W>&) { par = params; }
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
+        static_assert(W == 1, "dim 10 fits one wave");
         const double mu = readlane_f64(x.a[0], 0), lt = readlane_f64(x.a[1], 0);
         const double tau = uexp(lt);
         const double t5 = (tau / 5.0) * (tau / 5.0);
@@ -217,7 +226,7 @@ struct EightSchools {
         double term[2], dr[2], drth[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int d = elem_index(j);
+            int d = elem_index<W>(j);
             bool school = d >= 2 && d < 10;
             int i = school ? d - 2 : 0;
             double th = x.a[j];
@@ -239,7 +248,7 @@ struct EightSchools {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = elem_index<W>(k);
             double t = 0.0, g = 0.0;
             if (k < 2) {
                 if (d == 0) { t = -mu * mu / 50.0; g = -mu / 25.0 + gmu; }
@@ -250,7 +259,7 @@ struct EightSchools {
             acc = acc + t;
         }
         (void)dim;
-        return wave_sum(acc);
+        return R.sum(acc);
     }
 };
 
@@ -265,19 +274,23 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
     int pad;
 };
 
-template <int DPL>
-struct WaveShared {       // LDS of one wave (one block = one wave)
+template <int DPL, int W>
+struct BlockShared {      // LDS of one block (one block = W waves = one resident chain)
     uint32_t rng_cache[RNG_CACHE_WORDS];
-    double sig[64 * DPL];     // DiagMassMatrix stds of the resident chain, tile order
-    double mu[64 * DPL];      // DiagMassMatrix mean
-    PendEntry pend[MAX_MAXDEPTH + 1];
-    ChainScalars sc;          // the resident chain's scalars (copied in at ctx_begin, back at ctx_end)
+    double sig[64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
+    double mu[64 * W * DPL];      // DiagMassMatrix mean
+    double red[2 * RED_MAX_VALUES * W];
+    // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
+    // synchronisation (a shared copy would be a read-modify-write race between the waves)
+    PendEntry pend[W][MAX_MAXDEPTH + 1];
+    ChainScalars sc[W];       // the resident chain's scalars (copied in at ctx_begin; wave 0's copy goes back at ctx_end)
 };
 
-template <int DPL, class Dens>
+template <int DPL, int W, class Dens>
 struct ChainCtx {
     const KParams& P;
     Dens dens;
+    Reducer<W> red;
     DevRng rng;
     ZigTables zig;
     double* pv;         // this chain's persistent slots
@@ -292,10 +305,14 @@ struct ChainCtx {
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
     NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
+    NM_DEV void load(Tile<DPL>& t, const double* base) const { load_tile<DPL, W>(t, base); }
+    NM_DEV void store(const Tile<DPL>& t, double* base) const { store_tile<DPL, W>(t, base); }
+    NM_DEV int elem(int k) const { return elem_index<W>(k); }
+    NM_DEV const double2* tptr(const double* base) const { return reinterpret_cast<const double2*>(base) + tid(); }
 };
 
-template <int DPL, class Dens>
-NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chain, uint64_t wave) {
+template <int DPL, int W, class Dens>
+NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64_t chain, uint64_t wave) {
     const KParams& P = C.P;
     C.dim = (int)P.dim;
     C.maxdepth_cfg = (int)P.s.maxdepth;
@@ -303,29 +320,30 @@ NM_DEV void ctx_begin(ChainCtx<DPL, Dens>& C, WaveShared<DPL>& sh, uint64_t chai
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.lsig = sh.sig;
     C.lmu = sh.mu;
-    C.pend = sh.pend;
+    C.pend = sh.pend[wave_id()];
     C.zig = {P.zig_x, P.zig_f};
     {   // chain scalars: HBM -> LDS
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&P.sc[chain]);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc[wave_id()]);
         constexpr int NW = (int)(sizeof(ChainScalars) / 8);
         static_assert(sizeof(ChainScalars) % 8 == 0 && NW <= 64, "ChainScalars must be <= 64 u64 words");
         __syncthreads();
         if (lane_id() < NW) dst[lane_id()] = src[lane_id()];
         __syncthreads();
     }
+    C.red.init(sh.red);
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
-    C.dens.init(P.logp_params, C.dim);
+    C.dens.init(P.logp_params, C.dim, C.red);
 }
-template <int DPL, class Dens>
-NM_DEV void ctx_end(ChainCtx<DPL, Dens>& C, uint64_t chain) {
+template <int DPL, int W, class Dens>
+NM_DEV void ctx_end(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
     C.sc.rng_pos = C.rng.pos;
     __syncthreads();
     {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&C.sc);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&C.P.sc[chain]);
         constexpr int NW = (int)(sizeof(ChainScalars) / 8);
-        if (lane_id() < NW) dst[lane_id()] = src[lane_id()];
+        if (tid() < NW) dst[tid()] = src[tid()];   // threads 0..NW-1 are in wave 0: its copy
     }
 }
 
@@ -340,15 +358,15 @@ struct Pt {
 // One leapfrog, registers to registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
 //   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
-template <int DPL, class Dens>
-NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
+template <int DPL, int W, class Dens>
+NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     const double half = epsilon / 2.;
     Tile<DPL> x, gx;
-    const double2* sg2 = reinterpret_cast<const double2*>(C.lsig) + lane_id();
-    const double2* mu2 = reinterpret_cast<const double2*>(C.lmu) + lane_id();
+    const double2* sg2 = C.tptr(C.lsig);
+    const double2* mu2 = C.tptr(C.lmu);
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
-        const double2 sg = sg2[m * 64], mm = mu2[m * 64];
+        const double2 sg = sg2[m * 64 * W], mm = mu2[m * 64 * W];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = 2 * m + j;
@@ -359,11 +377,11 @@ NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, doubl
             x.a[k] = __builtin_fma(1.0, (j ? mm.y : mm.x), t);
         }
     }
-    o.logp = C.dens.template eval<DPL>(x, gx, C.dim);
+    o.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
     double acc = 0.0;
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
-        const double2 sg = sg2[m * 64];
+        const double2 sg = sg2[m * 64 * W];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = 2 * m + j;
@@ -372,7 +390,7 @@ NM_DEV void leapfrog(ChainCtx<DPL, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, doubl
             acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
         }
     }
-    o.ke = 0.5 * wave_sum(acc);
+    o.ke = 0.5 * C.red.sum(acc);
     if (x_out) *x_out = x;
     if (gx_out) *gx_out = gx;
 }
@@ -405,40 +423,39 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
 
 // momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577).  The stream-ordered samples are
 // staged through `stage` (a [64*DPL] scratch vector in HBM/L2 owned by this wave) and re-read in tile order.
-template <int DPL, class Dens>
-NM_DEV void sample_velocity(ChainCtx<DPL, Dens>& C, Tile<DPL>& v, double* stage) {
+template <int DPL, int W, class Dens>
+NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v, double* stage) {
     fill_standard_normals(C.rng, stage, C.dim, C.zig);
-    const double2* st = reinterpret_cast<const double2*>(stage) + lane_id();
+    const double2* st = C.tptr(stage);
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
-        double2 q = st[m * 64];
-        v.a[2 * m] = elem_index(2 * m) < C.dim ? 1.0 * q.x : 0.0;
-        v.a[2 * m + 1] = elem_index(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+        double2 q = st[m * 64 * W];
+        v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+        v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
     __syncthreads();
 }
 
-template <int DPL>
-NM_DEV double kinetic(const Tile<DPL>& v) {
+template <int DPL, int W>
+NM_DEV double kinetic(const Tile<DPL>& v, Reducer<W>& R) {
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) acc = __builtin_fma(v.a[k], v.a[k], acc);
-    return 0.5 * wave_sum(acc);
+    return 0.5 * R.sum(acc);
 }
 
 // Σ ln(t) over valid elements (array_sum_ln, cpu_math.rs:300-304)
-template <int DPL, class Dens>
-NM_DEV double sum_ln_tile(const ChainCtx<DPL, Dens>& C, const Tile<DPL>& t) {
+template <int DPL, int W, class Dens>
+NM_DEV double sum_ln_tile(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& t) {
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-        bool valid = elem_index(k) < C.dim;
+        bool valid = C.elem(k) < C.dim;
         acc = acc + (valid ? dlog(valid ? t.a[k] : 1.0) : 0.0);
     }
-    return wave_sum(acc);
+    return C.red.sum(acc);
 }
 
-NM_DEV bool wave_all(bool ok) { return __ballot(!ok) == 0ull; }
 
 NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // DualAverage::new dual_avg.rs:44-53
     sc.log_step = ulog(initial_step);
@@ -450,29 +467,29 @@ NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // Dua
 
 // Hamiltonian::init_state at x with the current mass matrix (reference transformed_hamiltonian.rs:640-661,
 // check_all :310-324).  Fills st.z, st.g, gx, st.logp; returns false for BadInitGrad.
-template <int DPL, class Dens>
-NM_DEV bool init_state(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
-    st.logp = C.dens.template eval<DPL>(x, gx, C.dim);
+template <int DPL, int W, class Dens>
+NM_DEV bool init_state(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
+    st.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
     Tile<DPL> isig, sig, mu;
-    load_tile(isig, C.slot(P_ISIG));
-    load_tile(sig, C.lsig);
-    load_tile(mu, C.lmu);
+    C.load(isig, C.slot(P_ISIG));
+    C.load(sig, C.lsig);
+    C.load(mu, C.lmu);
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);       // compute_transformed_position diagonal.rs:233-246
         st.z.a[k] = isig.a[k] * t;
         st.g.a[k] = gx.a[k] * sig.a[k];                       // compute_transformed_gradient :258-265
-        bool valid = elem_index(k) < C.dim;
+        bool valid = C.elem(k) < C.dim;
         ok = ok && (!valid || (is_finite(st.z.a[k]) && is_finite(st.g.a[k]) && st.g.a[k] != 0.0 &&
                                is_finite(gx.a[k]) && is_finite(x.a[k])));
     }
-    return wave_all(ok);
+    return C.red.all(ok);
 }
 
 // stepsize::Strategy::init (reference src/stepsize/adapt.rs:91-199): step-size search at `x`.
-template <int DPL, class Dens>
-NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
+template <int DPL, int W, class Dens>
+NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
     const nm_settings& s = C.P.s;
     if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
     Pt<DPL> st;
@@ -482,7 +499,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
     }
     const double logdet = C.sc.mm_logdet;
     sample_velocity(C, st.v, C.sslot(ML_V));                    // initialize_trajectory(resample) :687-736
-    const double ke0 = kinetic(st.v);
+    const double ke0 = kinetic(st.v, C.red);
     const double e0 = ke0 - (st.logp + logdet);
     AcceptCollector col;
     C.sc.step_size = s.initial_step;
@@ -514,8 +531,8 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x) {
 }
 
 // update_stepsize (reference src/stepsize/adapt.rs:235-267)
-template <int DPL, class Dens>
-NM_DEV void update_stepsize(ChainCtx<DPL, Dens>& C, bool use_best_guess) {
+template <int DPL, int W, class Dens>
+NM_DEV void update_stepsize(ChainCtx<DPL, W, Dens>& C, bool use_best_guess) {
     const nm_settings& s = C.P.s;
     double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
                                                       : (use_best_guess ? uexp(C.sc.log_step_adapted) : uexp(C.sc.log_step));
@@ -528,8 +545,8 @@ NM_DEV void update_stepsize(ChainCtx<DPL, Dens>& C, bool use_best_guess) {
     }
 }
 // DualAverage::advance (reference src/stepsize/dual_avg.rs:55-64)
-template <int DPL, class Dens>
-NM_DEV void update_estimator(ChainCtx<DPL, Dens>& C, bool late) {
+template <int DPL, int W, class Dens>
+NM_DEV void update_estimator(ChainCtx<DPL, W, Dens>& C, bool late) {
     const nm_settings& s = C.P.s;
     if (s.step_size_method == NM_STEP_FIXED) return;
     ChainScalars& sc = C.sc;
@@ -544,42 +561,42 @@ NM_DEV void update_estimator(ChainCtx<DPL, Dens>& C, bool late) {
 }
 
 // RunningVariance::add_sample (reference adapt/diagonal.rs:31-44, array_update_variance cpu_math.rs:605-631)
-template <int DPL, class Dens>
-NM_DEV void running_variance_add(ChainCtx<DPL, Dens>& C, int slot_mean, int slot_var, uint64_t new_count, const Tile<DPL>& value) {
-    if (new_count == 1) { store_tile(value, C.slot(slot_mean)); return; }
+template <int DPL, int W, class Dens>
+NM_DEV void running_variance_add(ChainCtx<DPL, W, Dens>& C, int slot_mean, int slot_var, uint64_t new_count, const Tile<DPL>& value) {
+    if (new_count == 1) { C.store(value, C.slot(slot_mean)); return; }
     const double diff_scale = 1.0 / (double)new_count;
     Tile<DPL> mean, var;
-    load_tile(mean, C.slot(slot_mean));
-    load_tile(var, C.slot(slot_var));
+    C.load(mean, C.slot(slot_mean));
+    C.load(var, C.slot(slot_var));
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         double diff = value.a[k] - mean.a[k];
         mean.a[k] = mean.a[k] + diff * diff_scale;
         var.a[k] = var.a[k] + diff * diff;
     }
-    store_tile(mean, C.slot(slot_mean));
-    store_tile(var, C.slot(slot_var));
+    C.store(mean, C.slot(slot_mean));
+    C.store(var, C.slot(slot_var));
 }
 
 // writes sigma / inv_sigma / mu (HBM + the LDS copy of the resident chain), logdet, id
-template <int DPL, class Dens>
-NM_DEV void commit_mass_matrix(ChainCtx<DPL, Dens>& C, const Tile<DPL>& sig, const Tile<DPL>& isig, const Tile<DPL>& mu) {
-    store_tile(sig, C.slot(P_SIG));
-    store_tile(isig, C.slot(P_ISIG));
-    store_tile(mu, C.slot(P_MU));
-    store_tile(sig, C.lsig);
-    store_tile(mu, C.lmu);
+template <int DPL, int W, class Dens>
+NM_DEV void commit_mass_matrix(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& sig, const Tile<DPL>& isig, const Tile<DPL>& mu) {
+    C.store(sig, C.slot(P_SIG));
+    C.store(isig, C.slot(P_ISIG));
+    C.store(mu, C.slot(P_MU));
+    C.store(sig, C.lsig);
+    C.store(mu, C.lmu);
     C.sc.mm_logdet = sum_ln_tile(C, isig);
     C.sc.mm_id += 1;
 }
 
 // DiagMassMatrix::update_diag_grad (reference diagonal.rs:133-154, cpu_math.rs:710-738)
-template <int DPL, class Dens>
-NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, const Tile<DPL>& gx) {
+template <int DPL, int W, class Dens>
+NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, const Tile<DPL>& gx) {
     Tile<DPL> sig, isig, mu;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
-        bool valid = elem_index(k) < C.dim;
+        bool valid = C.elem(k) < C.dim;
         double val = 1.0 / clampd(__builtin_fabs(gx.a[k]), 1e-20, 1e20);
         if (!is_finite(val)) val = 1.0;
         double sd = __builtin_sqrt(val), isd = __builtin_sqrt(1.0 / val);
@@ -595,21 +612,21 @@ NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, Dens>& C, const Tile<DPL>& x, co
 
 // Strategy::adapt -> update_diag_draw_grad / update_diag_draw (reference adapt/diagonal.rs:161-196,
 // diagonal.rs:85-131, cpu_math.rs:633-708).  Returns did_change.
-template <int DPL, class Dens>
-NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
+template <int DPL, int W, class Dens>
+NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C) {
     if (C.sc.cnt_fg < 3) return false;
     Tile<DPL> sig, isig, mu, dm, dv;
-    load_tile(sig, C.lsig);
-    load_tile(isig, C.slot(P_ISIG));
-    load_tile(dm, C.slot(E_DM));
-    load_tile(dv, C.slot(E_DV));
+    C.load(sig, C.lsig);
+    C.load(isig, C.slot(P_ISIG));
+    C.load(dm, C.slot(E_DM));
+    C.load(dv, C.slot(E_DV));
     if (C.P.s.use_grad_based_estimate) {
         Tile<DPL> gm, gv;
-        load_tile(gm, C.slot(E_GM));
-        load_tile(gv, C.slot(E_GV));
+        C.load(gm, C.slot(E_GM));
+        C.load(gv, C.slot(E_GV));
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            bool valid = elem_index(k) < C.dim;
+            bool valid = C.elem(k) < C.dim;
             double val = __builtin_sqrt(dv.a[k] / gv.a[k]);
             double sd = sig.a[k], isd = isig.a[k];
             if (!(!is_finite(val) | (val == 0.0))) {
@@ -628,7 +645,7 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
         const double scale = 1.0 / (double)C.sc.cnt_fg;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            bool valid = elem_index(k) < C.dim;
+            bool valid = C.elem(k) < C.dim;
             double d = dv.a[k] * scale;
             double sd = sig.a[k], isd = isig.a[k];
             if (!(!is_finite(d) | (d == 0.0))) {
@@ -645,16 +662,16 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, Dens>& C) {
     return true;
 }
 
-template <int DPL, class Dens>
-NM_DEV void copy_slot(ChainCtx<DPL, Dens>& C, int dst, int src) {
+template <int DPL, int W, class Dens>
+NM_DEV void copy_slot(ChainCtx<DPL, W, Dens>& C, int dst, int src) {
     Tile<DPL> t;
-    load_tile(t, C.slot(src));
-    store_tile(t, C.slot(dst));
+    C.load(t, C.slot(src));
+    C.store(t, C.slot(dst));
 }
 
 // GlobalStrategy::adapt (reference src/adapt_strategy.rs:121-222).  x, gx = chosen draw.
-template <int DPL, class Dens>
-NM_DEV uint64_t adapt(ChainCtx<DPL, Dens>& C, const AcceptCollector& col, bool is_good,
+template <int DPL, int W, class Dens>
+NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, const AcceptCollector& col, bool is_good,
                       const Tile<DPL>& x, const Tile<DPL>& gx) {
     const nm_settings& s = C.P.s;
     ChainScalars& sc = C.sc;
@@ -701,8 +718,8 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, Dens>& C, const AcceptCollector& col, bool i
             Tile<DPL> zero;
 #pragma unroll
             for (int k = 0; k < DPL; ++k) zero.a[k] = 0.0;
-            store_tile(zero, C.slot(B_DM)); store_tile(zero, C.slot(B_DV));
-            store_tile(zero, C.slot(B_GM)); store_tile(zero, C.slot(B_GV));
+            C.store(zero, C.slot(B_DM)); C.store(zero, C.slot(B_DV));
+            C.store(zero, C.slot(B_GM)); C.store(zero, C.slot(B_GV));
             force_update = true;
             if (!is_early) sc.current_window_size = next_window_size;
         }
@@ -743,8 +760,8 @@ struct CandRef { int slot; double logp, ke; int64_t idx; };   // slot: -3 live i
 enum TreeStop { STOP_NONE = 0, STOP_TURNING = 1, STOP_DIVERGING = 2, STOP_FATAL = 3 };
 
 // multinomial merge weights (reference merge_into, src/nuts.rs:172-207).  Returns take_B.
-template <int DPL, class Dens>
-NM_DEV bool merge_weights(ChainCtx<DPL, Dens>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
+template <int DPL, int W, class Dens>
+NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
     total = logaddexp(a_log_size, b_log_size);
     const double self_log_size = is_main ? a_log_size : total;
     if (b_log_size >= self_log_size) return true;
@@ -761,34 +778,33 @@ struct DrawResult {
     double e0;
 };
 
-NM_DEV const double2* lane_ptr(const double* base) { return reinterpret_cast<const double2*>(base) + lane_id(); }
 
 // is_turning(first-generated a, later-generated b) for two register points; fwd decides which is `start`
-template <int DPL>
-NM_DEV bool turning_regs(const Pt<DPL>& a, const Pt<DPL>& b, bool fwd) {
+template <int DPL, int W>
+NM_DEV bool turning_regs(const Pt<DPL>& a, const Pt<DPL>& b, bool fwd, Reducer<W>& R) {
     double s1 = 0., s2 = 0.;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         if (fwd) turn_acc(a.z.a[k], a.v.a[k], b.z.a[k], b.v.a[k], s1, s2);
         else turn_acc(b.z.a[k], b.v.a[k], a.z.a[k], a.v.a[k], s1, s2);
     }
-    wave_sum2(s1, s2);
+    R.sum2(s1, s2);
     return (s1 < 0.) | (s2 < 0.);
 }
 
 // the candidate's z goes to a fresh pool slot
-template <int DPL, class Dens>
-NM_DEV int cand_to_pool(ChainCtx<DPL, Dens>& C, uint32_t& used, const Tile<DPL>& z) {
+template <int DPL, int W, class Dens>
+NM_DEV int cand_to_pool(ChainCtx<DPL, W, Dens>& C, uint32_t& used, const Tile<DPL>& z) {
     const int p = (int)__builtin_ctz(~used);
     used |= 1u << p;
-    store_tile(z, C.sslot(slot_C(C.maxdepth_cfg, p)));
+    C.store(z, C.sslot(slot_C(C.maxdepth_cfg, p)));
     return p;
 }
 
 // nuts::draw (reference src/nuts.rs:281-388).  On entry the chain's current point is in its slots P_*.
 // On exit, if R.chosen.slot >= 0, zc holds the chosen point's z.
-template <int DPL, class Dens>
-NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, DrawResult& R, Tile<DPL>& zc) {
+template <int DPL, int W, class Dens>
+NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, DrawResult& R, Tile<DPL>& zc) {
     const nm_settings& s = C.P.s;
     ChainScalars& sc = C.sc;
     const int MD = C.maxdepth_cfg;
@@ -797,33 +813,33 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
     sample_velocity(C, E.v, C.sslot(ML_V));
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
         Tile<DPL> x, gx, isig, sig, mu;
-        load_tile(x, C.slot(P_X));
-        load_tile(gx, C.slot(P_GX));
-        load_tile(isig, C.slot(P_ISIG));
-        load_tile(sig, C.lsig);
-        load_tile(mu, C.lmu);
+        C.load(x, C.slot(P_X));
+        C.load(gx, C.slot(P_GX));
+        C.load(isig, C.slot(P_ISIG));
+        C.load(sig, C.lsig);
+        C.load(mu, C.lmu);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
             E.z.a[k] = isig.a[k] * t;
             E.g.a[k] = gx.a[k] * sig.a[k];
         }
-        store_tile(E.z, C.slot(P_Z));
-        store_tile(E.g, C.slot(P_GZ));
+        C.store(E.z, C.slot(P_Z));
+        C.store(E.g, C.slot(P_GZ));
         sc.logdet = sc.mm_logdet;
         sc.transform_id = sc.mm_id;
     } else {
-        load_tile(E.z, C.slot(P_Z));
-        load_tile(E.g, C.slot(P_GZ));
+        C.load(E.z, C.slot(P_Z));
+        C.load(E.g, C.slot(P_GZ));
     }
     const double logdet = sc.logdet;
-    const double ke_init = kinetic(E.v);
+    const double ke_init = kinetic(E.v, C.red);
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
-    store_tile(E.z, C.sslot(ML_Z)); store_tile(E.v, C.sslot(ML_V)); store_tile(E.g, C.sslot(ML_G));
-    store_tile(E.z, C.sslot(MR_Z)); store_tile(E.v, C.sslot(MR_V)); store_tile(E.g, C.sslot(MR_G));
+    C.store(E.z, C.sslot(ML_Z)); C.store(E.v, C.sslot(ML_V)); C.store(E.g, C.sslot(ML_G));
+    C.store(E.z, C.sslot(MR_Z)); C.store(E.v, C.sslot(MR_V)); C.store(E.g, C.sslot(MR_G));
     uint64_t depth = 0;
     double log_size = 0.;
     int64_t left_idx = 0, right_idx = 0;
@@ -884,17 +900,17 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
 
         if (depth == 0) {
             // a single leaf: edge -> E -> O
-            load_tile(E.z, C.sslot(fwd ? MR_Z : ML_Z));
-            load_tile(E.v, C.sslot(fwd ? MR_V : ML_V));
-            load_tile(E.g, C.sslot(fwd ? MR_G : ML_G));
+            C.load(E.z, C.sslot(fwd ? MR_Z : ML_Z));
+            C.load(E.v, C.sslot(fwd ? MR_V : ML_V));
+            C.load(E.g, C.sslot(fwd ? MR_G : ML_G));
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(O, sub_log_size)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
-            load_tile(O.z, C.sslot(fwd ? MR_Z : ML_Z));
-            load_tile(O.v, C.sslot(fwd ? MR_V : ML_V));
-            load_tile(O.g, C.sslot(fwd ? MR_G : ML_G));
+            C.load(O.z, C.sslot(fwd ? MR_Z : ML_Z));
+            C.load(O.v, C.sslot(fwd ? MR_V : ML_V));
+            C.load(O.g, C.sslot(fwd ? MR_G : ML_G));
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
@@ -904,8 +920,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                 if (stop != STOP_NONE) break;
                 if ((n & 3) == 0) {
                     const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
-                    store_tile(E.z, C.sslot(fs));
-                    store_tile(E.v, C.sslot(fs + 1));
+                    C.store(E.z, C.sslot(fs));
+                    C.store(E.v, C.sslot(fs + 1));
                 }
                 // ---- odd leaf n + 1
                 leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
@@ -914,7 +930,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                 if (stop != STOP_NONE) break;
                 // ---- level-1 merge: A = {E}, B = {O}, everything in registers
                 {
-                    const bool turning = check ? turning_regs(E, O, fwd) : false;
+                    const bool turning = check ? turning_regs(E, O, fwd, C.red) : false;
                     double total;
                     const bool take = merge_weights(C, wE, wO, false, total, fatal);
                     sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
@@ -931,16 +947,16 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                         // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
                         const uint64_t a_first = nn + 1 - (1ull << k);
                         const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                        const double2* afz = lane_ptr(C.sslot(slot_F(fa)));
-                        const double2* afv = lane_ptr(C.sslot(slot_F(fa) + 1));
-                        const double2* alz = lane_ptr(C.sslot(slot_L(MD, k - 1)));
-                        const double2* alv = lane_ptr(C.sslot(slot_L(MD, k - 1) + 1));
+                        const double2* afz = C.tptr(C.sslot(slot_F(fa)));
+                        const double2* afv = C.tptr(C.sslot(slot_F(fa) + 1));
+                        const double2* alz = C.tptr(C.sslot(slot_L(MD, k - 1)));
+                        const double2* alv = C.tptr(C.sslot(slot_L(MD, k - 1) + 1));
                         double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
                         if (k == 2) {
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = afz[m * 64], av = afv[m * 64];
-                                const double2 lz = alz[m * 64], lv = alv[m * 64];
+                                const double2 az = afz[m * 64 * W], av = afv[m * 64 * W];
+                                const double2 lz = alz[m * 64 * W], lv = alv[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -959,13 +975,13 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                                 }
                             }
                         } else {
-                            const double2* bfz = lane_ptr(C.sslot(slot_F(k - 1)));
-                            const double2* bfv = lane_ptr(C.sslot(slot_F(k - 1) + 1));
+                            const double2* bfz = C.tptr(C.sslot(slot_F(k - 1)));
+                            const double2* bfv = C.tptr(C.sslot(slot_F(k - 1) + 1));
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = afz[m * 64], av = afv[m * 64];
-                                const double2 lz = alz[m * 64], lv = alv[m * 64];
-                                const double2 bz2 = bfz[m * 64], bv2 = bfv[m * 64];
+                                const double2 az = afz[m * 64 * W], av = afv[m * 64 * W];
+                                const double2 lz = alz[m * 64 * W], lv = alv[m * 64 * W];
+                                const double2 bz2 = bfz[m * 64 * W], bv2 = bfv[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -984,7 +1000,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                                 }
                             }
                         }
-                        wave_sum2(s1, s2); wave_sum2(s3, s4); wave_sum2(s5, s6);
+                        { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
                         turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
                     }
                     double total;
@@ -1002,8 +1018,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                 if (stop != STOP_NONE) break;
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
-                    store_tile(O.z, C.sslot(slot_L(MD, t)));
-                    store_tile(O.v, C.sslot(slot_L(MD, t) + 1));
+                    C.store(O.z, C.sslot(slot_L(MD, t)));
+                    C.store(O.v, C.sslot(slot_L(MD, t) + 1));
                     if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
                     else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
                     PendEntry e;
@@ -1025,33 +1041,33 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const double2* mlz = lane_ptr(C.sslot(ML_Z));
-            const double2* mlv = lane_ptr(C.sslot(ML_V));
-            const double2* mrz = lane_ptr(C.sslot(MR_Z));
-            const double2* mrv = lane_ptr(C.sslot(MR_V));
+            const double2* mlz = C.tptr(C.sslot(ML_Z));
+            const double2* mlv = C.tptr(C.sslot(ML_V));
+            const double2* mrz = C.tptr(C.sslot(MR_Z));
+            const double2* mrv = C.tptr(C.sslot(MR_V));
             if (depth == 0) {
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
                     if (fwd) {
-                        double2 az = mlz[m * 64], av = mlv[m * 64];
+                        double2 az = mlz[m * 64 * W], av = mlv[m * 64 * W];
                         turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2);
                         turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2);
                     } else {
-                        double2 az = mrz[m * 64], av = mrv[m * 64];
+                        double2 az = mrz[m * 64 * W], av = mrv[m * 64 * W];
                         turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2);
                         turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2);
                     }
                 }
-                wave_sum2(s1, s2);
+                C.red.sum2(s1, s2);
                 turning = (s1 < 0.) | (s2 < 0.);
             } else {
-                const double2* ofz = lane_ptr(C.sslot(slot_F((int)depth)));
-                const double2* ofv = lane_ptr(C.sslot(slot_F((int)depth) + 1));
+                const double2* ofz = C.tptr(C.sslot(slot_F((int)depth)));
+                const double2* ofv = C.tptr(C.sslot(slot_F((int)depth) + 1));
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
-                    double2 lz = mlz[m * 64], lv = mlv[m * 64];
-                    double2 rz = mrz[m * 64], rv = mrv[m * 64];
-                    double2 oz = ofz[m * 64], ov = ofv[m * 64];
+                    double2 lz = mlz[m * 64 * W], lv = mlv[m * 64 * W];
+                    double2 rz = mrz[m * 64 * W], rv = mrv[m * 64 * W];
+                    double2 oz = ofz[m * 64 * W], ov = ofv[m * 64 * W];
                     const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
                     const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                     if (fwd) {
@@ -1066,7 +1082,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
                         turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
                     }
                 }
-                wave_sum2(s1, s2); wave_sum2(s3, s4); wave_sum2(s5, s6);
+                { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
                 turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
             }
         }
@@ -1081,9 +1097,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
         } else if (sub_cand.slot >= 0) {
             used &= ~(1u << sub_cand.slot);
         }
-        store_tile(O.z, C.sslot(fwd ? MR_Z : ML_Z));
-        store_tile(O.v, C.sslot(fwd ? MR_V : ML_V));
-        store_tile(O.g, C.sslot(fwd ? MR_G : ML_G));
+        C.store(O.z, C.sslot(fwd ? MR_Z : ML_Z));
+        C.store(O.v, C.sslot(fwd ? MR_V : ML_V));
+        C.store(O.g, C.sslot(fwd ? MR_G : ML_G));
         if (fwd) right_idx = O.idx; else left_idx = O.idx;
         depth += 1;
         log_size = total;
@@ -1092,15 +1108,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, Dens>& C, AcceptCollector& col, Dr
     R.depth = depth;
     R.chosen = mc;
     if (fatal) return NM_CHAIN_LOGP_FATAL;
-    if (mc.slot >= 0) load_tile(zc, C.sslot(slot_C(MD, mc.slot)));
+    if (mc.slot >= 0) C.load(zc, C.sslot(slot_C(MD, mc.slot)));
     return NM_CHAIN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // NutsChain::draw (reference src/chain.rs:151-188) + the scalar stats of expanded_draw (:190-232)
 // ---------------------------------------------------------------------------------------------
-template <int DPL, class Dens>
-NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
+template <int DPL, int W, class Dens>
+NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
     AcceptCollector col;
@@ -1111,7 +1127,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     if (st != NM_CHAIN_OK) {
         sc.status = st;
-        if (P.out_stats && lane_id() == 0) {
+        if (P.out_stats && tid() == 0) {
             nm_draw_stats zz = {};
             zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = st;
             P.out_stats[t_out * P.n_chains + chain] = zz;
@@ -1119,23 +1135,23 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
         return;
     }
     if (R.chosen.slot == -1) {                                   // the draw is the trajectory's initial point
-        load_tile(x, C.slot(P_X)); load_tile(gx, C.slot(P_GX));
-        load_tile(z, C.slot(P_Z)); load_tile(gz, C.slot(P_GZ));
+        C.load(x, C.slot(P_X)); C.load(gx, C.slot(P_GX));
+        C.load(z, C.slot(P_Z)); C.load(gz, C.slot(P_GZ));
     } else {
         // the winner's x, g_x, g_z from its z: the same operations as inside the leapfrog => the same bits
         Tile<DPL> sig, mu;
-        load_tile(sig, C.lsig);
-        load_tile(mu, C.lmu);
+        C.load(sig, C.lsig);
+        C.load(mu, C.lmu);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             double tt = z.a[k] * sig.a[k];
             x.a[k] = __builtin_fma(1.0, mu.a[k], tt);
         }
-        (void)C.dens.template eval<DPL>(x, gx, C.dim);
+        (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) gz.a[k] = gx.a[k] * sig.a[k];
-        store_tile(x, C.slot(P_X)); store_tile(gx, C.slot(P_GX));
-        store_tile(z, C.slot(P_Z)); store_tile(gz, C.slot(P_GZ));
+        C.store(x, C.slot(P_X)); C.store(gx, C.slot(P_GX));
+        C.store(z, C.slot(P_Z)); C.store(gz, C.slot(P_GZ));
         sc.logp = R.chosen.logp;
     }
     // DrawGradCollector::register_draw (adapt/diagonal.rs:73-83)
@@ -1145,22 +1161,22 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
         double* dst = P.out_positions + (t_out * P.n_chains + chain) * P.dim;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = C.elem(k);
             if (d < C.dim) dst[d] = x.a[k];
         }
     }
     double fd = 0.0;                                             // sq_norm_sum (cpu_math.rs:235-243)
 #pragma unroll
     for (int k = 0; k < DPL; ++k) fd = fd + (z.a[k] + gz.a[k]) * (z.a[k] + gz.a[k]);
-    fd = wave_sum(fd);
+    fd = C.red.sum(fd);
     const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
-    const int64_t tid = sc.transform_id;
+    const int64_t trans_id = sc.transform_id;
     sc.total_steps += col.count;
     uint64_t ast = adapt(C, col, is_good, x, gx);
     if (ast != NM_CHAIN_OK) sc.status = ast;
     out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
-    out.index_in_trajectory = idx; out.transformation_index = tid;
+    out.index_in_trajectory = idx; out.transformation_index = trans_id;
     out.step_size = sc.step_size;
     out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size : uexp(sc.log_step_adapted);
     out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
@@ -1169,24 +1185,24 @@ NM_DEV void chain_draw(ChainCtx<DPL, Dens>& C, uint64_t chain, uint64_t t_out) {
     out.fisher_distance = fd;
     out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
     out.chain_status = ast;
-    if (P.out_stats && lane_id() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels: one block = one wave; a wave strides over the chains
 // ---------------------------------------------------------------------------------------------
-template <int DPL, class Dens>
-__global__ __launch_bounds__(64) void nuts_draw_kernel(const KParams P) {
-    __shared__ WaveShared<DPL> sh;
+template <int DPL, int W, class Dens>
+__global__ __launch_bounds__(64 * W) void nuts_draw_kernel(const KParams P) {
+    __shared__ BlockShared<DPL, W> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, Dens> C(P, sh.sc);
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         if (C.sc.status == NM_CHAIN_OK) {
             {
                 Tile<DPL> t;
-                load_tile(t, C.slot(P_SIG)); store_tile(t, C.lsig);
-                load_tile(t, C.slot(P_MU)); store_tile(t, C.lmu);
+                C.load(t, C.slot(P_SIG)); C.store(t, C.lsig);
+                C.load(t, C.slot(P_MU)); C.store(t, C.lmu);
             }
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
@@ -1199,31 +1215,31 @@ __global__ __launch_bounds__(64) void nuts_draw_kernel(const KParams P) {
 }
 
 // NutsChain::set_position (reference src/chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119)
-template <int DPL, class Dens>
-__global__ __launch_bounds__(64) void nuts_init_kernel(const KParams P) {
-    __shared__ WaveShared<DPL> sh;
+template <int DPL, int W, class Dens>
+__global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
+    __shared__ BlockShared<DPL, W> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, Dens> C(P, sh.sc);
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
         dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
         Tile<DPL> x, gx;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
-            int d = elem_index(k);
+            int d = C.elem(k);
             x.a[k] = d < C.dim ? P.x0[chain * P.dim + d] : 0.0;
         }
         // init_state_untransformed (transformed_hamiltonian.rs:663-685)
-        (void)C.dens.template eval<DPL>(x, gx, C.dim);
+        (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) ok = ok && is_finite(gx.a[k]) && is_finite(x.a[k]);
         uint64_t status = NM_CHAIN_OK;
-        if (!wave_all(ok)) status = NM_CHAIN_BAD_INIT;
+        if (!C.red.all(ok)) status = NM_CHAIN_BAD_INIT;
         if (status == NM_CHAIN_OK) {
             // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
-            store_tile(x, C.slot(E_DM)); store_tile(x, C.slot(B_DM));
-            store_tile(gx, C.slot(E_GM)); store_tile(gx, C.slot(B_GM));
+            C.store(x, C.slot(E_DM)); C.store(x, C.slot(B_DM));
+            C.store(gx, C.slot(E_GM)); C.store(gx, C.slot(B_GM));
             sc.cnt_fg = 1; sc.cnt_bg = 1;
             mass_matrix_from_grad(C, x, gx);
             status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
@@ -1233,8 +1249,8 @@ __global__ __launch_bounds__(64) void nuts_init_kernel(const KParams P) {
             Tile<DPL> g2;
             if (!init_state(C, x, st, g2)) status = NM_CHAIN_BAD_INIT;
             else {
-                store_tile(x, C.slot(P_X)); store_tile(g2, C.slot(P_GX));
-                store_tile(st.z, C.slot(P_Z)); store_tile(st.g, C.slot(P_GZ));
+                C.store(x, C.slot(P_X)); C.store(g2, C.slot(P_GX));
+                C.store(st.z, C.slot(P_Z)); C.store(st.g, C.slot(P_GZ));
                 sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
             }
         }

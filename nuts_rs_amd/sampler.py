@@ -148,7 +148,8 @@ class ChainBatch:
     """`n_chains` NUTS chains on one GPU: the batched `settings.new_chain(...)` of the reference."""
 
     def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
-                 chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0):
+                 chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0, waves_per_chain: int = 0,
+                 grid_blocks: int = 0):
         self.settings = settings
         self.logp = logp
         self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
@@ -157,6 +158,7 @@ class ChainBatch:
         cfg = NmEngineConfig()
         L.nm_engine_config_default(C.byref(cfg))
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
+        cfg.waves_per_chain, cfg.grid_blocks = waves_per_chain, grid_blocks
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()
@@ -172,6 +174,13 @@ class ChainBatch:
 
     def dim(self):
         return self.logp.dim
+
+    def threads_per_chain(self):
+        """64 x waves cooperating on a chain; fixes the reduction order over dim (oracle: gpu_cfg(threads_per_chain))."""
+        return int(_lib.load().nm_engine_threads_per_chain(self._h))
+
+    def dims_per_lane(self):
+        return int(_lib.load().nm_engine_dims_per_lane(self._h))
 
     def init_positions_uniform(self):
         """x0 ~ U(-1,1) from each chain's outer generator: `CpuMath::init_position` in Sampler order."""

@@ -18,11 +18,12 @@ def oracle_settings(O, settings: N.DiagNutsSettings):
     return s
 
 
-def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0):
-    b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane)
+def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0, waves_per_chain=0):
+    b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane,
+                     waves_per_chain=waves_per_chain)
     status = b.set_position(x0, raise_on_error=False)
     pos, st = b.draw_many(n_draws) if (status == 0).all() else (None, None)
-    extra = dict(status=status)
+    extra = dict(status=status, threads_per_chain=b.threads_per_chain(), dims_per_lane=b.dims_per_lane())
     if pos is not None:
         sd, mu = b.mass_matrix()
         extra.update(stds=sd, mean=mu, step_sizes=b.step_sizes(), x=b.positions(), gx=b.gradients(),

@@ -22,7 +22,7 @@ def declared_symbols():
 def test_library_exports_every_declared_symbol():
     L = N.load_library()
     names = declared_symbols()
-    assert len(names) >= 25
+    assert len(names) >= 27
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/nuts_amd.h but not exported"
     assert set(names) == set(_lib.ABI_SYMBOLS)

@@ -50,6 +50,13 @@ PARITY_CASES = [
     ("funnel_k3_dim101", dict(seed=16, num_tune=150), 101, 12, 230, "funnel", 0),
     ("funnel_dim11", dict(seed=17, num_tune=100), 11, 10, 200, "funnel", 0),
     ("eight_schools_k4", dict(seed=18, num_tune=200), 10, 16, 320, "schools", 0),
+    # several wavefronts per chain (cross-wave sums through LDS): (dims_per_lane, waves_per_chain)
+    ("dim1024_w2_dpl8", dict(seed=19, num_tune=40), 1024, 3, 55, "iid", (8, 2)),
+    ("dim1024_w4_dpl4", dict(seed=20, num_tune=40), 1024, 3, 55, "iid", (4, 4)),
+    ("dim700_w2_dpl8_pad", dict(seed=23, num_tune=40), 700, 3, 55, "diag", (8, 2)),
+    ("dim2000_w2_dpl16", dict(seed=24, num_tune=30), 2000, 2, 40, "iid", (16, 2)),
+    ("dim4096_w4_dpl16", dict(seed=25, num_tune=25), 4096, 2, 32, "iid", (16, 4)),
+    ("funnel_dim300_w4", dict(seed=26, num_tune=60), 300, 4, 90, "funnel", (4, 4)),
 ]
 
 
@@ -68,8 +75,12 @@ def test_chain_parity_bit_exact(oracle, case):
     else:
         logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-6, 6, dim)))        # scales e^-3 .. e^3: deep, ragged trees
     x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
-    pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl)
-    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws)
+    dpl, wpc = dpl if isinstance(dpl, tuple) else (dpl, 0)
+    pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl, waves_per_chain=wpc)
+    if wpc:
+        assert ex["threads_per_chain"] == 64 * wpc and ex["dims_per_lane"] == dpl
+    # the reduction order over dim is a function of the threads that share a chain; the oracle reproduces it
+    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=ex["threads_per_chain"])
     assert failed == 0 and (ex["status"] == 0).all()
     assert_bit_exact(pos_g, st_g, pos_o, st_o)
     assert ex["counters"]["total_leapfrogs"] == steps
