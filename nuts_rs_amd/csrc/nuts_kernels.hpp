@@ -40,7 +40,10 @@ enum PSlot : int {
     B_DM, B_DV, B_GM, B_GV,            // background
     NUM_PSLOT
 };
-enum SSlot : int { ML_Z = 0, ML_V, ML_G, MR_Z, MR_V, MR_G, S_DYN };   // main tree: left / right edge (z, v, g_z)
+// main-tree edges: three (z, v, g_z) slots; `left` and `right` are slot ids 0..2 (both start as the initial point's
+// slot, a successful doubling writes the new edge to a slot neither side uses)
+enum SSlot : int { EDGE0_Z = 0, EDGE0_V, EDGE0_G, EDGE1_Z, EDGE1_V, EDGE1_G, EDGE2_Z, EDGE2_V, EDGE2_G, STAGE_V, S_DYN };
+__host__ __device__ inline int slot_edge(int id) { return EDGE0_Z + 3 * id; }
 // dynamic scratch: F[k] (z,v), L[k] (z,v) for k in 0..=maxdepth, then the candidate pool C[p] (z), p in 0..maxdepth+2
 __host__ __device__ inline int slot_F(int k) { return S_DYN + 2 * k; }
 __host__ __device__ inline int slot_L(int maxdepth, int k) { return S_DYN + 2 * (maxdepth + 1) + 2 * k; }
@@ -280,6 +283,8 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     double sig[64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
     double mu[64 * W * DPL];      // DiagMassMatrix mean
     double red[2 * RED_MAX_VALUES * W];
+    double l1_z[64 * W * DPL];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest end point
+    double l1_v[64 * W * DPL];    //       (written every 4th leaf, read two leaves later) never leaves the CU
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
@@ -295,6 +300,8 @@ struct ChainCtx {
     ZigTables zig;
     double* pv;         // this chain's persistent slots
     double* sv;         // this wave's tree scratch
+    double* l1z;        // LDS: L[1] end point
+    double* l1v;
     double* lsig;       // LDS [64*DPL]: sigma of the resident chain (tile order: lane l reads its own elements)
     double* lmu;        // LDS [64*DPL]: mu
     PendEntry* pend;    // LDS
@@ -319,6 +326,8 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.lsig = sh.sig;
+    C.l1z = sh.l1_z;
+    C.l1v = sh.l1_v;
     C.lmu = sh.mu;
     C.pend = sh.pend[wave_id()];
     C.zig = {P.zig_x, P.zig_f};
@@ -498,7 +507,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
         if (!init_state(C, x, st, gx)) return NM_CHAIN_BAD_INIT;
     }
     const double logdet = C.sc.mm_logdet;
-    sample_velocity(C, st.v, C.sslot(ML_V));                    // initialize_trajectory(resample) :687-736
+    sample_velocity(C, st.v, C.sslot(STAGE_V));                    // initialize_trajectory(resample) :687-736
     const double ke0 = kinetic(st.v, C.red);
     const double e0 = ke0 - (st.logp + logdet);
     AcceptCollector col;
@@ -810,7 +819,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
-    sample_velocity(C, E.v, C.sslot(ML_V));
+    sample_velocity(C, E.v, C.sslot(STAGE_V));
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
         Tile<DPL> x, gx, isig, sig, mu;
         C.load(x, C.slot(P_X));
@@ -838,8 +847,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
-    C.store(E.z, C.sslot(ML_Z)); C.store(E.v, C.sslot(ML_V)); C.store(E.g, C.sslot(ML_G));
-    C.store(E.z, C.sslot(MR_Z)); C.store(E.v, C.sslot(MR_V)); C.store(E.g, C.sslot(MR_G));
+    C.store(E.z, C.sslot(slot_edge(0))); C.store(E.v, C.sslot(slot_edge(0) + 1)); C.store(E.g, C.sslot(slot_edge(0) + 2));
+    int left_slot = 0, right_slot = 0;   // edge slot ids
+    bool o_is_edge = false;              // O still holds the edge written by the last successful doubling ...
+    int o_edge_sign = 0;                 // ... in this direction
     uint64_t depth = 0;
     double log_size = 0.;
     int64_t left_idx = 0, right_idx = 0;
@@ -882,6 +893,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         int stop = STOP_NONE;
         double sub_log_size = 0.;
         CandRef sub_cand = {-2, 0., 0., 0};
+        const bool reuse_edge = o_is_edge && o_edge_sign == sign;
+        o_is_edge = false;               // O is about to be overwritten; set again only by a successful merge
 
         // divergence test + collector for a fresh leaf (transformed_hamiltonian.rs:590-612); returns -energy_error
 #define NM_LEAF_ACCOUNT(PT, WOUT)                                                                         \
@@ -900,17 +913,17 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 
         if (depth == 0) {
             // a single leaf: edge -> E -> O
-            C.load(E.z, C.sslot(fwd ? MR_Z : ML_Z));
-            C.load(E.v, C.sslot(fwd ? MR_V : ML_V));
-            C.load(E.g, C.sslot(fwd ? MR_G : ML_G));
+            const int es = slot_edge(fwd ? right_slot : left_slot);
+            C.load(E.z, C.sslot(es)); C.load(E.v, C.sslot(es + 1)); C.load(E.g, C.sslot(es + 2));
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(O, sub_log_size)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
-            C.load(O.z, C.sslot(fwd ? MR_Z : ML_Z));
-            C.load(O.v, C.sslot(fwd ? MR_V : ML_V));
-            C.load(O.g, C.sslot(fwd ? MR_G : ML_G));
+            if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
+                const int es = slot_edge(fwd ? right_slot : left_slot);
+                C.load(O.z, C.sslot(es)); C.load(O.v, C.sslot(es + 1)); C.load(O.g, C.sslot(es + 2));
+            }
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
@@ -953,10 +966,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         const double2* alv = C.tptr(C.sslot(slot_L(MD, k - 1) + 1));
                         double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
                         if (k == 2) {
+                            const double2* l1z2 = C.tptr(C.l1z);      // A.last = L[1] lives in LDS
+                            const double2* l1v2 = C.tptr(C.l1v);
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
                                 const double2 az = afz[m * 64 * W], av = afv[m * 64 * W];
-                                const double2 lz = alz[m * 64 * W], lv = alv[m * 64 * W];
+                                const double2 lz = l1z2[m * 64 * W], lv = l1v2[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -1018,8 +1033,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if (stop != STOP_NONE) break;
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
-                    C.store(O.z, C.sslot(slot_L(MD, t)));
-                    C.store(O.v, C.sslot(slot_L(MD, t) + 1));
+                    if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
+                    else { C.store(O.z, C.sslot(slot_L(MD, t))); C.store(O.v, C.sslot(slot_L(MD, t) + 1)); }
                     if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
                     else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
                     PendEntry e;
@@ -1041,10 +1056,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const double2* mlz = C.tptr(C.sslot(ML_Z));
-            const double2* mlv = C.tptr(C.sslot(ML_V));
-            const double2* mrz = C.tptr(C.sslot(MR_Z));
-            const double2* mrv = C.tptr(C.sslot(MR_V));
+            const double2* mlz = C.tptr(C.sslot(slot_edge(left_slot)));
+            const double2* mlv = C.tptr(C.sslot(slot_edge(left_slot) + 1));
+            const double2* mrz = C.tptr(C.sslot(slot_edge(right_slot)));
+            const double2* mrv = C.tptr(C.sslot(slot_edge(right_slot) + 1));
             if (depth == 0) {
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
@@ -1097,9 +1112,13 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         } else if (sub_cand.slot >= 0) {
             used &= ~(1u << sub_cand.slot);
         }
-        C.store(O.z, C.sslot(fwd ? MR_Z : ML_Z));
-        C.store(O.v, C.sslot(fwd ? MR_V : ML_V));
-        C.store(O.g, C.sslot(fwd ? MR_G : ML_G));
+        {   // the new edge goes to the slot this side owns alone, or to the free one while both sides share the initial point
+            int ns = fwd ? right_slot : left_slot;
+            if (left_slot == right_slot) ns = 1;
+            C.store(O.z, C.sslot(slot_edge(ns))); C.store(O.v, C.sslot(slot_edge(ns) + 1)); C.store(O.g, C.sslot(slot_edge(ns) + 2));
+            if (fwd) right_slot = ns; else left_slot = ns;
+            o_is_edge = true; o_edge_sign = sign;
+        }
         if (fwd) right_idx = O.idx; else left_idx = O.idx;
         depth += 1;
         log_size = total;
