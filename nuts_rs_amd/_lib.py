@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnuts_amd.so")
+LIB_PATH = os.environ.get("NUTS_AMD_LIB", os.path.join(_HERE, "libnuts_amd.so"))   # env override: tuning builds
 
 NM_OK = 0
 STATUS_NAMES = {0: "NM_OK", 1: "NM_ERR_INVALID_ARG", 2: "NM_ERR_NO_DEVICE", 3: "NM_ERR_HIP", 4: "NM_ERR_UNSUPPORTED",

@@ -1,33 +1,55 @@
-"""Build libnuts_amd.so (the HIP engine) in-tree for gfx950.  `python -m nuts_rs_amd.build`."""
+"""Build libnuts_amd.so (the HIP engine) in-tree for gfx950.  `python -m nuts_rs_amd.build [--force] [-v]`.
+
+The kernels of each density live in their own translation unit (csrc/kern_*.hip) so the build runs in parallel;
+every unit is compiled with hipcc --offload-arch=gfx950 (cross-compiles without a GPU) and the objects are linked
+into one shared library that exports the C ABI of include/nuts_amd.h.
+"""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnuts_amd.so")
-SOURCES = ["nuts_engine.hip", "nuts_kernels.hpp", "dev_math.hpp"]
+UNITS = ["nuts_engine.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_eight_schools.hip"]
+HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "nuts_amd.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def needs_build():
+    deps = [os.path.join(CSRC, f) for f in UNITS + HEADERS]
+    return _newer(LIB, deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "nuts_engine.hip"), "-o", LIB]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+
+    def compile_unit(u):
+        src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o"))
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_unit, UNITS))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 

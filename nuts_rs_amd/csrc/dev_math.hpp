@@ -123,7 +123,7 @@ NM_DEV double uniform_f64(double x) {
 }
 
 // ---- deterministic exp / ln (Sun fdlibm e_exp.c / e_log.c algorithms) ---------------------------
-__host__ __device__ __noinline__ double dexp(double x) {
+static __host__ __device__ __noinline__ double dexp(double x) {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
     const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
@@ -155,7 +155,7 @@ __host__ __device__ __noinline__ double dexp(double x) {
     return y * u2d((uint64_t)(1023 + k + 1000) << 52) * 9.33263618503218878990e-302;
 }
 
-__host__ __device__ __noinline__ double dlog(double x) {
+static __host__ __device__ __noinline__ double dlog(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,

@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "nuts_kernels.hpp"
+#include "nuts_launch.hpp"
 
 using namespace nm;
 
@@ -137,39 +137,12 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 // kernel dispatch
 // ---------------------------------------------------------------------------------------------
 
-enum KernelKind { K_INIT, K_DRAW, K_QUERY };   // K_QUERY: resident blocks per CU of the draw kernel
-
-// grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
-// hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
-template <int DPL, int W, class Dens>
-static hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
-    if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
-    dim3 grid(grid_blocks), block(64 * W);
-    if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((nuts_draw_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
-    return hipGetLastError();
-}
-// supported tilings: W = 1: DPL 2,4,8,16 (dim <= 1024); W = 2: DPL 8,16 (dim <= 2048); W = 4: DPL 4,16 (dim <= 4096)
-template <class Dens>
-static hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
-    switch (w * 100 + dpl) {
-    case 102: return launch_t<2, 1, Dens>(kind, P, grid, stream, occ);
-    case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
-    case 108: return launch_t<8, 1, Dens>(kind, P, grid, stream, occ);
-    case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
-    case 208: return launch_t<8, 2, Dens>(kind, P, grid, stream, occ);
-    case 216: return launch_t<16, 2, Dens>(kind, P, grid, stream, occ);
-    case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
-    case 416: return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
-    }
-    return hipErrorInvalidValue;
-}
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr) {
     switch (logp_kind) {
-    case NM_LOGP_IID_NORMAL: return launch_d<IidNormal>(dpl, w, kind, P, grid, stream, occ);
-    case NM_LOGP_DIAG_NORMAL: return launch_d<DiagNormal>(dpl, w, kind, P, grid, stream, occ);
-    case NM_LOGP_FUNNEL: return launch_d<Funnel>(dpl, w, kind, P, grid, stream, occ);
-    case NM_LOGP_EIGHT_SCHOOLS: return (dpl == 2 && w == 1) ? launch_t<2, 1, EightSchools>(kind, P, grid, stream, occ) : hipErrorInvalidValue;
+    case NM_LOGP_IID_NORMAL: return launch_iid_normal(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_DIAG_NORMAL: return launch_diag_normal(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_FUNNEL: return launch_funnel(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools(dpl, w, kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }

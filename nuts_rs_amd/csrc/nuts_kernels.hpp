@@ -28,6 +28,14 @@ namespace nm {
 
 constexpr int MAX_MAXDEPTH = 20;
 
+// LDS residency switches (tuning): which tree end points of the resident chain stay on the CU
+#ifndef NM_LDS_L1
+#define NM_LDS_L1 1      // L[1]: last leaf of the pending level-1 sub-tree
+#endif
+#ifndef NM_LDS_EDGES
+#define NM_LDS_EDGES 0   // (z, v) of the two main-tree edges (1 halves the resident chains per CU: measured no gain on K2)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // HBM layout.
 //   pvec[chain][PSlot][DP]  : what a chain owns between draws
@@ -40,8 +48,9 @@ enum PSlot : int {
     B_DM, B_DV, B_GM, B_GV,            // background
     NUM_PSLOT
 };
-// main-tree edges: three (z, v, g_z) slots; `left` and `right` are slot ids 0..2 (both start as the initial point's
-// slot, a successful doubling writes the new edge to a slot neither side uses)
+// main-tree edges: `left` and `right` are edge ids 0/1 (both start as the initial point's id 0; a successful doubling
+// writes the new edge to the id this side owns alone, or to id 1 while both sides still share id 0).  Only the g_z of
+// an edge lives here (EDGEn_G); its (z, v) stay in LDS (BlockShared::edge_z / edge_v).
 enum SSlot : int { EDGE0_Z = 0, EDGE0_V, EDGE0_G, EDGE1_Z, EDGE1_V, EDGE1_G, EDGE2_Z, EDGE2_V, EDGE2_G, STAGE_V, S_DYN };
 __host__ __device__ inline int slot_edge(int id) { return EDGE0_Z + 3 * id; }
 // dynamic scratch: F[k] (z,v), L[k] (z,v) for k in 0..=maxdepth, then the candidate pool C[p] (z), p in 0..maxdepth+2
@@ -283,8 +292,10 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     double sig[64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
     double mu[64 * W * DPL];      // DiagMassMatrix mean
     double red[2 * RED_MAX_VALUES * W];
-    double l1_z[64 * W * DPL];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest end point
-    double l1_v[64 * W * DPL];    //       (written every 4th leaf, read two leaves later) never leaves the CU
+    double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
+    double l1_v[NM_LDS_L1 ? 64 * W * DPL : 2];    // end point (written every 4th leaf, read two leaves later) never leaves the CU
+    double edge_z[2][NM_LDS_EDGES ? 64 * W * DPL : 2];   // (z, v) of the two main-tree edges: read by every top-level U-turn
+    double edge_v[2][NM_LDS_EDGES ? 64 * W * DPL : 2];   // test and by the next doubling in that direction; only g_z goes to HBM
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
@@ -302,6 +313,8 @@ struct ChainCtx {
     double* sv;         // this wave's tree scratch
     double* l1z;        // LDS: L[1] end point
     double* l1v;
+    double* edz;        // LDS: edge (z, v), two slots of dpad doubles each
+    double* edv;
     double* lsig;       // LDS [64*DPL]: sigma of the resident chain (tile order: lane l reads its own elements)
     double* lmu;        // LDS [64*DPL]: mu
     PendEntry* pend;    // LDS
@@ -312,6 +325,9 @@ struct ChainCtx {
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
     NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
+    NM_DEV double* edge_z(int id) const { return NM_LDS_EDGES ? edz + id * (64 * W * DPL) : sslot(EDGE0_Z + 3 * id); }
+    NM_DEV double* edge_v(int id) const { return NM_LDS_EDGES ? edv + id * (64 * W * DPL) : sslot(EDGE0_V + 3 * id); }
+    NM_DEV double* edge_g(int id) const { return sslot(EDGE0_G + 3 * id); }
     NM_DEV void load(Tile<DPL>& t, const double* base) const { load_tile<DPL, W>(t, base); }
     NM_DEV void store(const Tile<DPL>& t, double* base) const { store_tile<DPL, W>(t, base); }
     NM_DEV int elem(int k) const { return elem_index<W>(k); }
@@ -326,8 +342,10 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.lsig = sh.sig;
-    C.l1z = sh.l1_z;
-    C.l1v = sh.l1_v;
+    C.l1z = NM_LDS_L1 ? sh.l1_z : C.sslot(slot_L(C.maxdepth_cfg, 1));
+    C.l1v = NM_LDS_L1 ? sh.l1_v : C.sslot(slot_L(C.maxdepth_cfg, 1) + 1);
+    C.edz = &sh.edge_z[0][0];
+    C.edv = &sh.edge_v[0][0];
     C.lmu = sh.mu;
     C.pend = sh.pend[wave_id()];
     C.zig = {P.zig_x, P.zig_f};
@@ -404,22 +422,47 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
     if (gx_out) *gx_out = gx;
 }
 
-// AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:112-166)
+// AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:112-166).
+// The two running means need exp(min(d,0)) and exp(d) of every leaf's energy difference d.  Evaluating them when the
+// leaf is produced would put two dependent exp chains on the (wave-uniform, latency-bound) critical path of every
+// leaf; instead lane (i mod 64) keeps the i-th pending d in a VGPR and `flush` evaluates up to 64 of them at once
+// (one exp per lane) and then adds them to the sums sequentially in leaf order — the same additions in the same
+// order as the reference's `RunningMean::add`, hence the same bits.
 struct AcceptCollector {
     double initial_energy, sum, sum_sym, max_energy_error;
     uint64_t count;
-    NM_DEV void register_init(double e0) { initial_energy = e0; sum = 0.; sum_sym = 0.; count = 0; max_energy_error = 0.; }
-    NM_DEV void register_divergent() { sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf(); }
+    double pend_d;     // per-lane: the pending d of leaf (count - npend + lane) ...
+    int npend;         // ... for lane < npend
+    NM_DEV void register_init(double e0) {
+        initial_energy = e0; sum = 0.; sum_sym = 0.; count = 0; max_energy_error = 0.;
+        pend_d = 0.; npend = 0;
+    }
+    NM_DEV void flush() {
+        if (npend == 0) return;
+        // per-lane evaluation (lanes >= npend compute on 0 and are ignored)
+        const double d = lane_id() < npend ? pend_d : 0.0;
+        const double e = dexp(fmin_rs(d, 0.));
+        const double es = 2. * e / (1. + dexp(d));
+        for (int i = 0; i < npend; ++i) {
+            sum = sum + readlane_f64(e, i);
+            sum_sym = sum_sym + readlane_f64(es, i);
+        }
+        npend = 0;
+    }
+    NM_DEV void register_divergent() {
+        flush();
+        sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf();
+    }
     NM_DEV void register_ok(double end_energy) {
-        double diff = initial_energy - end_energy;
-        double e = uexp(fmin_rs(diff, 0.));
-        sum = sum + e;
-        sum_sym = sum_sym + 2. * e / (1. + uexp(diff));
+        const double diff = initial_energy - end_energy;
+        if (lane_id() == npend) pend_d = diff;
+        npend += 1;
         count += 1;
         if (__builtin_fabs(diff) > __builtin_fabs(max_energy_error)) max_energy_error = diff;
+        if (npend == 64) flush();
     }
-    NM_DEV double mean() const { return sum / (double)count; }
-    NM_DEV double mean_sym() const { return sum_sym / (double)count; }
+    NM_DEV double mean() { flush(); return sum / (double)count; }
+    NM_DEV double mean_sym() { flush(); return sum_sym / (double)count; }
 };
 
 // is_turning partial sums (reference transformed_hamiltonian.rs:617-638, scalar_prods3 util.rs:221-347):
@@ -680,7 +723,7 @@ NM_DEV void copy_slot(ChainCtx<DPL, W, Dens>& C, int dst, int src) {
 
 // GlobalStrategy::adapt (reference src/adapt_strategy.rs:121-222).  x, gx = chosen draw.
 template <int DPL, int W, class Dens>
-NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, const AcceptCollector& col, bool is_good,
+NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_good,
                       const Tile<DPL>& x, const Tile<DPL>& gx) {
     const nm_settings& s = C.P.s;
     ChainScalars& sc = C.sc;
@@ -847,7 +890,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
-    C.store(E.z, C.sslot(slot_edge(0))); C.store(E.v, C.sslot(slot_edge(0) + 1)); C.store(E.g, C.sslot(slot_edge(0) + 2));
+    C.store(E.z, C.edge_z(0)); C.store(E.v, C.edge_v(0)); C.store(E.g, C.edge_g(0));
     int left_slot = 0, right_slot = 0;   // edge slot ids
     bool o_is_edge = false;              // O still holds the edge written by the last successful doubling ...
     int o_edge_sign = 0;                 // ... in this direction
@@ -913,16 +956,16 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 
         if (depth == 0) {
             // a single leaf: edge -> E -> O
-            const int es = slot_edge(fwd ? right_slot : left_slot);
-            C.load(E.z, C.sslot(es)); C.load(E.v, C.sslot(es + 1)); C.load(E.g, C.sslot(es + 2));
+            const int es = fwd ? right_slot : left_slot;
+            C.load(E.z, C.edge_z(es)); C.load(E.v, C.edge_v(es)); C.load(E.g, C.edge_g(es));
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(O, sub_log_size)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
-                const int es = slot_edge(fwd ? right_slot : left_slot);
-                C.load(O.z, C.sslot(es)); C.load(O.v, C.sslot(es + 1)); C.load(O.g, C.sslot(es + 2));
+                const int es = fwd ? right_slot : left_slot;
+                C.load(O.z, C.edge_z(es)); C.load(O.v, C.edge_v(es)); C.load(O.g, C.edge_g(es));
             }
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
@@ -1056,10 +1099,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const double2* mlz = C.tptr(C.sslot(slot_edge(left_slot)));
-            const double2* mlv = C.tptr(C.sslot(slot_edge(left_slot) + 1));
-            const double2* mrz = C.tptr(C.sslot(slot_edge(right_slot)));
-            const double2* mrv = C.tptr(C.sslot(slot_edge(right_slot) + 1));
+            const double2* mlz = C.tptr(C.edge_z(left_slot));
+            const double2* mlv = C.tptr(C.edge_v(left_slot));
+            const double2* mrz = C.tptr(C.edge_z(right_slot));
+            const double2* mrv = C.tptr(C.edge_v(right_slot));
             if (depth == 0) {
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
@@ -1115,7 +1158,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         {   // the new edge goes to the slot this side owns alone, or to the free one while both sides share the initial point
             int ns = fwd ? right_slot : left_slot;
             if (left_slot == right_slot) ns = 1;
-            C.store(O.z, C.sslot(slot_edge(ns))); C.store(O.v, C.sslot(slot_edge(ns) + 1)); C.store(O.g, C.sslot(slot_edge(ns) + 2));
+            C.store(O.z, C.edge_z(ns)); C.store(O.v, C.edge_v(ns)); C.store(O.g, C.edge_g(ns));
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;
         }

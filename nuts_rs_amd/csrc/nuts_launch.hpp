@@ -1,0 +1,46 @@
+// nuts_launch.hpp — kernel launch plumbing shared by the per-density translation units (each density's kernels
+// are compiled in their own .hip file so the build parallelises).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nuts_kernels.hpp"
+
+namespace nm {
+enum KernelKind { K_INIT, K_DRAW, K_QUERY };   // K_QUERY: resident blocks per CU of the draw kernel
+
+// grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
+// hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
+template <int DPL, int W, class Dens>
+inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
+    if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
+    dim3 grid(grid_blocks), block(64 * W);
+    if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((nuts_draw_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
+    return hipGetLastError();
+}
+// supported tilings: W = 1: DPL 2,4,8,16 (dim <= 1024); W = 2: DPL 8,16 (dim <= 2048); W = 4: DPL 4,16 (dim <= 4096)
+template <class Dens>
+inline hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
+    switch (w * 100 + dpl) {
+#ifdef NM_DEV_ONLY_K2
+    case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
+    default: return hipErrorInvalidValue;
+#else
+    case 102: return launch_t<2, 1, Dens>(kind, P, grid, stream, occ);
+    case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
+    case 108: return launch_t<8, 1, Dens>(kind, P, grid, stream, occ);
+    case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
+    case 208: return launch_t<8, 2, Dens>(kind, P, grid, stream, occ);
+    case 216: return launch_t<16, 2, Dens>(kind, P, grid, stream, occ);
+    case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
+    case 416: return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
+#endif
+    }
+    return hipErrorInvalidValue;
+}
+
+// one definition per density, in kern_<density>.hip
+hipError_t launch_iid_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_diag_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_funnel(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_eight_schools(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+}  // namespace nm
