@@ -325,9 +325,17 @@ struct ChainCtx {
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
     NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
-    NM_DEV double* edge_z(int id) const { return NM_LDS_EDGES ? edz + id * (64 * W * DPL) : sslot(EDGE0_Z + 3 * id); }
-    NM_DEV double* edge_v(int id) const { return NM_LDS_EDGES ? edv + id * (64 * W * DPL) : sslot(EDGE0_V + 3 * id); }
+#if NM_LDS_EDGES
+    NM_DEV double* edge_z(int id) const { return edz + id * (64 * W * DPL); }
+    NM_DEV double* edge_v(int id) const { return edv + id * (64 * W * DPL); }
     NM_DEV double* edge_g(int id) const { return sslot(EDGE0_G + 3 * id); }
+#else
+    // edge id 0 is the trajectory's initial point and costs no store: its z / g_z are the chain's P_Z / P_GZ slots and
+    // its v is the staged normals buffer (stream order == memory order of a chain vector); ids 1, 2 are scratch slots
+    NM_DEV double* edge_z(int id) const { return id == 0 ? slot(P_Z) : sslot(EDGE0_Z + 3 * id); }
+    NM_DEV double* edge_v(int id) const { return id == 0 ? sslot(STAGE_V) : sslot(EDGE0_V + 3 * id); }
+    NM_DEV double* edge_g(int id) const { return id == 0 ? slot(P_GZ) : sslot(EDGE0_G + 3 * id); }
+#endif
     NM_DEV void load(Tile<DPL>& t, const double* base) const { load_tile<DPL, W>(t, base); }
     NM_DEV void store(const Tile<DPL>& t, double* base) const { store_tile<DPL, W>(t, base); }
     NM_DEV int elem(int k) const { return elem_index<W>(k); }
@@ -890,7 +898,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
+#if NM_LDS_EDGES
     C.store(E.z, C.edge_z(0)); C.store(E.v, C.edge_v(0)); C.store(E.g, C.edge_g(0));
+#endif
     int left_slot = 0, right_slot = 0;   // edge slot ids
     bool o_is_edge = false;              // O still holds the edge written by the last successful doubling ...
     int o_edge_sign = 0;                 // ... in this direction
@@ -1157,7 +1167,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         }
         {   // the new edge goes to the slot this side owns alone, or to the free one while both sides share the initial point
             int ns = fwd ? right_slot : left_slot;
+            const int other_side = fwd ? left_slot : right_slot;
+#if NM_LDS_EDGES
             if (left_slot == right_slot) ns = 1;
+#else
+            if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
+#endif
             C.store(O.z, C.edge_z(ns)); C.store(O.v, C.edge_v(ns)); C.store(O.g, C.edge_g(ns));
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;
