@@ -23,7 +23,9 @@ NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 NM_DEV int tid() { return (int)threadIdx.x; }          // thread within the chain's block (64*W threads)
-NM_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+// wave index inside the block; IS wave-uniform, but anything derived from threadIdx is divergent to the compiler
+// unless it goes through readfirstlane (guide T20) — and values loaded through a "divergent" index poison everything
+NM_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- wavefront reductions ---------------------------------------------------------------------
 // Sum over the 64 lanes, result identical in every lane.  Pairing = xor butterfly with offsets 1,2,4,8,16,32

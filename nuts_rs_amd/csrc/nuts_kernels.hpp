@@ -29,12 +29,18 @@ namespace nm {
 constexpr int MAX_MAXDEPTH = 20;
 
 // LDS residency switches (tuning): which tree end points of the resident chain stay on the CU
+#ifndef NM_TRIM_FIRST
+#define NM_TRIM_FIRST 1   // first doubling / depth-1 top-level tests use the points still held in E
+#endif
 #ifndef NM_LDS_L1
 #define NM_LDS_L1 1      // L[1]: last leaf of the pending level-1 sub-tree
 #endif
-#ifndef NM_LDS_EDGES
-#define NM_LDS_EDGES 0   // (z, v) of the two main-tree edges (1 halves the resident chains per CU: measured no gain on K2)
+// U-turn operand loops: at most this many unrolled iterations of operand loads may be in flight (a scheduling barrier
+// follows each group) — unbounded hoisting of the 6 operand streams costs ~190 VGPRs at DPL 16 and ends in scratch spills
+#ifndef NM_CHECK_GROUP
+#define NM_CHECK_GROUP 2
 #endif
+#define NM_GROUP_BARRIER(m) do { if (((m) + 1) % NM_CHECK_GROUP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // HBM layout.
@@ -134,6 +140,44 @@ NM_DEV void store_tile(const Tile<DPL>& t, double* base) {
 // element index held in register k of this thread
 template <int W>
 NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 * W + tid()) + (k & 1); }
+
+// ---------------------------------------------------------------------------------------------
+// HBM access through buffer descriptors (guide T8/T20).  A chain vector is addressed as
+//   SRD(region base, wave-uniform)  +  soffset = slot * DP * 8 (SGPR)  +  voffset = tid*16 + m*T*16 (one VGPR + immediate)
+// so no 64-bit per-lane address is ever formed: with plain pointers the compiler hoists one such address per
+// (slot, m) out of the draw loop — hundreds of VGPRs that end up spilled to scratch and reloaded in the hot loop.
+// ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// A wave-uniform int the compiler cannot second-guess.  A plain __builtin_amdgcn_readfirstlane is folded away when
+// the IR uniformity analysis already calls its input uniform, yet instruction selection may still have computed that
+// input on the VALU — and then every buffer op taking it as soffset gets wrapped in a waterfall loop (T20), which
+// serialises the loads.  Laundering the value through an empty asm (opaque, "divergent" to the analysis) keeps the
+// readfirstlane, so the result is a real SGPR; the compiler still sees the builtin and pads its hazards.
+NM_DEV int force_sgpr(int x) {
+    asm volatile("" : "+v"(x));
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+NM_DEV rsrc_t make_rsrc(const void* base, uint64_t bytes) {
+    // the inputs ARE wave-uniform; readfirstlane makes that provable so no waterfall loop is generated (T20)
+    const uint64_t b = (uint64_t)base;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)(uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0, n, 0x00020000);
+}
+NM_DEV double2 buf_load2(rsrc_t r, int voff, int soff) {
+    v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z));
+}
+NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
+    v4u q;
+    q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
+    q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, 0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // densities: eval(x, gx, dim) -> logp (wave-uniform), fills gx; padded elements (index >= dim) must give
@@ -294,8 +338,6 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     double red[2 * RED_MAX_VALUES * W];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
     double l1_v[NM_LDS_L1 ? 64 * W * DPL : 2];    // end point (written every 4th leaf, read two leaves later) never leaves the CU
-    double edge_z[2][NM_LDS_EDGES ? 64 * W * DPL : 2];   // (z, v) of the two main-tree edges: read by every top-level U-turn
-    double edge_v[2][NM_LDS_EDGES ? 64 * W * DPL : 2];   // test and by the next doubling in that direction; only g_z goes to HBM
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
@@ -313,8 +355,6 @@ struct ChainCtx {
     double* sv;         // this wave's tree scratch
     double* l1z;        // LDS: L[1] end point
     double* l1v;
-    double* edz;        // LDS: edge (z, v), two slots of dpad doubles each
-    double* edv;
     double* lsig;       // LDS [64*DPL]: sigma of the resident chain (tile order: lane l reads its own elements)
     double* lmu;        // LDS [64*DPL]: mu
     PendEntry* pend;    // LDS
@@ -323,19 +363,53 @@ struct ChainCtx {
     ChainScalars& sc;   // LDS
 
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
+    rsrc_t rp, rs;      // buffer descriptors of this chain's persistent slots / this block's tree scratch
+    int voff;           // tid * 16: byte offset of this thread's first pair inside a chain vector
+    int slot_bytes;     // DP * 8
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
     NM_DEV double* sslot(int s) const { return sv + (size_t)s * P.dpad; }
-#if NM_LDS_EDGES
-    NM_DEV double* edge_z(int id) const { return edz + id * (64 * W * DPL); }
-    NM_DEV double* edge_v(int id) const { return edv + id * (64 * W * DPL); }
-    NM_DEV double* edge_g(int id) const { return sslot(EDGE0_G + 3 * id); }
-#else
-    // edge id 0 is the trajectory's initial point and costs no store: its z / g_z are the chain's P_Z / P_GZ slots and
-    // its v is the staged normals buffer (stream order == memory order of a chain vector); ids 1, 2 are scratch slots
-    NM_DEV double* edge_z(int id) const { return id == 0 ? slot(P_Z) : sslot(EDGE0_Z + 3 * id); }
-    NM_DEV double* edge_v(int id) const { return id == 0 ? sslot(STAGE_V) : sslot(EDGE0_V + 3 * id); }
-    NM_DEV double* edge_g(int id) const { return id == 0 ? slot(P_GZ) : sslot(EDGE0_G + 3 * id); }
-#endif
+    // tile <-> HBM slot of the persistent (P) or scratch (S) region
+    NM_DEV void loadR(Tile<DPL>& t, rsrc_t r, int s) const {
+        const int so = force_sgpr(s * slot_bytes);
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m) {
+            double2 q = buf_load2(r, voff + m * (64 * W * 16), so);
+            t.a[2 * m] = q.x; t.a[2 * m + 1] = q.y;
+        }
+    }
+    NM_DEV void storeR(const Tile<DPL>& t, rsrc_t r, int s) const {
+        const int so = force_sgpr(s * slot_bytes);
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m) buf_store2(r, voff + m * (64 * W * 16), so, t.a[2 * m], t.a[2 * m + 1]);
+    }
+    NM_DEV void loadP(Tile<DPL>& t, int s) const { loadR(t, rp, s); }
+    NM_DEV void storeP(const Tile<DPL>& t, int s) const { storeR(t, rp, s); }
+    NM_DEV void loadS(Tile<DPL>& t, int s) const { loadR(t, rs, s); }
+    NM_DEV void storeS(const Tile<DPL>& t, int s) const { storeR(t, rs, s); }
+    // one pair of a slot (U-turn operand streams); so = slot byte offset (wave-uniform)
+    NM_DEV int soS(int s) const { return force_sgpr(s * slot_bytes); }
+    NM_DEV double2 ld2(rsrc_t r, int so, int m) const { return buf_load2(r, voff + m * (64 * W * 16), so); }
+    // main-tree edges.  Edge id 0 is the trajectory's initial point and costs no store: its z / g_z are the chain's
+    // P_Z / P_GZ slots and its v is the staged normals buffer (stream order == memory order of a chain vector);
+    // ids 1, 2 are scratch slots.
+    struct SlotRef { rsrc_t r; int so; };
+    // (the edge id is wave-uniform; readfirstlane makes the descriptor / offset selection provably so — T20)
+    NM_DEV SlotRef edge_z(int id) const { id = force_sgpr(id); return id == 0 ? SlotRef{rp, soS(P_Z)} : SlotRef{rs, soS(EDGE0_Z + 3 * id)}; }
+    NM_DEV SlotRef edge_v(int id) const { id = force_sgpr(id); return SlotRef{rs, soS(id == 0 ? (int)STAGE_V : EDGE0_V + 3 * id)}; }
+    NM_DEV SlotRef edge_g(int id) const { id = force_sgpr(id); return id == 0 ? SlotRef{rp, soS(P_GZ)} : SlotRef{rs, soS(EDGE0_G + 3 * id)}; }
+    NM_DEV void loadRef(Tile<DPL>& t, SlotRef f) const {
+        const int so = f.so;
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m) {
+            double2 q = buf_load2(f.r, voff + m * (64 * W * 16), so);
+            t.a[2 * m] = q.x; t.a[2 * m + 1] = q.y;
+        }
+    }
+    NM_DEV void storeRef(const Tile<DPL>& t, SlotRef f) const {
+        const int so = f.so;
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m) buf_store2(f.r, voff + m * (64 * W * 16), so, t.a[2 * m], t.a[2 * m + 1]);
+    }
     NM_DEV void load(Tile<DPL>& t, const double* base) const { load_tile<DPL, W>(t, base); }
     NM_DEV void store(const Tile<DPL>& t, double* base) const { store_tile<DPL, W>(t, base); }
     NM_DEV int elem(int k) const { return elem_index<W>(k); }
@@ -349,17 +423,19 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64
     C.maxdepth_cfg = (int)P.s.maxdepth;
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
+    C.slot_bytes = (int)(P.dpad * 8);
+    C.voff = tid() * 16;
+    C.rp = make_rsrc(C.pv, (uint64_t)NUM_PSLOT * P.dpad * 8);
+    C.rs = make_rsrc(C.sv, (uint64_t)P.nsslot * P.dpad * 8);
     C.lsig = sh.sig;
     C.l1z = NM_LDS_L1 ? sh.l1_z : C.sslot(slot_L(C.maxdepth_cfg, 1));
     C.l1v = NM_LDS_L1 ? sh.l1_v : C.sslot(slot_L(C.maxdepth_cfg, 1) + 1);
-    C.edz = &sh.edge_z[0][0];
-    C.edv = &sh.edge_v[0][0];
     C.lmu = sh.mu;
-    C.pend = sh.pend[wave_id()];
+    C.pend = sh.pend[W == 1 ? 0 : wave_id()];
     C.zig = {P.zig_x, P.zig_f};
     {   // chain scalars: HBM -> LDS
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&P.sc[chain]);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc[wave_id()]);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc[W == 1 ? 0 : wave_id()]);
         constexpr int NW = (int)(sizeof(ChainScalars) / 8);
         static_assert(sizeof(ChainScalars) % 8 == 0 && NW <= 64, "ChainScalars must be <= 64 u64 words");
         __syncthreads();
@@ -484,12 +560,12 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
 // momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577).  The stream-ordered samples are
 // staged through `stage` (a [64*DPL] scratch vector in HBM/L2 owned by this wave) and re-read in tile order.
 template <int DPL, int W, class Dens>
-NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v, double* stage) {
-    fill_standard_normals(C.rng, stage, C.dim, C.zig);
-    const double2* st = C.tptr(stage);
+NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
+    fill_standard_normals(C.rng, C.sslot(STAGE_V), C.dim, C.zig);
+    const int so = C.soS(STAGE_V);
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
-        double2 q = st[m * 64 * W];
+        double2 q = C.ld2(C.rs, so, m);
         v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
         v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
@@ -531,7 +607,7 @@ template <int DPL, int W, class Dens>
 NM_DEV bool init_state(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
     st.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
     Tile<DPL> isig, sig, mu;
-    C.load(isig, C.slot(P_ISIG));
+    C.loadP(isig, P_ISIG);
     C.load(sig, C.lsig);
     C.load(mu, C.lmu);
     bool ok = true;
@@ -558,7 +634,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
         if (!init_state(C, x, st, gx)) return NM_CHAIN_BAD_INIT;
     }
     const double logdet = C.sc.mm_logdet;
-    sample_velocity(C, st.v, C.sslot(STAGE_V));                    // initialize_trajectory(resample) :687-736
+    sample_velocity(C, st.v);                    // initialize_trajectory(resample) :687-736
     const double ke0 = kinetic(st.v, C.red);
     const double e0 = ke0 - (st.logp + logdet);
     AcceptCollector col;
@@ -623,27 +699,27 @@ NM_DEV void update_estimator(ChainCtx<DPL, W, Dens>& C, bool late) {
 // RunningVariance::add_sample (reference adapt/diagonal.rs:31-44, array_update_variance cpu_math.rs:605-631)
 template <int DPL, int W, class Dens>
 NM_DEV void running_variance_add(ChainCtx<DPL, W, Dens>& C, int slot_mean, int slot_var, uint64_t new_count, const Tile<DPL>& value) {
-    if (new_count == 1) { C.store(value, C.slot(slot_mean)); return; }
+    if (new_count == 1) { C.storeP(value, slot_mean); return; }
     const double diff_scale = 1.0 / (double)new_count;
     Tile<DPL> mean, var;
-    C.load(mean, C.slot(slot_mean));
-    C.load(var, C.slot(slot_var));
+    C.loadP(mean, slot_mean);
+    C.loadP(var, slot_var);
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         double diff = value.a[k] - mean.a[k];
         mean.a[k] = mean.a[k] + diff * diff_scale;
         var.a[k] = var.a[k] + diff * diff;
     }
-    C.store(mean, C.slot(slot_mean));
-    C.store(var, C.slot(slot_var));
+    C.storeP(mean, slot_mean);
+    C.storeP(var, slot_var);
 }
 
 // writes sigma / inv_sigma / mu (HBM + the LDS copy of the resident chain), logdet, id
 template <int DPL, int W, class Dens>
 NM_DEV void commit_mass_matrix(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& sig, const Tile<DPL>& isig, const Tile<DPL>& mu) {
-    C.store(sig, C.slot(P_SIG));
-    C.store(isig, C.slot(P_ISIG));
-    C.store(mu, C.slot(P_MU));
+    C.storeP(sig, P_SIG);
+    C.storeP(isig, P_ISIG);
+    C.storeP(mu, P_MU);
     C.store(sig, C.lsig);
     C.store(mu, C.lmu);
     C.sc.mm_logdet = sum_ln_tile(C, isig);
@@ -677,13 +753,13 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C) {
     if (C.sc.cnt_fg < 3) return false;
     Tile<DPL> sig, isig, mu, dm, dv;
     C.load(sig, C.lsig);
-    C.load(isig, C.slot(P_ISIG));
-    C.load(dm, C.slot(E_DM));
-    C.load(dv, C.slot(E_DV));
+    C.loadP(isig, P_ISIG);
+    C.loadP(dm, E_DM);
+    C.loadP(dv, E_DV);
     if (C.P.s.use_grad_based_estimate) {
         Tile<DPL> gm, gv;
-        C.load(gm, C.slot(E_GM));
-        C.load(gv, C.slot(E_GV));
+        C.loadP(gm, E_GM);
+        C.loadP(gv, E_GV);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             bool valid = C.elem(k) < C.dim;
@@ -725,8 +801,8 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C) {
 template <int DPL, int W, class Dens>
 NM_DEV void copy_slot(ChainCtx<DPL, W, Dens>& C, int dst, int src) {
     Tile<DPL> t;
-    C.load(t, C.slot(src));
-    C.store(t, C.slot(dst));
+    C.loadP(t, src);
+    C.storeP(t, dst);
 }
 
 // GlobalStrategy::adapt (reference src/adapt_strategy.rs:121-222).  x, gx = chosen draw.
@@ -778,8 +854,8 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
             Tile<DPL> zero;
 #pragma unroll
             for (int k = 0; k < DPL; ++k) zero.a[k] = 0.0;
-            C.store(zero, C.slot(B_DM)); C.store(zero, C.slot(B_DV));
-            C.store(zero, C.slot(B_GM)); C.store(zero, C.slot(B_GV));
+            C.storeP(zero, B_DM); C.storeP(zero, B_DV);
+            C.storeP(zero, B_GM); C.storeP(zero, B_GV);
             force_update = true;
             if (!is_early) sc.current_window_size = next_window_size;
         }
@@ -857,7 +933,7 @@ template <int DPL, int W, class Dens>
 NM_DEV int cand_to_pool(ChainCtx<DPL, W, Dens>& C, uint32_t& used, const Tile<DPL>& z) {
     const int p = (int)__builtin_ctz(~used);
     used |= 1u << p;
-    C.store(z, C.sslot(slot_C(C.maxdepth_cfg, p)));
+    C.storeS(z, slot_C(C.maxdepth_cfg, p));
     return p;
 }
 
@@ -870,12 +946,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
-    sample_velocity(C, E.v, C.sslot(STAGE_V));
+    sample_velocity(C, E.v);
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
         Tile<DPL> x, gx, isig, sig, mu;
-        C.load(x, C.slot(P_X));
-        C.load(gx, C.slot(P_GX));
-        C.load(isig, C.slot(P_ISIG));
+        C.loadP(x, P_X);
+        C.loadP(gx, P_GX);
+        C.loadP(isig, P_ISIG);
         C.load(sig, C.lsig);
         C.load(mu, C.lmu);
 #pragma unroll
@@ -884,13 +960,13 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             E.z.a[k] = isig.a[k] * t;
             E.g.a[k] = gx.a[k] * sig.a[k];
         }
-        C.store(E.z, C.slot(P_Z));
-        C.store(E.g, C.slot(P_GZ));
+        C.storeP(E.z, P_Z);
+        C.storeP(E.g, P_GZ);
         sc.logdet = sc.mm_logdet;
         sc.transform_id = sc.mm_id;
     } else {
-        C.load(E.z, C.slot(P_Z));
-        C.load(E.g, C.slot(P_GZ));
+        C.loadP(E.z, P_Z);
+        C.loadP(E.g, P_GZ);
     }
     const double logdet = sc.logdet;
     const double ke_init = kinetic(E.v, C.red);
@@ -898,9 +974,6 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     R.e0 = e0;
     col.register_init(e0);
     // main tree = the initial point
-#if NM_LDS_EDGES
-    C.store(E.z, C.edge_z(0)); C.store(E.v, C.edge_v(0)); C.store(E.g, C.edge_g(0));
-#endif
     int left_slot = 0, right_slot = 0;   // edge slot ids
     bool o_is_edge = false;              // O still holds the edge written by the last successful doubling ...
     int o_edge_sign = 0;                 // ... in this direction
@@ -965,9 +1038,11 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         }
 
         if (depth == 0) {
-            // a single leaf: edge -> E -> O
-            const int es = fwd ? right_slot : left_slot;
-            C.load(E.z, C.edge_z(es)); C.load(E.v, C.edge_v(es)); C.load(E.g, C.edge_g(es));
+            // a single leaf from the initial point, which E has held since initialize_trajectory: E -> O
+#if !NM_TRIM_FIRST
+            { const int es = fwd ? right_slot : left_slot;
+              C.loadRef(E.z, C.edge_z(es)); C.loadRef(E.v, C.edge_v(es)); C.loadRef(E.g, C.edge_g(es)); }
+#endif
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(O, sub_log_size)
@@ -975,7 +1050,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         } else {
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
                 const int es = fwd ? right_slot : left_slot;
-                C.load(O.z, C.edge_z(es)); C.load(O.v, C.edge_v(es)); C.load(O.g, C.edge_g(es));
+                C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es)); C.loadRef(O.g, C.edge_g(es));
             }
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
@@ -984,10 +1059,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_LEAF_ACCOUNT(E, wE)
                 if (stop != STOP_NONE) break;
-                if ((n & 3) == 0) {
+                if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {     // at depth 1 leaf 0 is still in E when it is needed (top-level tests)
                     const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
-                    C.store(E.z, C.sslot(fs));
-                    C.store(E.v, C.sslot(fs + 1));
+                    C.storeS(E.z, fs);
+                    C.storeS(E.v, fs + 1);
                 }
                 // ---- odd leaf n + 1
                 leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
@@ -1013,17 +1088,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
                         const uint64_t a_first = nn + 1 - (1ull << k);
                         const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                        const double2* afz = C.tptr(C.sslot(slot_F(fa)));
-                        const double2* afv = C.tptr(C.sslot(slot_F(fa) + 1));
-                        const double2* alz = C.tptr(C.sslot(slot_L(MD, k - 1)));
-                        const double2* alv = C.tptr(C.sslot(slot_L(MD, k - 1) + 1));
+                        const int so_afz = C.soS(slot_F(fa)), so_afv = C.soS(slot_F(fa) + 1);
+                        const int so_alz = C.soS(slot_L(MD, k - 1)), so_alv = C.soS(slot_L(MD, k - 1) + 1);
                         double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
                         if (k == 2) {
                             const double2* l1z2 = C.tptr(C.l1z);      // A.last = L[1] lives in LDS
                             const double2* l1v2 = C.tptr(C.l1v);
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = afz[m * 64 * W], av = afv[m * 64 * W];
+                                const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
                                 const double2 lz = l1z2[m * 64 * W], lv = l1v2[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
@@ -1041,15 +1114,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                         turn_acc(bz, bv, azj, avj, s5, s6);
                                     }
                                 }
+                                NM_GROUP_BARRIER(m);
                             }
                         } else {
-                            const double2* bfz = C.tptr(C.sslot(slot_F(k - 1)));
-                            const double2* bfv = C.tptr(C.sslot(slot_F(k - 1) + 1));
+                            const int so_bfz = C.soS(slot_F(k - 1)), so_bfv = C.soS(slot_F(k - 1) + 1);
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = afz[m * 64 * W], av = afv[m * 64 * W];
-                                const double2 lz = alz[m * 64 * W], lv = alv[m * 64 * W];
-                                const double2 bz2 = bfz[m * 64 * W], bv2 = bfv[m * 64 * W];
+                                const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
+                                const double2 lz = C.ld2(C.rs, so_alz, m), lv = C.ld2(C.rs, so_alv, m);
+                                const double2 bz2 = C.ld2(C.rs, so_bfz, m), bv2 = C.ld2(C.rs, so_bfv, m);
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -1066,6 +1139,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                         turn_acc(bz, bv, azj, avj, s5, s6);
                                     }
                                 }
+                                NM_GROUP_BARRIER(m);
                             }
                         }
                         { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
@@ -1087,7 +1161,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
                     if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
-                    else { C.store(O.z, C.sslot(slot_L(MD, t))); C.store(O.v, C.sslot(slot_L(MD, t) + 1)); }
+                    else { C.storeS(O.z, slot_L(MD, t)); C.storeS(O.v, slot_L(MD, t) + 1); }
                     if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
                     else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
                     PendEntry e;
@@ -1109,33 +1183,33 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const double2* mlz = C.tptr(C.edge_z(left_slot));
-            const double2* mlv = C.tptr(C.edge_v(left_slot));
-            const double2* mrz = C.tptr(C.edge_z(right_slot));
-            const double2* mrv = C.tptr(C.edge_v(right_slot));
+            const auto mlz = C.edge_z(left_slot), mlv = C.edge_v(left_slot);
+            const auto mrz = C.edge_z(right_slot), mrv = C.edge_v(right_slot);
             if (depth == 0) {
+#if NM_TRIM_FIRST
+                turning = turning_regs(E, O, fwd, C.red);        // (initial point, leaf): both in registers
+#else
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
-                    if (fwd) {
-                        double2 az = mlz[m * 64 * W], av = mlv[m * 64 * W];
-                        turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2);
-                        turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2);
-                    } else {
-                        double2 az = mrz[m * 64 * W], av = mrv[m * 64 * W];
-                        turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2);
-                        turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2);
-                    }
+                    double2 az = fwd ? C.ld2(mlz.r, mlz.so, m) : C.ld2(mrz.r, mrz.so, m);
+                    double2 av = fwd ? C.ld2(mlv.r, mlv.so, m) : C.ld2(mrv.r, mrv.so, m);
+                    if (fwd) { turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2); turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2); }
+                    else { turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2); turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2); }
                 }
                 C.red.sum2(s1, s2);
                 turning = (s1 < 0.) | (s2 < 0.);
+#endif
             } else {
-                const double2* ofz = C.tptr(C.sslot(slot_F((int)depth)));
-                const double2* ofv = C.tptr(C.sslot(slot_F((int)depth) + 1));
+                // other.first (leaf 0 of this doubling): F[depth]; at depth 1 it is still E
+                const int so_ofz = C.soS(slot_F((int)depth)), so_ofv = C.soS(slot_F((int)depth) + 1);
+                const bool of_in_regs = NM_TRIM_FIRST && depth == 1;
 #pragma unroll
                 for (int m = 0; m < DPL / 2; ++m) {
-                    double2 lz = mlz[m * 64 * W], lv = mlv[m * 64 * W];
-                    double2 rz = mrz[m * 64 * W], rv = mrv[m * 64 * W];
-                    double2 oz = ofz[m * 64 * W], ov = ofv[m * 64 * W];
+                    double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
+                    double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
+                    double2 oz, ov;
+                    if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
+                    else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
                     const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
                     const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                     if (fwd) {
@@ -1149,6 +1223,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
                         turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
                     }
+                    NM_GROUP_BARRIER(m);
                 }
                 { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
                 turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
@@ -1168,12 +1243,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         {   // the new edge goes to the slot this side owns alone, or to the free one while both sides share the initial point
             int ns = fwd ? right_slot : left_slot;
             const int other_side = fwd ? left_slot : right_slot;
-#if NM_LDS_EDGES
-            if (left_slot == right_slot) ns = 1;
-#else
             if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
-#endif
-            C.store(O.z, C.edge_z(ns)); C.store(O.v, C.edge_v(ns)); C.store(O.g, C.edge_g(ns));
+            C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); C.storeRef(O.g, C.edge_g(ns));
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;
         }
@@ -1185,7 +1256,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     R.depth = depth;
     R.chosen = mc;
     if (fatal) return NM_CHAIN_LOGP_FATAL;
-    if (mc.slot >= 0) C.load(zc, C.sslot(slot_C(MD, mc.slot)));
+    if (mc.slot >= 0) C.loadS(zc, slot_C(MD, mc.slot));
     return NM_CHAIN_OK;
 }
 
@@ -1212,8 +1283,8 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
         return;
     }
     if (R.chosen.slot == -1) {                                   // the draw is the trajectory's initial point
-        C.load(x, C.slot(P_X)); C.load(gx, C.slot(P_GX));
-        C.load(z, C.slot(P_Z)); C.load(gz, C.slot(P_GZ));
+        C.loadP(x, P_X); C.loadP(gx, P_GX);
+        C.loadP(z, P_Z); C.loadP(gz, P_GZ);
     } else {
         // the winner's x, g_x, g_z from its z: the same operations as inside the leapfrog => the same bits
         Tile<DPL> sig, mu;
@@ -1227,8 +1298,8 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
         (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) gz.a[k] = gx.a[k] * sig.a[k];
-        C.store(x, C.slot(P_X)); C.store(gx, C.slot(P_GX));
-        C.store(z, C.slot(P_Z)); C.store(gz, C.slot(P_GZ));
+        C.storeP(x, P_X); C.storeP(gx, P_GX);
+        C.storeP(z, P_Z); C.storeP(gz, P_GZ);
         sc.logp = R.chosen.logp;
     }
     // DrawGradCollector::register_draw (adapt/diagonal.rs:73-83)
@@ -1273,13 +1344,13 @@ template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, W, Dens> C(P, sh.sc[wave_id()]);
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         if (C.sc.status == NM_CHAIN_OK) {
             {
                 Tile<DPL> t;
-                C.load(t, C.slot(P_SIG)); C.store(t, C.lsig);
-                C.load(t, C.slot(P_MU)); C.store(t, C.lmu);
+                C.loadP(t, P_SIG); C.store(t, C.lsig);
+                C.loadP(t, P_MU); C.store(t, C.lmu);
             }
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
@@ -1296,7 +1367,7 @@ template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        ChainCtx<DPL, W, Dens> C(P, sh.sc[wave_id()]);
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
         dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
@@ -1315,8 +1386,8 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         if (!C.red.all(ok)) status = NM_CHAIN_BAD_INIT;
         if (status == NM_CHAIN_OK) {
             // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
-            C.store(x, C.slot(E_DM)); C.store(x, C.slot(B_DM));
-            C.store(gx, C.slot(E_GM)); C.store(gx, C.slot(B_GM));
+            C.storeP(x, E_DM); C.storeP(x, B_DM);
+            C.storeP(gx, E_GM); C.storeP(gx, B_GM);
             sc.cnt_fg = 1; sc.cnt_bg = 1;
             mass_matrix_from_grad(C, x, gx);
             status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
@@ -1326,8 +1397,8 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
             Tile<DPL> g2;
             if (!init_state(C, x, st, g2)) status = NM_CHAIN_BAD_INIT;
             else {
-                C.store(x, C.slot(P_X)); C.store(g2, C.slot(P_GX));
-                C.store(st.z, C.slot(P_Z)); C.store(st.g, C.slot(P_GZ));
+                C.storeP(x, P_X); C.storeP(g2, P_GX);
+                C.storeP(st.z, P_Z); C.storeP(st.g, P_GZ);
                 sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
             }
         }
