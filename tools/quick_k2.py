@@ -8,8 +8,9 @@ tune = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 draws = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 dpl = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 wpc = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+gb = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 s = N.DiagNutsSettings(num_chains=C, seed=20260928, num_tune=tune, num_draws=draws)
-b = N.ChainBatch(s, N.LogpSpec.iid_normal(D, 3.0), C, dims_per_lane=dpl, waves_per_chain=wpc)
+b = N.ChainBatch(s, N.LogpSpec.iid_normal(D, 3.0), C, dims_per_lane=dpl, waves_per_chain=wpc, grid_blocks=gb)
 x0 = b.init_positions_uniform()
 t = time.time(); st = b.set_position(x0); print('init', time.time()-t, (st != 0).sum())
 t = time.time(); b.draw_device(tune); t1 = time.time()-t
