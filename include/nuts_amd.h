@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 1
+#define NM_ABI_VERSION 2
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -148,7 +148,39 @@ typedef struct nm_draw_stats {
     double   fisher_distance;      /* sum (z+g_z)^2, math.rs:92 */
     double   divergence_energy_error; /* NaN when not diverging or unknown */
     uint64_t chain_status;         /* NM_CHAIN_* */
+    int64_t  transformation_update_id; /* DiagMassMatrixStats.transformation_update_id (src/transform/diagonal.rs:32-71):
+                                      the mass-matrix version if it differs from the one seen at the previous draw's
+                                      statistics (first draw: compared with -1, src/sampler.rs:795), else -1 (= None) */
 } nm_draw_stats;
+/* Notes on reference naming.  `NutsStats.draw` (src/chain.rs:215-232) is read AFTER `draw_count += 1`
+ * (src/chain.rs:184, :195) and therefore equals nm_draw_stats.draw + 1; `divergence_draw` likewise.
+ * `divergence_message` is a pure function of divergence_energy_error (src/dynamics/hamiltonian.rs:86-98):
+ * NaN -> "Divergence due to NaN energy error", else "Divergence due to large energy error: {:.4}". */
+
+/* Where one call of nm_engine_draw_ex records its results.  Every pointer is a DEVICE pointer or NULL (not
+ * recorded).  Vector outputs are [n_draws][n_chains][dim] row-major; the reference's store_* settings
+ * (src/sampler.rs:218-226, :236) decide which of them a caller allocates:
+ *   store_unconstrained -> d_positions (PointStats.unconstrained_draw == the draw itself)
+ *   store_gradient      -> d_gradient
+ *   store_transformed   -> d_transformed_position, d_transformed_gradient
+ *   store_mass_matrix   -> d_mass_matrix_inv, d_transformation_mu   (event rows)
+ *   store_divergences   -> d_divergence_start, d_divergence_start_gradient, d_divergence_end   (event rows)
+ * Event rows are written only on the draws where the event happens (stats.transformation_update_id >= 0, resp.
+ * stats.diverging != 0); other rows are left untouched.  `divergence_momentum` is always None on this path
+ * (start_momentum: None, src/dynamics/transformed_hamiltonian.rs:567, :596) and has no buffer. */
+typedef struct nm_draw_outputs {
+    double*        d_positions;               /* the draws (State::write_position, src/chain.rs:163-164) */
+    nm_draw_stats* d_stats;                   /* [n_draws][n_chains] */
+    double*        d_gradient;                /* PointStats.gradient: untransformed gradient at the draw */
+    double*        d_transformed_position;    /* PointStats.transformed_position  z = (x - mu)/sigma */
+    double*        d_transformed_gradient;    /* PointStats.transformed_gradient  g_z = g_x * sigma */
+    double*        d_mass_matrix_inv;         /* DiagMassMatrixStats.mass_matrix_inv = the `stds` vector (diagonal.rs:52-56) */
+    double*        d_transformation_mu;       /* DiagMassMatrixStats.transformation_mu = the `mean` vector */
+    double*        d_divergence_start;        /* DivergenceInfo.start_location (position the divergent leapfrog started from) */
+    double*        d_divergence_start_gradient;
+    double*        d_divergence_end;          /* DivergenceInfo.end_location */
+    uint64_t       reserved[6];
+} nm_draw_outputs;
 
 typedef struct nm_engine nm_engine;
 
@@ -190,12 +222,21 @@ nm_status nm_init_positions_uniform(uint64_t seed, uint64_t chain_id_offset, uin
  * Both may also be fetched afterwards with the nm_engine_read_* helpers. */
 nm_status nm_engine_draw(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats);
 
+/* `Chain::expanded_draw` x n_draws (reference src/chain.rs:190-204): nm_engine_draw plus the vector-valued
+ * statistics selected by the non-NULL pointers of `out`.  Asynchronous variant: returns after enqueueing. */
+nm_status nm_engine_draw_ex(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* out);
+nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* out);
+
 /* Same, asynchronous on the engine's stream: returns after enqueueing. */
 nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats);
 nm_status nm_engine_synchronize(nm_engine* e);
 
 /* Convenience: run n_draws and copy results to host buffers ([n_draws][n_chains][dim] / [n_draws][n_chains]). */
 nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats);
+
+/* nm_engine_draw_ex with HOST destinations: the pointers of `h_out` are host arrays of the same shapes; event
+ * rows that were not written read as NaN. */
+nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* h_out);
 
 /* Current per-chain quantities, host copies ([n_chains][dim] unless noted). */
 nm_status nm_engine_get_positions(nm_engine* e, double* h_x);

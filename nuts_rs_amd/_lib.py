@@ -19,7 +19,8 @@ STATUS_NAMES = {0: "NM_OK", 1: "NM_ERR_INVALID_ARG", 2: "NM_ERR_NO_DEVICE", 3: "
 ABI_SYMBOLS = [
     "nm_settings_default", "nm_engine_config_default", "nm_engine_create", "nm_engine_destroy",
     "nm_engine_set_positions", "nm_init_positions_uniform", "nm_engine_draw", "nm_engine_draw_async",
-    "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
+    "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
+    "nm_engine_draw_ex_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
@@ -60,7 +61,17 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
+    ("transformation_update_id", "<i8"),
 ])
+
+# nm_draw_outputs: the draws, the scalar statistics and the vector-valued statistics (reference stat names)
+VECTOR_STATS = ("gradient", "transformed_position", "transformed_gradient", "mass_matrix_inv", "transformation_mu",
+                "divergence_start", "divergence_start_gradient", "divergence_end")
+
+
+class NmDrawOutputs(C.Structure):
+    _fields_ = ([("d_positions", C.c_void_p), ("d_stats", C.c_void_p)] + [("d_" + k, C.c_void_p) for k in VECTOR_STATS]
+                + [("reserved", C.c_uint64 * 6)])
 
 _lib = None
 
@@ -96,6 +107,9 @@ def load():
     L.nm_engine_draw_async.argtypes = [vp, u64, vp, vp]
     L.nm_engine_synchronize.argtypes = [vp]
     L.nm_engine_draw_to_host.argtypes = [vp, u64, vp, vp]
+    L.nm_engine_draw_ex.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]
+    L.nm_engine_draw_ex_async.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]
+    L.nm_engine_draw_ex_to_host.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]
     L.nm_engine_get_positions.argtypes = [vp, vp]
     L.nm_engine_get_gradients.argtypes = [vp, vp]
     L.nm_engine_get_mass_matrix.argtypes = [vp, vp, vp]

@@ -320,7 +320,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
             nm_chain_rng_key(s.seed, cfg.chain_id_offset + c, key);
             for (int i = 0; i < 8; ++i)
                 q.key[i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) | ((uint32_t)key[4 * i + 3] << 24);
-            q.transform_id = -1; q.mm_id = -1;
+            q.transform_id = -1; q.mm_id = -1; q.stats_last_id = -1;
             q.tuning = 1; q.has_initial_mass_matrix = 1;
             q.current_window_size = s.mass_matrix_switch_freq;
             q.status = NM_CHAIN_OK;
@@ -380,15 +380,21 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     return NM_OK;
 }
 
-extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
+extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* out) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (!out) return fail(NM_ERR_INVALID_ARG, "null nm_draw_outputs");
     if (!e->positioned) return fail(NM_ERR_STATE, "nm_engine_draw before nm_engine_set_positions");
     if (n_draws == 0) return NM_OK;
     HIP_TRY(hipSetDevice(e->device));
     nm_status st = collect_timing(e);
     if (st != NM_OK) return st;
     KParams P = e->P;
-    P.n_draws = n_draws; P.out_positions = d_positions; P.out_stats = d_stats;
+    P.n_draws = n_draws; P.out_positions = out->d_positions; P.out_stats = out->d_stats;
+    P.out_gradient = out->d_gradient;
+    P.out_tpos = out->d_transformed_position; P.out_tgrad = out->d_transformed_gradient;
+    P.out_mm_inv = out->d_mass_matrix_inv; P.out_mm_mu = out->d_transformation_mu;
+    P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
+    P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -403,29 +409,56 @@ extern "C" nm_status nm_engine_synchronize(nm_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     return collect_timing(e);
 }
+extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
+    nm_draw_outputs out = {};
+    out.d_positions = d_positions; out.d_stats = d_stats;
+    return nm_engine_draw_ex_async(e, n_draws, &out);
+}
+extern "C" nm_status nm_engine_draw_ex(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* out) {
+    nm_status st = nm_engine_draw_ex_async(e, n_draws, out);
+    if (st != NM_OK) return st;
+    return nm_engine_synchronize(e);
+}
 extern "C" nm_status nm_engine_draw(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
     nm_status st = nm_engine_draw_async(e, n_draws, d_positions, d_stats);
     if (st != NM_OK) return st;
     return nm_engine_synchronize(e);
 }
 
-extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats) {
+extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* h_out) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (!h_out) return fail(NM_ERR_INVALID_ARG, "null nm_draw_outputs");
     HIP_TRY(hipSetDevice(e->device));
-    double* d_pos = nullptr;
-    nm_draw_stats* d_st = nullptr;
-    const size_t pos_bytes = (size_t)n_draws * e->n_chains * e->dim * sizeof(double);
+    const size_t vec_bytes = (size_t)n_draws * e->n_chains * e->dim * sizeof(double);
     const size_t st_bytes = (size_t)n_draws * e->n_chains * sizeof(nm_draw_stats);
-    if (h_positions && pos_bytes) HIP_TRY(hipMalloc(&d_pos, pos_bytes));
-    if (h_stats && st_bytes) {
-        hipError_t er = hipMalloc(&d_st, st_bytes);
-        if (er != hipSuccess) { if (d_pos) (void)hipFree(d_pos); return fail(NM_ERR_HIP, "hipMalloc stats: %s", hipGetErrorString(er)); }
+    // (host destination, device slot, bytes, is an event array)
+    nm_draw_outputs d = {};
+    struct Item { void* host; void** dev; size_t bytes; bool event; };
+    Item items[] = {
+        {h_out->d_positions, (void**)&d.d_positions, vec_bytes, false},
+        {h_out->d_stats, (void**)&d.d_stats, st_bytes, false},
+        {h_out->d_gradient, (void**)&d.d_gradient, vec_bytes, false},
+        {h_out->d_transformed_position, (void**)&d.d_transformed_position, vec_bytes, false},
+        {h_out->d_transformed_gradient, (void**)&d.d_transformed_gradient, vec_bytes, false},
+        {h_out->d_mass_matrix_inv, (void**)&d.d_mass_matrix_inv, vec_bytes, true},
+        {h_out->d_transformation_mu, (void**)&d.d_transformation_mu, vec_bytes, true},
+        {h_out->d_divergence_start, (void**)&d.d_divergence_start, vec_bytes, true},
+        {h_out->d_divergence_start_gradient, (void**)&d.d_divergence_start_gradient, vec_bytes, true},
+        {h_out->d_divergence_end, (void**)&d.d_divergence_end, vec_bytes, true},
+    };
+    nm_status st = NM_OK;
+    for (Item& it : items) {
+        if (!it.host || !it.bytes) continue;
+        hipError_t er = hipMalloc(it.dev, it.bytes);
+        if (er == hipSuccess && it.event) er = hipMemsetAsync(*it.dev, 0xFF, it.bytes, e->stream);   // all-ones = NaN
+        if (er != hipSuccess) { st = fail(NM_ERR_HIP, "device buffer of %zu bytes: %s", it.bytes, hipGetErrorString(er)); break; }
     }
-    nm_status st = nm_engine_draw(e, n_draws, d_pos, d_st);
-    if (st == NM_OK && d_pos && hipMemcpy(h_positions, d_pos, pos_bytes, hipMemcpyDeviceToHost) != hipSuccess) st = fail(NM_ERR_HIP, "copy positions");
-    if (st == NM_OK && d_st && hipMemcpy(h_stats, d_st, st_bytes, hipMemcpyDeviceToHost) != hipSuccess) st = fail(NM_ERR_HIP, "copy stats");
-    if (d_pos) (void)hipFree(d_pos);
-    if (d_st) (void)hipFree(d_st);
+    if (st == NM_OK) st = nm_engine_draw_ex(e, n_draws, &d);
+    for (Item& it : items) {
+        if (st == NM_OK && *it.dev && hipMemcpy(it.host, *it.dev, it.bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            st = fail(NM_ERR_HIP, "copy of a result array to the host failed");
+        if (*it.dev) (void)hipFree(*it.dev);
+    }
     if (st != NM_OK) return st;
     // surface chain failures the way Chain::draw's Result does
     std::vector<ChainScalars> sc(e->n_chains);
@@ -434,6 +467,11 @@ extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, doub
     for (auto& q : sc) if (q.status != NM_CHAIN_OK) failed++;
     if (failed) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s) stopped with an error status", (unsigned long long)failed);
     return NM_OK;
+}
+extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats) {
+    nm_draw_outputs h = {};
+    h.d_positions = h_positions; h.d_stats = h_stats;
+    return nm_engine_draw_ex_to_host(e, n_draws, &h);
 }
 
 static nm_status read_slot(nm_engine* e, int slot, double* h_out) {

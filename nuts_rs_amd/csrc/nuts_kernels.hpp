@@ -89,6 +89,7 @@ struct ChainScalars {
     uint64_t last_n_steps;
     uint64_t status;       // NM_CHAIN_*
     uint64_t total_steps;  // leapfrogs since creation (metric)
+    int64_t stats_last_id; // mass-matrix id at the previous statistics extraction (chain.rs:195-200), starts at -1
 };
 
 struct KParams {
@@ -107,6 +108,9 @@ struct KParams {
     // outputs of the draw kernel
     double* out_positions;       // [n_draws][n_chains][dim] or null
     nm_draw_stats* out_stats;    // [n_draws][n_chains] or null
+    // vector-valued statistics (nm_draw_outputs), [n_draws][n_chains][dim] or null
+    double *out_gradient, *out_tpos, *out_tgrad, *out_mm_inv, *out_mm_mu;
+    double *out_div_start, *out_div_start_grad, *out_div_end;
     uint64_t n_draws;
     const double* x0;            // init kernel: [n_chains][dim]
 };
@@ -910,6 +914,7 @@ struct DrawResult {
     uint64_t depth;
     bool diverging, reached_maxdepth, has_divergence_energy_error;
     double divergence_energy_error;
+    int64_t div_start_idx;       // index_in_trajectory of the point the divergent leapfrog started from
     CandRef chosen;
     double e0;
 };
@@ -994,7 +999,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
     }
     R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false;
-    R.divergence_energy_error = 0.;
+    R.divergence_energy_error = 0.; R.div_start_idx = 0;
+    const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
     bool fatal = false;
     bool in_extra = false;        // inside the `for _ in 0..extra_doublings` loop of src/nuts.rs:350-371
     uint64_t extra_left = 0;
@@ -1023,13 +1029,17 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         o_is_edge = false;               // O is about to be overwritten; set again only by a successful merge
 
         // divergence test + collector for a fresh leaf (transformed_hamiltonian.rs:590-612); returns -energy_error
-#define NM_LEAF_ACCOUNT(PT, WOUT)                                                                         \
+#define NM_LEAF_ACCOUNT(START, PT, WOUT)                                                                  \
         {                                                                                                 \
             const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
             const double err_ = energy_ - e0;                                                             \
             if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
+                R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
+                if (want_div) {          /* DivergenceInfo locations: the F[0] scratch pair is dead from here on */ \
+                    C.storeS((START).z, slot_F(0)); C.storeS((PT).z, slot_F(0) + 1);                      \
+                }                                                                                         \
                 stop = STOP_DIVERGING;                                                                    \
             } else {                                                                                      \
                 col.register_ok(energy_);                                                                 \
@@ -1045,7 +1055,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 #endif
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
-            NM_LEAF_ACCOUNT(O, sub_log_size)
+            NM_LEAF_ACCOUNT(E, O, sub_log_size)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
@@ -1057,7 +1067,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 double wE = 0., wO = 0.;
                 leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
-                NM_LEAF_ACCOUNT(E, wE)
+                NM_LEAF_ACCOUNT(O, E, wE)
                 if (stop != STOP_NONE) break;
                 if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {     // at depth 1 leaf 0 is still in E when it is needed (top-level tests)
                     const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
@@ -1067,7 +1077,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 // ---- odd leaf n + 1
                 leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
-                NM_LEAF_ACCOUNT(O, wO)
+                NM_LEAF_ACCOUNT(E, O, wO)
                 if (stop != STOP_NONE) break;
                 // ---- level-1 merge: A = {E}, B = {O}, everything in registers
                 {
@@ -1263,6 +1273,44 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 // ---------------------------------------------------------------------------------------------
 // NutsChain::draw (reference src/chain.rs:151-188) + the scalar stats of expanded_draw (:190-232)
 // ---------------------------------------------------------------------------------------------
+// one row of a [n_draws][n_chains][dim] statistics array
+template <int DPL, int W, class Dens>
+NM_DEV void write_row(ChainCtx<DPL, W, Dens>& C, double* base, size_t row, const Tile<DPL>& t) {
+    if (!base) return;
+    double* dst = base + row;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        int d = C.elem(k);
+        if (d < C.dim) dst[d] = t.a[k];
+    }
+}
+
+// DivergenceInfo.{start_location, start_gradient, end_location} (transformed_hamiltonian.rs:590-604) of the draw's
+// divergent leapfrog, from the z of its two points (stashed in F[0] by NM_LEAF_ACCOUNT): x = z·σ + μ and the density
+// gradient are recomputed with the leapfrog's own operations, hence the same bits.  A start point with index 0 is
+// the trajectory's initial point, whose x and g_x are still in P_X / P_GX.
+template <int DPL, int W, class Dens>
+NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx, size_t row) {
+    const KParams& P = C.P;
+    Tile<DPL> x, gx, zt, sig, mu;
+    C.load(sig, C.lsig);
+    C.load(mu, C.lmu);
+    if (start_idx == 0) {
+        C.loadP(x, P_X); C.loadP(gx, P_GX);
+    } else {
+        C.loadS(zt, slot_F(0));
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) x.a[k] = __builtin_fma(1.0, mu.a[k], zt.a[k] * sig.a[k]);
+        (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+    }
+    write_row(C, P.out_div_start, row, x);
+    write_row(C, P.out_div_start_grad, row, gx);
+    C.loadS(zt, slot_F(0) + 1);
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) x.a[k] = __builtin_fma(1.0, mu.a[k], zt.a[k] * sig.a[k]);
+    write_row(C, P.out_div_end, row, x);
+}
+
 template <int DPL, int W, class Dens>
 NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
@@ -1282,6 +1330,9 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
         }
         return;
     }
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
+        emit_divergence_vectors(C, R.div_start_idx, row);         // before P_X / P_GX take the new draw
     if (R.chosen.slot == -1) {                                   // the draw is the trajectory's initial point
         C.loadP(x, P_X); C.loadP(gx, P_GX);
         C.loadP(z, P_Z); C.loadP(gz, P_GZ);
@@ -1305,14 +1356,10 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     // DrawGradCollector::register_draw (adapt/diagonal.rs:73-83)
     const int64_t idx = R.chosen.idx;
     const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
-    if (P.out_positions) {
-        double* dst = P.out_positions + (t_out * P.n_chains + chain) * P.dim;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            int d = C.elem(k);
-            if (d < C.dim) dst[d] = x.a[k];
-        }
-    }
+    write_row(C, P.out_positions, row, x);
+    write_row(C, P.out_gradient, row, gx);                       // PointStats (transformed_hamiltonian.rs:122-157)
+    write_row(C, P.out_tpos, row, z);
+    write_row(C, P.out_tgrad, row, gz);
     double fd = 0.0;                                             // sq_norm_sum (cpu_math.rs:235-243)
 #pragma unroll
     for (int k = 0; k < DPL; ++k) fd = fd + (z.a[k] + gz.a[k]) * (z.a[k] + gz.a[k]);
@@ -1333,6 +1380,14 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     out.fisher_distance = fd;
     out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
     out.chain_status = ast;
+    // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70): an event when the version moved since the last draw
+    out.transformation_update_id = -1;
+    if (sc.mm_id != sc.stats_last_id) {
+        out.transformation_update_id = sc.mm_id;
+        if (P.out_mm_inv) { C.load(x, C.lsig); write_row(C, P.out_mm_inv, row, x); }
+        if (P.out_mm_mu) { C.load(x, C.lmu); write_row(C, P.out_mm_mu, row, x); }
+    }
+    sc.stats_last_id = sc.mm_id;
     if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
 }

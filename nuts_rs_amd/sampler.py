@@ -16,7 +16,8 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, check
+from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, VECTOR_STATS,
+                   check)
 
 LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS = 0, 1, 2, 3
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
@@ -214,6 +215,39 @@ class ChainBatch:
         check(_lib.load().nm_engine_draw_to_host(self._h, n_draws, pos.ctypes.data if positions else None,
                                                  st.ctypes.data if stats else None))
         return pos, st
+
+    def stored_vectors(self):
+        """The vector statistics the settings' store_* switches select (reference src/sampler.rs:218-226, :236)."""
+        s = self.settings
+        names = []
+        if s.store_gradient:
+            names.append("gradient")
+        if s.store_transformed:
+            names += ["transformed_position", "transformed_gradient"]
+        if s.adapt_options.mass_matrix_options.store_mass_matrix:
+            names += ["mass_matrix_inv", "transformation_mu"]
+        if s.store_divergences:
+            names += ["divergence_start", "divergence_start_gradient", "divergence_end"]
+        return names
+
+    def expanded_draw_many(self, n_draws, vectors=None):
+        """`Chain::expanded_draw` x n_draws (src/chain.rs:190-204): positions, scalar stats and a dict of the
+        vector-valued statistics ([n_draws, n_chains, dim]; rows of events that did not happen are NaN).
+        `vectors` defaults to what the settings' store_* switches select."""
+        names = list(self.stored_vectors() if vectors is None else vectors)
+        bad = [k for k in names if k not in VECTOR_STATS]
+        if bad:
+            raise ValueError(f"unknown vector statistics {bad}; known: {VECTOR_STATS}")
+        shape = (n_draws, self.n_chains, self.logp.dim)
+        pos = np.empty(shape)
+        st = np.zeros(shape[:2], dtype=STATS_DTYPE)
+        vec = {k: np.empty(shape) for k in names}
+        out = NmDrawOutputs()
+        out.d_positions, out.d_stats = pos.ctypes.data, st.ctypes.data
+        for k, a in vec.items():
+            setattr(out, "d_" + k, a.ctypes.data)
+        check(_lib.load().nm_engine_draw_ex_to_host(self._h, n_draws, C.byref(out)))
+        return pos, st, vec
 
     def draw_device(self, n_draws, d_positions=0, d_stats=0, sync=True):
         """n_draws draws with results left in caller-provided device buffers (raw pointers, e.g. tensor.data_ptr())."""

@@ -48,6 +48,21 @@ struct DrawStats {   // same field order as nm_draw_stats
     double step_size, step_size_bar, mean_tree_accept, mean_tree_accept_sym, max_energy_error;
     double logp, energy, energy_error, fisher_distance, divergence_energy_error;
     uint64_t chain_status;
+    int64_t transformation_update_id;   // DiagMassMatrixStats.transformation_update_id, -1 = None
+};
+
+// Optional vector-valued statistics of one draw (rows of length dim; nullptr = not wanted).  The reference's
+// PointStats (transformed_hamiltonian.rs:96-112), DiagMassMatrixStats (transform/diagonal.rs:32-71) and
+// DivergenceStats (dynamics/hamiltonian.rs:38-55).  Event rows are written only on the draws where the event happens.
+struct DrawVectors {
+    double* gradient = nullptr;
+    double* transformed_position = nullptr;
+    double* transformed_gradient = nullptr;
+    double* mass_matrix_inv = nullptr;          // where transformation_update_id >= 0
+    double* transformation_mu = nullptr;
+    double* divergence_start = nullptr;         // where diverging
+    double* divergence_start_gradient = nullptr;
+    double* divergence_end = nullptr;
 };
 
 enum { LOGP_IID_NORMAL = 0, LOGP_DIAG_NORMAL = 1, LOGP_FUNNEL = 2, LOGP_EIGHT_SCHOOLS = 3, LOGP_HOST_CALLBACK = 100 };
@@ -267,7 +282,12 @@ struct Collector {   // CombinedCollector (reference src/adapt_strategy.rs:286-3
     explicit Collector(size_t n) : dg(n) {}
 };
 
-struct DivergenceInfo { bool present = false; bool has_energy_error = false; double energy_error = 0; };
+struct DivergenceInfo {   // dynamics/hamiltonian.rs:20-36 (start_momentum is always None on this path)
+    bool present = false; bool has_energy_error = false; double energy_error = 0;
+    Vec start_location, start_gradient, end_location;
+    bool has_end = false;
+    int64_t start_idx = 0, end_idx = 0;
+};
 enum LeapfrogKind { LF_OK, LF_DIVERGENCE, LF_ERR };
 struct LeapfrogResult { LeapfrogKind kind; State state; DivergenceInfo info; };
 
@@ -300,6 +320,7 @@ struct Hamiltonian {
         if (st != 0) {
             if (st == 2) return {LF_ERR, nullptr, {}};
             DivergenceInfo info; info.present = true;
+            info.start_location = s.x; info.start_gradient = s.gx; info.start_idx = s.index_in_trajectory;
             if (acc) acc->register_leapfrog(*m, out.get(), true);
             return {LF_DIVERGENCE, nullptr, info};
         }
@@ -313,6 +334,8 @@ struct Hamiltonian {
         const double energy_error = o.energy() - energy_baseline;
         if ((energy_error > max_energy_error) | !std::isfinite(energy_error)) {  // :590-610
             DivergenceInfo info; info.present = true; info.has_energy_error = true; info.energy_error = energy_error;
+            info.start_location = s.x; info.start_gradient = s.gx; info.end_location = o.x; info.has_end = true;
+            info.start_idx = s.index_in_trajectory; info.end_idx = o.index_in_trajectory;
             if (acc) acc->register_leapfrog(*m, out.get(), true);
             return {LF_DIVERGENCE, nullptr, info};
         }
@@ -561,6 +584,7 @@ struct Chain {
     DualAverage da;
     double last_mean_tree_accept = 0, last_sym_mean_tree_accept = 0, last_max_energy_error = 0;
     uint64_t last_n_steps = 0;
+    int64_t stats_last_id = -1;
     size_t n;
 
     Chain(const Settings& s_, const Density& d, const MathCfg& cfg, uint64_t chain, const uint8_t key[32])
@@ -705,7 +729,7 @@ struct Chain {
     }
 
     // NutsChain::draw chain.rs:151-188 (+ the stats of expanded_draw :190-232)
-    int draw(double* out_position, DrawStats* stats) {
+    int draw(double* out_position, DrawStats* stats, const DrawVectors* vec = nullptr) {
         State chosen;
         SampleInfo info;
         int rc = nuts_draw(m, state, rng, h, options, coll, &chosen, &info);
@@ -726,7 +750,23 @@ struct Chain {
             o.divergence_energy_error = (info.divergence.present && info.divergence.has_energy_error)
                                             ? info.divergence.energy_error : NAN;
             o.chain_status = arc;
+            // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70) against the id seen at the previous
+            // extraction (chain.rs:195-200; starts at -1, sampler.rs:795)
+            o.transformation_update_id = h.mm.id != stats_last_id ? h.mm.id : -1;
         }
+        if (vec) {
+            auto put = [&](double* dst, const Vec& v) { if (dst) for (size_t i = 0; i < n; ++i) dst[i] = v[i]; };
+            put(vec->gradient, chosen->gx);
+            put(vec->transformed_position, chosen->z);
+            put(vec->transformed_gradient, chosen->gz);
+            if (h.mm.id != stats_last_id) { put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean); }
+            if (info.divergence.present) {
+                put(vec->divergence_start, info.divergence.start_location);
+                put(vec->divergence_start_gradient, info.divergence.start_gradient);
+                if (info.divergence.has_end) put(vec->divergence_end, info.divergence.end_location);
+            }
+        }
+        stats_last_id = h.mm.id;
         draw_count += 1;
         state = chosen;
         last_info = info;

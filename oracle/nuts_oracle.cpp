@@ -84,7 +84,8 @@ void nmo_chain_get_state(void* cv, double* x, double* gx, double* stds, double* 
 // out_stats [n_draws][n] or NULL.  Returns the number of chains that failed.
 int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
             const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_draws,
-            double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads) {
+            double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads,
+            const DrawVectors* out_vec /* bases of [n_draws][n][dim] arrays, or NULL */) {
     std::atomic<uint64_t> next{0}, steps{0};
     std::atomic<int> failed{0};
     auto work = [&]() {
@@ -99,7 +100,16 @@ int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params,
             uint64_t local = 0;
             for (uint64_t t = 0; t < n_draws; ++t) {
                 DrawStats st;
-                int rc = ch.draw(out_positions ? out_positions + (t * n_chains + c) * dim : nullptr, &st);
+                DrawVectors row;
+                if (out_vec) {
+                    const size_t off = (t * n_chains + c) * dim;
+                    auto at = [&](double* b) { return b ? b + off : nullptr; };
+                    row = {at(out_vec->gradient), at(out_vec->transformed_position), at(out_vec->transformed_gradient),
+                           at(out_vec->mass_matrix_inv), at(out_vec->transformation_mu), at(out_vec->divergence_start),
+                           at(out_vec->divergence_start_gradient), at(out_vec->divergence_end)};
+                }
+                int rc = ch.draw(out_positions ? out_positions + (t * n_chains + c) * dim : nullptr, &st,
+                                 out_vec ? &row : nullptr);
                 if (out_stats) out_stats[t * n_chains + c] = st;
                 local += st.n_steps;
                 if (rc != ST_OK) { failed++; break; }

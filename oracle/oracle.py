@@ -47,7 +47,15 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
+    ("transformation_update_id", "<i8"),
 ])
+
+VECTOR_STATS = ("gradient", "transformed_position", "transformed_gradient", "mass_matrix_inv", "transformation_mu",
+                "divergence_start", "divergence_start_gradient", "divergence_end")
+
+
+class DrawVectors(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in VECTOR_STATS]
 
 
 class MathCfg(C.Structure):
@@ -96,7 +104,7 @@ def lib():
     L.nmo_run.restype = C.c_int
     L.nmo_run.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                           C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_void_p, C.c_void_p,
-                          C.POINTER(C.c_uint64), C.c_uint64]
+                          C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p]
     L.nmo_run_timed.restype = C.c_int
     L.nmo_run_timed.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                                 C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -198,16 +206,26 @@ class Chain:
 
 
 def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0, n_threads=1,
-        want_positions=True, want_stats=True):
-    """Many chains on host threads (reference Sampler structure).  Returns positions [draws][chains][dim], stats, steps."""
+        want_positions=True, want_stats=True, vectors=None):
+    """Many chains on host threads (reference Sampler structure).  Returns positions [draws][chains][dim], stats, steps.
+
+    vectors: optional dict that receives the vector-valued statistics, [draws][chains][dim] each (NaN-filled; event
+    rows are written only on the draws where the event happens)."""
     params = np.ascontiguousarray(params, dtype=np.float64)
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     pos = np.empty((n_draws, n_chains, dim)) if want_positions else None
     st = np.zeros((n_draws, n_chains), dtype=STATS_DTYPE) if want_stats else None
     steps = C.c_uint64()
+    dv = None
+    if vectors is not None:
+        dv = DrawVectors()
+        for k in VECTOR_STATS:
+            vectors[k] = np.full((n_draws, n_chains, dim), np.nan)
+            setattr(dv, k, vectors[k].ctypes.data)
     failed = lib().nmo_run(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains, chain_offset,
                            x0, n_draws, pos.ctypes.data if pos is not None else None,
-                           st.ctypes.data if st is not None else None, C.byref(steps), n_threads)
+                           st.ctypes.data if st is not None else None, C.byref(steps), n_threads,
+                           C.byref(dv) if dv is not None else None)
     return pos, st, steps.value, failed
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import nuts_rs_amd as N
 
 STAT_FIELDS_EXACT = ["draw", "chain", "depth", "maxdepth_reached", "diverging", "tuning", "n_steps",
-                     "index_in_trajectory", "transformation_index", "chain_status"]
+                     "index_in_trajectory", "transformation_index", "chain_status", "transformation_update_id"]
 STAT_FIELDS_FLOAT = ["step_size", "step_size_bar", "mean_tree_accept", "mean_tree_accept_sym", "max_energy_error",
                      "logp", "energy", "energy_error", "fisher_distance"]
 
@@ -50,3 +50,13 @@ def assert_bit_exact(pos_g, st_g, pos_o, st_o):
         assert bad.size == 0, f"stat {f} differs first at (draw, chain) = {bad[0]}: gpu {st_g[f][tuple(bad[0])]!r} oracle {st_o[f][tuple(bad[0])]!r}"
     bad = np.argwhere(pos_g.view(np.uint64) != pos_o.view(np.uint64))
     assert bad.size == 0, f"positions differ first at (draw, chain, dim) = {bad[0]}"
+
+
+def assert_vectors_bit_exact(vec_g, vec_o):
+    """Vector-valued statistics: same bits, and the same rows left unwritten (NaN)."""
+    assert set(vec_g) <= set(vec_o)
+    for k, g in vec_g.items():
+        o = vec_o[k]
+        both_nan = np.isnan(g) & np.isnan(o)
+        bad = np.argwhere((g.view(np.uint64) != o.view(np.uint64)) & ~both_nan)
+        assert bad.size == 0, f"{k} differs first at (draw, chain, dim) = {bad[0]}: gpu {g[tuple(bad[0])]!r} oracle {o[tuple(bad[0])]!r}"

@@ -26,13 +26,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/nuts_amd.h but not exported"
     assert set(names) == set(_lib.ABI_SYMBOLS)
-    assert L.nm_abi_version() == 1
+    assert L.nm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     # every field is 8 bytes wide (header contract)
     assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 33
-    assert _lib.STATS_DTYPE.itemsize == 8 * 20
+    assert _lib.STATS_DTYPE.itemsize == 8 * 21
+    assert C.sizeof(_lib.NmDrawOutputs) == 8 * 16
     assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 32
 
 

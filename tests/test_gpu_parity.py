@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import nuts_rs_amd as N
-from helpers import assert_bit_exact, run_engine, run_oracle
+from helpers import assert_bit_exact, assert_vectors_bit_exact, oracle_settings, run_engine, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -232,3 +232,44 @@ def test_k4_eight_schools_posterior():
     assert 2.0 < np.median(tau) < 3.6
     assert abs(pos[..., 2:].mean()) < 0.15 and abs(pos[..., 2:].std() - 1.0) < 0.1      # theta~ close to N(0,1)
     assert st["diverging"].mean() < 0.02
+
+
+VECTOR_CASES = [
+    # (id, settings kwargs, density, dim, n_chains, n_draws, (dims_per_lane, waves_per_chain))
+    ("funnel_divergences", dict(seed=31, num_tune=80), "funnel", 31, 12, 160, (0, 0)),
+    ("low_threshold_iid", dict(seed=32, num_tune=40, max_energy_error=0.25), "iid", 70, 6, 70, (0, 0)),
+    ("schools", dict(seed=33, num_tune=120), "schools", 10, 8, 200, (0, 0)),
+    ("iid_w2", dict(seed=34, num_tune=40, max_energy_error=0.5), "iid", 600, 3, 55, (8, 2)),
+]
+
+
+@pytest.mark.parametrize("case", VECTOR_CASES, ids=[c[0] for c in VECTOR_CASES])
+def test_expanded_draw_vector_statistics_bit_exact(oracle, case):
+    """`expanded_draw` (src/chain.rs:190-204): gradient / transformed point / mass-matrix events / divergence
+    locations, against the oracle's copies of the same reference fields."""
+    _, kw, dens, dim, n_chains, n_draws, (dpl, wpc) = case
+    s = N.DiagNutsSettings(num_chains=n_chains, store_gradient=True, store_unconstrained=True, store_transformed=True,
+                           store_divergences=True, **kw)
+    s.adapt_options.mass_matrix_options.store_mass_matrix = True
+    logp = {"funnel": lambda: N.LogpSpec.funnel(dim), "iid": lambda: N.LogpSpec.iid_normal(dim, 3.0),
+            "schools": N.LogpSpec.eight_schools}[dens]()
+    x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
+    b = N.ChainBatch(s, logp, n_chains, dims_per_lane=dpl, waves_per_chain=wpc)
+    assert sorted(b.stored_vectors()) == sorted(N.VECTOR_STATS)
+    b.set_position(x0)
+    pos_g, st_g, vec_g = b.expanded_draw_many(n_draws)
+    tpc = b.threads_per_chain()
+    b.close()
+    vec_o = {}
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc),
+                                        n_chains, x0, n_draws, n_threads=8, vectors=vec_o)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    assert_vectors_bit_exact(vec_g, vec_o)
+    # the events really occur in these cases, and only their rows are written
+    div = st_g["diverging"] != 0
+    upd = st_g["transformation_update_id"] >= 0
+    assert div.sum() > 0 and upd.sum() > n_chains
+    assert (np.isnan(vec_g["divergence_start"]).all(axis=2) == ~div).all()
+    assert (np.isnan(vec_g["mass_matrix_inv"]).all(axis=2) == ~upd).all()
+    assert upd[0].all() and not upd[-1].any()                    # first extraction compares with -1; none after tuning

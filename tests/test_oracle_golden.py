@@ -305,3 +305,48 @@ def test_other_densities_gradients(oracle):
             oracle.lib().nmo_logp(C.byref(cfg), kind, dim, p, len(p), xp, gg, C.byref(lpp))
             oracle.lib().nmo_logp(C.byref(cfg), kind, dim, p, len(p), xm, gg, C.byref(lpm))
             assert abs((lpp.value - lpm.value) / (2 * h) - g[i]) < 1e-5 * max(1.0, abs(g[i]))
+
+
+def test_expanded_draw_vector_statistics(oracle):
+    """The vector-valued statistics of `expanded_draw` (reference src/chain.rs:190-204 and the three extract_stats
+    it flattens): what each row must contain follows from the reference's definitions."""
+    O = oracle
+    dim, n_chains, n_draws = 7, 6, 140
+    s = O.default_settings(num_tune=80, seed=3)
+    x0 = O.init_positions_uniform(3, 0, n_chains, dim)
+    vec = {}
+    cfg, par = O.ref_cfg(), np.zeros(1)
+    pos, st, _, failed = O.run(s, O.LOGP_FUNNEL, dim, par, cfg, n_chains, x0, n_draws, vectors=vec)
+    assert failed == 0
+
+    def grad(x):
+        g, lp = np.empty(dim), C.c_double()
+        assert O.lib().nmo_logp(C.byref(cfg), O.LOGP_FUNNEL, dim, par, len(par), np.ascontiguousarray(x), g, C.byref(lp)) == 0
+        return g
+    # PointStats: gradient is the density's gradient at the draw; z, g_z are the whitened point under the
+    # transformation the point was produced with (transformation_index)
+    for t, c in [(5, 0), (60, 3), (139, 5)]:
+        assert (vec["gradient"][t, c] == grad(pos[t, c])).all()
+    # DiagMassMatrixStats: an event exactly when the version moved; first draw compares with -1
+    upd = st["transformation_update_id"]
+    assert (upd[0] >= 0).all() and (upd[-1] == -1).all()
+    for c in range(n_chains):
+        ids = upd[:, c][upd[:, c] >= 0]
+        assert (np.diff(ids) > 0).all()                                        # strictly increasing versions
+        rows = upd[:, c] >= 0
+        assert (np.isnan(vec["mass_matrix_inv"][:, c]).all(axis=1) == ~rows).all()
+        assert (np.isnan(vec["transformation_mu"][:, c]).all(axis=1) == ~rows).all()
+        # after warm-up: z = (x - mu) / sigma with the last stored event
+        last = np.flatnonzero(rows)[-1]
+        sig, mu = vec["mass_matrix_inv"][last, c], vec["transformation_mu"][last, c]
+        z = (pos[-1, c] - mu) / sig
+        assert np.allclose(vec["transformed_position"][-1, c], z, rtol=1e-12, atol=1e-12)
+        assert np.allclose(vec["transformed_gradient"][-1, c], vec["gradient"][-1, c] * sig, rtol=1e-14)
+    # DivergenceStats: rows only on diverging draws; start/end are one leapfrog apart
+    div = st["diverging"] != 0
+    assert div.sum() > 0
+    assert (np.isnan(vec["divergence_start"]).all(axis=2) == ~div).all()
+    assert (np.isnan(vec["divergence_end"]).all(axis=2) == ~div).all()
+    t, c = np.argwhere(div)[0]
+    assert (vec["divergence_start_gradient"][t, c] == grad(vec["divergence_start"][t, c])).all()
+    assert not (vec["divergence_start"][t, c] == vec["divergence_end"][t, c]).all()
