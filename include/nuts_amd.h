@@ -93,10 +93,15 @@ typedef struct nm_settings {
     double   da_t0;                          /* 10 */
     double   da_gamma;                       /* 0.05 */
     double   da_max_step_size;               /* pi */
+    /* adapt_options.step_size_settings.adapt_options.adam: AdamOptions (src/stepsize/adam.rs:12-34) */
+    double   adam_beta1;                     /* 0.9 */
+    double   adam_beta2;                     /* 0.999 */
+    double   adam_epsilon;                   /* 1e-8 */
+    double   adam_learning_rate;             /* 0.05 */
 } nm_settings;
 
 #define NM_STEP_DUAL_AVERAGE 0
-#define NM_STEP_ADAM 1      /* reference src/stepsize/adam.rs — NM_ERR_UNSUPPORTED */
+#define NM_STEP_ADAM 1      /* reference src/stepsize/adam.rs:42-112 */
 #define NM_STEP_FIXED 2
 
 /* Fill `s` with `DiagNutsSettings::default()` (reference src/sampler.rs:630-634). */

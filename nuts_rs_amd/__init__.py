@@ -5,11 +5,11 @@ The compute path is hand-written HIP for gfx950 in csrc/ exposed through the C A
 Importing the package does not need a GPU; creating a ChainBatch does (there is no CPU fallback).
 """
 from ._lib import NutsAmdError, STATS_DTYPE, VECTOR_STATS, load as load_library  # noqa: F401
-from .sampler import (ChainBatch, DiagAdaptExpSettings, DiagNutsSettings, DualAverageOptions,  # noqa: F401
+from .sampler import (AdamOptions, ChainBatch, DiagAdaptExpSettings, DiagNutsSettings, DualAverageOptions,  # noqa: F401
                       EuclideanAdaptOptions, LogpSpec, Progress, StepSizeSettings, sample,
                       LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS,
                       STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED)
 
-__all__ = ["ChainBatch", "DiagNutsSettings", "EuclideanAdaptOptions", "StepSizeSettings", "DualAverageOptions",
+__all__ = ["AdamOptions", "ChainBatch", "DiagNutsSettings", "EuclideanAdaptOptions", "StepSizeSettings", "DualAverageOptions",
            "DiagAdaptExpSettings", "LogpSpec", "Progress", "sample", "NutsAmdError", "STATS_DTYPE", "VECTOR_STATS",
            "load_library"]

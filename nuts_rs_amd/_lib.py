@@ -43,6 +43,8 @@ class NmSettings(C.Structure):
         ("target_accept", C.c_double), ("initial_step", C.c_double), ("has_jitter", C.c_uint64),
         ("jitter", C.c_double), ("step_size_method", C.c_uint64), ("fixed_step_size", C.c_double),
         ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
+        ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
+        ("adam_learning_rate", C.c_double),
     ]
 
 

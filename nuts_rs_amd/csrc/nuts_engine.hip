@@ -127,6 +127,7 @@ extern "C" void nm_settings_default(nm_settings* s) {
     s->target_accept = 0.8; s->initial_step = 0.1; s->has_jitter = 1; s->jitter = 0.1;
     s->step_size_method = NM_STEP_DUAL_AVERAGE; s->fixed_step_size = 0.0;
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
+    s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;
 }
 extern "C" void nm_engine_config_default(nm_engine_config* c) {
     memset(c, 0, sizeof *c);
@@ -244,8 +245,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (n_chains == 0) return fail(NM_ERR_INVALID_ARG, "n_chains must be > 0");
     const nm_settings& s = *settings;
     if (s.maxdepth > (uint64_t)MAX_MAXDEPTH) return fail(NM_ERR_UNSUPPORTED, "maxdepth %llu > %d", (unsigned long long)s.maxdepth, MAX_MAXDEPTH);
-    if (s.step_size_method == NM_STEP_ADAM) return fail(NM_ERR_UNSUPPORTED, "Adam step-size adaptation is not implemented (reference src/stepsize/adam.rs)");
-    if (s.step_size_method != NM_STEP_DUAL_AVERAGE && s.step_size_method != NM_STEP_FIXED) return fail(NM_ERR_INVALID_ARG, "unknown step_size_method");
+    if (s.step_size_method > NM_STEP_FIXED) return fail(NM_ERR_INVALID_ARG, "step_size_method %llu is not one of NM_STEP_*", (unsigned long long)s.step_size_method);
     // GlobalStrategy::new asserts (adapt_strategy.rs:83-84)
     const double num_tune_f = (double)s.num_tune;
     const uint64_t step_size_window = (uint64_t)(s.step_size_window * num_tune_f);

@@ -84,6 +84,9 @@ struct ChainScalars {
     // DualAverage (dual_avg.rs:34-41)
     double log_step, log_step_adapted, hbar, mu;
     uint64_t da_count;
+    // Adam (stepsize/adam.rs:42-53); its log_step shares `log_step` above
+    double adam_m, adam_v;
+    uint64_t adam_t;
     // stepsize::Strategy last_* (stepsize/adapt.rs:58-64)
     double last_mean_tree_accept, last_sym_mean_tree_accept, last_max_energy_error;
     uint64_t last_n_steps;
@@ -597,12 +600,30 @@ NM_DEV double sum_ln_tile(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& t) {
 }
 
 
-NM_DEV void dual_average_reset(ChainScalars& sc, double initial_step) {   // DualAverage::new dual_avg.rs:44-53
+// DualAverage::new (dual_avg.rs:44-53) or Adam::new (adam.rs:56-64), as stepsize::Strategy::{new, init} pick them
+NM_DEV void stepsize_adapt_reset(ChainScalars& sc, const nm_settings& s, double initial_step) {
     sc.log_step = ulog(initial_step);
-    sc.log_step_adapted = ulog(initial_step);
+    if (s.step_size_method == NM_STEP_ADAM) {
+        sc.adam_m = 0.; sc.adam_v = 0.; sc.adam_t = 0;
+        return;
+    }
+    sc.log_step_adapted = sc.log_step;
     sc.hbar = 0.;
     sc.mu = ulog(10. * initial_step);
     sc.da_count = 1;
+}
+
+// f64::powi = compiler-builtins' __powidf2: square-and-multiply from the low bit of the exponent
+NM_DEV double powi_rs(double a, int32_t b) {
+    uint32_t pw = b < 0 ? 0u - (uint32_t)b : (uint32_t)b;
+    double mul = 1.0;
+    for (;;) {
+        if (pw & 1u) mul *= a;
+        pw >>= 1;
+        if (pw == 0) break;
+        a *= a;
+    }
+    return b < 0 ? 1.0 / mul : mul;
 }
 
 // Hamiltonian::init_state at x with the current mass matrix (reference transformed_hamiltonian.rs:640-661,
@@ -659,10 +680,10 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
         const double accept = col.mean();
         if (it == 0) { dir = accept > s.target_accept ? 1 : -1; continue; }
         if (dir > 0) {
-            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { dual_average_reset(C.sc, C.sc.step_size); return NM_CHAIN_OK; }
+            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
             C.sc.step_size *= 2.;
         } else {
-            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { dual_average_reset(C.sc, C.sc.step_size); return NM_CHAIN_OK; }
+            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
             C.sc.step_size /= 2.;
         }
     }
@@ -675,7 +696,8 @@ template <int DPL, int W, class Dens>
 NM_DEV void update_stepsize(ChainCtx<DPL, W, Dens>& C, bool use_best_guess) {
     const nm_settings& s = C.P.s;
     double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
-                                                      : (use_best_guess ? uexp(C.sc.log_step_adapted) : uexp(C.sc.log_step));
+                : s.step_size_method == NM_STEP_ADAM ? uexp(C.sc.log_step)          // Adam has no averaged iterate
+                : (use_best_guess ? uexp(C.sc.log_step_adapted) : uexp(C.sc.log_step));
     if (s.has_jitter) {
         double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
         double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
@@ -684,13 +706,23 @@ NM_DEV void update_stepsize(ChainCtx<DPL, W, Dens>& C, bool use_best_guess) {
         C.sc.step_size = step;
     }
 }
-// DualAverage::advance (reference src/stepsize/dual_avg.rs:55-64)
+// DualAverage::advance (reference src/stepsize/dual_avg.rs:55-64) / Adam::advance
 template <int DPL, int W, class Dens>
 NM_DEV void update_estimator(ChainCtx<DPL, W, Dens>& C, bool late) {
     const nm_settings& s = C.P.s;
     if (s.step_size_method == NM_STEP_FIXED) return;
     ChainScalars& sc = C.sc;
     const double accept_stat = late ? sc.last_sym_mean_tree_accept : sc.last_mean_tree_accept;
+    if (s.step_size_method == NM_STEP_ADAM) {                    // Adam::advance (stepsize/adam.rs:70-98)
+        const double gradient = accept_stat - s.target_accept;
+        sc.adam_t += 1;
+        sc.adam_m = s.adam_beta1 * sc.adam_m + (1.0 - s.adam_beta1) * gradient;
+        sc.adam_v = s.adam_beta2 * sc.adam_v + (1.0 - s.adam_beta2) * gradient * gradient;
+        const double m_hat = sc.adam_m / (1.0 - powi_rs(s.adam_beta1, (int32_t)sc.adam_t));
+        const double v_hat = sc.adam_v / (1.0 - powi_rs(s.adam_beta2, (int32_t)sc.adam_t));
+        sc.log_step += s.adam_learning_rate * m_hat / (__builtin_sqrt(v_hat) + s.adam_epsilon);
+        return;
+    }
     const double w = 1. / ((double)sc.da_count + s.da_t0);
     sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
     sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
@@ -1373,7 +1405,8 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
     out.index_in_trajectory = idx; out.transformation_index = trans_id;
     out.step_size = sc.step_size;
-    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size : uexp(sc.log_step_adapted);
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size
+                      : P.s.step_size_method == NM_STEP_ADAM ? uexp(sc.log_step) : uexp(sc.log_step_adapted);
     out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
     out.max_energy_error = sc.last_max_energy_error;
     out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
@@ -1425,7 +1458,7 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
-        dual_average_reset(sc, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
+        stepsize_adapt_reset(sc, P.s, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
         Tile<DPL> x, gx;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {

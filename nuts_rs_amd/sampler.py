@@ -32,6 +32,14 @@ class DualAverageOptions:          # src/stepsize/dual_avg.rs:12-31
 
 
 @dataclass
+class AdamOptions:                 # src/stepsize/adam.rs:12-34
+    beta1: float = 0.9
+    beta2: float = 0.999
+    epsilon: float = 1e-8
+    learning_rate: float = 0.05
+
+
+@dataclass
 class StepSizeSettings:            # src/stepsize/adapt.rs:308-329
     target_accept: float = 0.8
     initial_step: float = 0.1
@@ -39,6 +47,7 @@ class StepSizeSettings:            # src/stepsize/adapt.rs:308-329
     method: int = STEP_DUAL_AVERAGE          # StepSizeAdaptMethod::{DualAverage, Adam, Fixed(f64)}
     fixed_step_size: float = 0.0
     dual_average: DualAverageOptions = field(default_factory=DualAverageOptions)
+    adam: AdamOptions = field(default_factory=AdamOptions)
 
 
 @dataclass
@@ -101,6 +110,8 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
         s.step_size_method, s.fixed_step_size = st.method, st.fixed_step_size
         s.da_k, s.da_t0, s.da_gamma = st.dual_average.k, st.dual_average.t0, st.dual_average.gamma
         s.da_max_step_size = st.dual_average.max_step_size
+        s.adam_beta1, s.adam_beta2 = st.adam.beta1, st.adam.beta2
+        s.adam_epsilon, s.adam_learning_rate = st.adam.epsilon, st.adam.learning_rate
         return s
 
 

@@ -40,6 +40,7 @@ struct Settings {
     uint64_t step_size_method;
     double fixed_step_size;
     double da_k, da_t0, da_gamma, da_max_step_size;
+    double adam_beta1, adam_beta2, adam_epsilon, adam_learning_rate;
 };
 
 struct DrawStats {   // same field order as nm_draw_stats
@@ -563,6 +564,35 @@ struct DualAverage {       // reference src/stepsize/dual_avg.rs:34-81
     }
 };
 
+// f64::powi: the llvm.powi intrinsic is lowered to compiler-builtins' __powidf2 (square-and-multiply from the low bit)
+static inline double powi(double a, int32_t b) {
+    uint32_t pw = b < 0 ? 0u - (uint32_t)b : (uint32_t)b;
+    double mul = 1.0;
+    for (;;) {
+        if (pw & 1u) mul *= a;
+        pw >>= 1;
+        if (pw == 0) break;
+        a *= a;
+    }
+    return b < 0 ? 1.0 / mul : mul;
+}
+
+struct Adam {              // reference src/stepsize/adam.rs:42-112
+    double log_step = 0, m1 = 0, v = 0;
+    uint64_t t = 0;
+    double beta1, beta2, epsilon, learning_rate;
+    void reset(const Ctx& m, double initial_step) { log_step = m.ln(initial_step); m1 = 0.; v = 0.; t = 0; }
+    void advance(double accept_stat, double target) {
+        const double gradient = accept_stat - target;
+        t += 1;
+        m1 = beta1 * m1 + (1.0 - beta1) * gradient;
+        v = beta2 * v + (1.0 - beta2) * gradient * gradient;
+        const double m_hat = m1 / (1.0 - powi(beta1, (int32_t)t));
+        const double v_hat = v / (1.0 - powi(beta2, (int32_t)t));
+        log_step += learning_rate * m_hat / (std::sqrt(v_hat) + epsilon);
+    }
+};
+
 struct Chain {
     Ctx m;
     Density dens;
@@ -582,6 +612,7 @@ struct Chain {
     RunningVariance var_draw, var_grad, var_draw_bg, var_grad_bg;
     // stepsize::Strategy (stepsize/adapt.rs:52-65)
     DualAverage da;
+    Adam adam;
     double last_mean_tree_accept = 0, last_sym_mean_tree_accept = 0, last_max_energy_error = 0;
     uint64_t last_n_steps = 0;
     int64_t stats_last_id = -1;
@@ -602,10 +633,15 @@ struct Chain {
         current_window_size = s.mass_matrix_switch_freq;
         da.k = s.da_k; da.t0 = s.da_t0; da.gamma = s.da_gamma; da.max_step_size = s.da_max_step_size;
         da.reset(m, s.initial_step);                                            // stepsize/adapt.rs:69-72
+        adam.beta1 = s.adam_beta1; adam.beta2 = s.adam_beta2; adam.epsilon = s.adam_epsilon;
+        adam.learning_rate = s.adam_learning_rate;
+        adam.reset(m, s.initial_step);
     }
     Chain(const Chain&) = delete;
 
     bool is_fixed() const { return s.step_size_method == 2; }
+    bool is_adam() const { return s.step_size_method == 1; }
+    void adapt_reset(double step) { if (is_adam()) adam.reset(m, step); else da.reset(m, step); }
 
     // stepsize::Strategy::init  stepsize/adapt.rs:91-199
     int stepsize_init(const double* position) {
@@ -629,10 +665,10 @@ struct Chain {
             if (r2.kind != LF_OK) { h.step_size = s.initial_step; return ST_OK; }
             double a = c2.mean();
             if (dir > 0) {
-                if ((a <= s.target_accept) | (h.step_size > 1e5)) { da.reset(m, h.step_size); return ST_OK; }
+                if ((a <= s.target_accept) | (h.step_size > 1e5)) { adapt_reset(h.step_size); return ST_OK; }
                 h.step_size *= 2.;
             } else {
-                if ((a >= s.target_accept) | (h.step_size < 1e-10)) { da.reset(m, h.step_size); return ST_OK; }
+                if ((a >= s.target_accept) | (h.step_size < 1e-10)) { adapt_reset(h.step_size); return ST_OK; }
                 h.step_size /= 2.;
             }
         }
@@ -643,7 +679,8 @@ struct Chain {
     // update_stepsize stepsize/adapt.rs:235-267
     void update_stepsize(bool use_best_guess) {
         double step = is_fixed() ? s.fixed_step_size
-                                 : (use_best_guess ? m.exp(da.log_step_adapted) : m.exp(da.log_step));
+                      : is_adam() ? m.exp(adam.log_step)
+                                  : (use_best_guess ? m.exp(da.log_step_adapted) : m.exp(da.log_step));
         if (s.has_jitter) {
             UniformF64 u = UniformF64::make(1.0 - s.jitter, 1.0 + s.jitter);
             double j = u.sample(rng);
@@ -652,7 +689,9 @@ struct Chain {
     }
     void update_estimator(bool late) {
         if (is_fixed()) return;
-        da.advance(m, late ? last_sym_mean_tree_accept : last_mean_tree_accept, s.target_accept);
+        const double accept_stat = late ? last_sym_mean_tree_accept : last_mean_tree_accept;
+        if (is_adam()) adam.advance(accept_stat, s.target_accept);
+        else da.advance(m, accept_stat, s.target_accept);
     }
 
     // NutsChain::set_position chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119
@@ -742,7 +781,7 @@ struct Chain {
             o.diverging = info.divergence.present; o.tuning = tuning; o.n_steps = last_n_steps;
             o.index_in_trajectory = chosen->index_in_trajectory; o.transformation_index = chosen->transform_id;
             o.step_size = h.step_size;
-            o.step_size_bar = is_fixed() ? s.fixed_step_size : m.exp(da.log_step_adapted);
+            o.step_size_bar = is_fixed() ? s.fixed_step_size : is_adam() ? m.exp(adam.log_step) : m.exp(da.log_step_adapted);
             o.mean_tree_accept = last_mean_tree_accept; o.mean_tree_accept_sym = last_sym_mean_tree_accept;
             o.max_energy_error = last_max_energy_error;
             o.logp = chosen->logp; o.energy = chosen->energy(); o.energy_error = chosen->energy_error();

@@ -25,6 +25,7 @@ void nmo_settings_default(Settings* s) {
     s->target_accept = 0.8; s->initial_step = 0.1; s->has_jitter = 1; s->jitter = 0.1;
     s->step_size_method = 0; s->fixed_step_size = 0.0;
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
+    s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;   // adam.rs:25-33
 }
 uint64_t nmo_settings_size(void) { return sizeof(Settings); }
 uint64_t nmo_draw_stats_size(void) { return sizeof(DrawStats); }
@@ -172,6 +173,16 @@ int nmo_run_timed(const Settings* s, int64_t kind, uint64_t dim, const double* p
     if (out_steps) *out_steps = steps.load();
     if (out_warm_steps) *out_warm_steps = wsteps.load();
     return failed.load();
+}
+
+// Adam::new(initial_step) then advance(accept[i], target): log_step after every advance
+void nmo_adam_sequence(const MathCfg* cfg, double initial_step, const double* accept, uint64_t n, double target,
+                       double beta1, double beta2, double epsilon, double learning_rate, double* out_log_step) {
+    Ctx m{*cfg};
+    Adam a;
+    a.beta1 = beta1; a.beta2 = beta2; a.epsilon = epsilon; a.learning_rate = learning_rate;
+    a.reset(m, initial_step);
+    for (uint64_t i = 0; i < n; ++i) { a.advance(accept[i], target); out_log_step[i] = a.log_step; }
 }
 
 // ----- primitives for known-answer tests ------------------------------------------------------

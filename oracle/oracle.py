@@ -38,6 +38,8 @@ class Settings(C.Structure):
         ("target_accept", C.c_double), ("initial_step", C.c_double), ("has_jitter", C.c_uint64),
         ("jitter", C.c_double), ("step_size_method", C.c_uint64), ("fixed_step_size", C.c_double),
         ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
+        ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
+        ("adam_learning_rate", C.c_double),
     ]
 
 
@@ -105,6 +107,9 @@ def lib():
     L.nmo_run.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                           C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p]
+    L.nmo_adam_sequence.restype = None
+    L.nmo_adam_sequence.argtypes = [C.POINTER(MathCfg), C.c_double, C.POINTER(C.c_double), C.c_uint64, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
     L.nmo_run_timed.restype = C.c_int
     L.nmo_run_timed.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                                 C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -203,6 +208,16 @@ class Chain:
         lib().nmo_chain_get_state(self._h, x.ctypes.data, gx.ctypes.data, sd.ctypes.data, mu.ctypes.data,
                                   C.byref(eps), C.byref(pos))
         return dict(x=x, gx=gx, stds=sd, mean=mu, step_size=eps.value, rng_pos=pos.value)
+
+
+def adam_sequence(initial_step, accept, target, beta1, beta2, epsilon, learning_rate, cfg=None):
+    acc = np.ascontiguousarray(accept, dtype=np.float64)
+    out = np.empty(len(acc))
+    cfg = cfg or ref_cfg()
+    lib().nmo_adam_sequence(C.byref(cfg), C.c_double(initial_step), acc.ctypes.data_as(C.POINTER(C.c_double)), len(acc),
+                            C.c_double(target), C.c_double(beta1), C.c_double(beta2), C.c_double(epsilon),
+                            C.c_double(learning_rate), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
 
 
 def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0, n_threads=1,

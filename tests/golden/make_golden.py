@@ -70,7 +70,7 @@ def reference_kats():
         "max_ulps": 32,
     }
     # reference defaults (src/sampler.rs:507-531,:630-634; src/adapt_strategy.rs:56-69; src/stepsize/adapt.rs:320-329;
-    # src/stepsize/dual_avg.rs:22-31; src/transform/adapt/diagonal.rs:99-106)
+    # src/stepsize/dual_avg.rs:22-31; src/stepsize/adam.rs:25-33; src/transform/adapt/diagonal.rs:99-106)
     k["default_settings"] = {
         "source": "/root/reference/src/sampler.rs:507-531,:630-634 and nested Default impls",
         "num_tune": 400, "num_draws": 1000, "maxdepth": 10, "mindepth": 0, "max_energy_error": 1000.0,
@@ -79,6 +79,7 @@ def reference_kats():
         "mass_matrix_update_freq": 1, "mass_matrix_window_growth": 1.5, "store_mass_matrix": 0,
         "use_grad_based_estimate": 1, "target_accept": 0.8, "initial_step": 0.1, "has_jitter": 1, "jitter": 0.1,
         "step_size_method": 0, "da_k": 0.75, "da_t0": 10.0, "da_gamma": 0.05, "da_max_step_size": 3.141592653589793,
+        "adam_beta1": 0.9, "adam_beta2": 0.999, "adam_epsilon": 1e-8, "adam_learning_rate": 0.05,   # src/stepsize/adam.rs:25-33
     }
     return k
 

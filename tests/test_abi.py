@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # every field is 8 bytes wide (header contract)
-    assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 33
+    assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 37
     assert _lib.STATS_DTYPE.itemsize == 8 * 21
     assert C.sizeof(_lib.NmDrawOutputs) == 8 * 16
     assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 32
@@ -78,8 +78,8 @@ def test_argument_validation():
     s2 = N.DiagNutsSettings(maxdepth=40).to_c()
     assert L.nm_engine_create(C.byref(s2), C.byref(spec), 4, None, C.byref(h)) == 4     # unsupported
     s3 = N.DiagNutsSettings().to_c()
-    s3.step_size_method = N.STEP_ADAM
-    assert L.nm_engine_create(C.byref(s3), C.byref(spec), 4, None, C.byref(h)) == 4
+    s3.step_size_method = 7                                                             # not a StepSizeAdaptMethod
+    assert L.nm_engine_create(C.byref(s3), C.byref(spec), 4, None, C.byref(h)) == 1
     s4 = N.DiagNutsSettings(num_tune=0).to_c()                                          # reference asserts early_end < num_tune
     assert L.nm_engine_create(C.byref(s4), C.byref(spec), 4, None, C.byref(h)) == 1
     assert b"early_end" in L.nm_last_error()

@@ -94,8 +94,10 @@ def test_chain_parity_bit_exact(oracle, case):
 
 
 def test_step_size_options_parity(oracle):
-    """Fixed step size and jitter None (stepsize/adapt.rs:27, :259-266)."""
-    for st_kw in (dict(method=N.STEP_FIXED, fixed_step_size=0.4), dict(jitter=None), dict(target_accept=0.95)):
+    """Fixed step size, jitter None (stepsize/adapt.rs:27, :259-266) and the Adam adaptor (stepsize/adam.rs:42-112)."""
+    for st_kw in (dict(method=N.STEP_FIXED, fixed_step_size=0.4), dict(jitter=None), dict(target_accept=0.95),
+                  dict(method=N.STEP_ADAM), dict(method=N.STEP_ADAM, jitter=None,
+                                                 adam=N.AdamOptions(beta1=0.8, beta2=0.99, learning_rate=0.1))):
         a = N.EuclideanAdaptOptions(step_size_settings=N.StepSizeSettings(**st_kw))
         s = N.DiagNutsSettings(num_chains=3, seed=21, num_tune=60, adapt_options=a)
         logp = N.LogpSpec.iid_normal(16, 3.0)

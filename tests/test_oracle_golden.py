@@ -350,3 +350,30 @@ def test_expanded_draw_vector_statistics(oracle):
     t, c = np.argwhere(div)[0]
     assert (vec["divergence_start_gradient"][t, c] == grad(vec["divergence_start"][t, c])).all()
     assert not (vec["divergence_start"][t, c] == vec["divergence_end"][t, c]).all()
+
+
+def test_adam_step_size_adaptation(oracle):
+    """Adam adaptor (reference src/stepsize/adam.rs:42-112): the update formula on a hand-computed sequence, and the
+    sampler converging with it (the reference has no dedicated test; the envelope is adapt_strategy.rs:367-435's)."""
+    O = oracle
+    # closed form of the first step: m_hat = g, v_hat = g^2  =>  log_step += lr * g / (|g| + eps)
+    b1, b2, eps, lr, target = 0.9, 0.999, 1e-8, 0.05, 0.8
+    log_step, m, v = np.log(0.1), 0.0, 0.0
+    expect = []
+    for t, acc in enumerate([0.95, 0.6, 0.81, 0.2], start=1):
+        g = acc - target
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        log_step += lr * (m / (1 - b1 ** t)) / (np.sqrt(v / (1 - b2 ** t)) + eps)
+        expect.append(log_step)
+    got = O.adam_sequence(0.1, [0.95, 0.6, 0.81, 0.2], target, b1, b2, eps, lr)
+    assert np.allclose(got, expect, rtol=1e-14)
+    assert abs(got[0] - (np.log(0.1) + lr * 0.15 / (0.15 + eps))) < 1e-15
+    s = O.default_settings(num_tune=300, seed=5, step_size_method=1)
+    x0 = O.init_positions_uniform(5, 0, 4, 10)
+    pos, st, _, failed = O.run(s, O.LOGP_IID_NORMAL, 10, [3.0], O.ref_cfg(), 4, x0, 500)
+    assert failed == 0 and st["diverging"][300:].sum() == 0
+    assert abs(pos[300:].mean() - 3.0) < 0.15
+    acc = st["mean_tree_accept"][200:300].mean()
+    assert 0.6 < acc < 0.95                                   # moved the step size toward target_accept = 0.8
+    assert (st["step_size_bar"][-1] > 0.2).all()              # from initial_step 0.1 up to the O(1) scale of N(3, 1)
