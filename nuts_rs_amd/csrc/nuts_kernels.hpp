@@ -1428,8 +1428,19 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
 // ---------------------------------------------------------------------------------------------
 // kernels: one block = one wave; a wave strides over the chains
 // ---------------------------------------------------------------------------------------------
+// Minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument): the small
+// tilings are latency-bound with few lanes busy, so more resident chains per CU beat a spill-free allocation there.
+#ifndef NM_OCC_DPL2
+#define NM_OCC_DPL2 4    // <= 128 VGPRs: K4 +17 %, K3 +6 % (tools/bench_configs.py); DPL 4 at 3 waves: no gain
+#endif
+#ifndef NM_OCC_DPL4
+#define NM_OCC_DPL4 1
+#endif
+template <int DPL, int W>
+constexpr int draw_min_waves() { return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DPL == 4 ? NM_OCC_DPL4 : 1; }
+
 template <int DPL, int W, class Dens>
-__global__ __launch_bounds__(64 * W) void nuts_draw_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W> sh;
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
