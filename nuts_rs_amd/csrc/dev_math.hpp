@@ -282,18 +282,21 @@ struct DevRng {
     const uint32_t* key;   // 8 words (LDS)
     uint64_t pos;      // next u32 word of the stream
     uint64_t base;     // stream position of cache word 0 (multiple of 16)
-    uint32_t* cache;   // LDS, RNG_CACHE_WORDS words, private to this wave
+    uint32_t* cache;   // LDS, at least RNG_CACHE_WORDS words
+    uint32_t cap;      // valid words in the cache (RNG_CACHE_WORDS after a refill; more while a bulk fill lends its buffer)
 
     NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* lds) {
         key = k;
         pos = p;
         base = p + 16;   // invalid: forces a refill on first use
         cache = lds;
+        cap = RNG_CACHE_WORDS;
     }
-    NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)RNG_CACHE_WORDS; }
+    NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)cap; }
     NM_DEV void refill() {
         __syncthreads();
         base = pos & ~15ull;
+        cap = RNG_CACHE_WORDS;
         if (tid() < RNG_CACHE_WORDS / 16) {
             uint32_t out[16];
             chacha8_block(key, (base >> 4) + (uint64_t)tid(), 0ull, out);
@@ -383,6 +386,216 @@ NM_DEV void fill_standard_normals(DevRng& rng, double* stage, int count, ZigTabl
         }
     }
     __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bulk variant for the momentum refresh.  Everything the stream consumes inside `array_gaussian` is a whole u64, so
+// from the start position the stream is a fixed grid of u64 "cells"; each cell is either the fast-path candidate of
+// one sample or is swallowed by the slow path of an earlier failing cell.  Instead of re-aligning 64 lanes after every
+// rejection (a chain of ~28 dependent passes for 1024 samples), one chunk does
+//   1. all ChaCha blocks of up to 64*P cells into LDS (all threads),
+//   2. the fast-path test of every cell, P independent passes (table gathers all in flight), x kept in registers,
+//      rejection masks by ballot,
+//   3. a wave-uniform walk over the ~1.2 % rejected cells in stream order: the slow path of each (reading the stream
+//      through the same LDS words) tells how many cells it swallowed,
+//   4. a scatter of every surviving x to its sample index (cell index minus the cells swallowed before it).
+// Sample values and the final stream position are those of the sequential algorithm, bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ZIG_FMAX = 64;      // slow-path events handled per chunk (a chunk that meets more simply ends early)
+NM_DEV int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// small wave-uniform tables kept one entry per lane (a VGPR read with a scalar lane index costs a few cycles; the
+// same table in LDS would put a ~100-cycle round trip into every step of the scalar walk)
+NM_DEV int lane_get(int v, int idx) { return __builtin_amdgcn_readlane(v, idx); }
+NM_DEV double lane_get_f64(double v, int idx) {
+    const uint64_t b = d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, idx);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), idx);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+
+// `count` StandardNormal variates in stream order into samp[0..count) (LDS).  wbuf: LDS, 128*P + 16 words; P <= 64.
+#ifndef NM_PROF
+#define NM_PROF 0
+#endif
+#if NM_PROF
+#define NM_MARK_F(slot)                                                           \
+    {                                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) prof[slot] += now_ - prof_t;     \
+        prof_t = now_;                                                            \
+    }
+#else
+#define NM_MARK_F(slot)
+#endif
+template <int P>
+NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp, int count, ZigTables T, int nthreads,
+                                       unsigned long long* prof, unsigned long long& prof_t) {
+    static_assert(P <= 64, "rejection masks are kept one per lane");
+    const int lane = lane_id();
+    uint32_t* const small_cache = rng.cache;
+    int produced = 0;
+    __syncthreads();
+    while (produced < count) {
+        const int need = count - produced;
+        int nc = (need + 8 + 63) & ~63;                       // cells of this chunk: a few more than samples wanted
+        if (nc > 64 * P) nc = 64 * P;
+        const uint64_t pos0 = rng.pos;
+        const uint64_t b0 = pos0 >> 4;
+        const int nb = (int)(((pos0 + 2ull * (uint64_t)nc - 1ull) >> 4) - b0) + 1;
+        for (int b = tid(); b < nb; b += nthreads) {          // 1. the words of all cells
+            uint32_t out[16];
+            chacha8_block(rng.key, b0 + (uint64_t)b, 0ull, out);
+            uint4* dst = reinterpret_cast<uint4*>(wbuf + b * 16);
+            dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+            dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+            dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+        }
+        __syncthreads();
+        NM_MARK_F(8)
+        rng.cache = wbuf; rng.base = b0 << 4; rng.cap = (uint32_t)nb * 16u;     // the slow path reads the same words
+        const int w0 = (int)(pos0 - rng.base);
+        // 2. fast-path test of every cell.  No branch between the passes (cells past nc hold stale words: tested,
+        // ignored), so all table gathers are in flight together.  Lane p keeps the rejection mask of pass p.
+        double xr[P];
+        int* const flist = reinterpret_cast<int*>(small_cache);   // rejected cells in stream order (+ 64 dummy slots)
+        int nrej = 0;
+        {
+            uint64_t cb[P];
+            double tx[P], tn[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {                         // all LDS reads, then all table gathers, then the math:
+                const int c = 64 * p + lane;                      // no branch in between, so the loads overlap
+                cb[p] = ((uint64_t)wbuf[w0 + 2 * c + 1] << 32) | wbuf[w0 + 2 * c];
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int zi = (int)(cb[p] & 0xff);
+                tx[p] = T.x[zi];
+                tn[p] = T.x[zi + 1];
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int c = 64 * p + lane;
+                const double u = u2d((cb[p] >> 12) | 0x4000000000000000ull) - 3.0;
+                const double x = u * tx[p];
+                const bool rej = !(__builtin_fabs(x) < tn[p]) && c < nc;
+                xr[p] = x;
+                const uint64_t fail = __ballot(rej);
+                const int rank = nrej + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fail >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)fail, 0u));
+                flist[(rej && rank < ZIG_FMAX) ? rank : ZIG_FMAX + lane] = c;   // unconditional store
+                nrej += (int)__builtin_popcountll(fail);
+            }
+        }
+        // 2b. the slow path of every rejected cell at once, one lane each.  What a rejected cell f yields depends
+        // only on the cells behind it: the wedge test uses cell f+1 (accept: f's own x, 1 cell swallowed); if that
+        // rejects, cell f+2 is the next candidate (fast-path accept: its x, 2 cells swallowed).  Base-layer tails,
+        // a second rejection in a row and cells at the end of the chunk are left to the scalar routine in step 3.
+        const int nlist = nrej < ZIG_FMAX ? nrej : ZIG_FMAX;
+        int fcell, sp_r;
+        double sp_x;
+        bool sp_scalar;
+        {
+            fcell = lane < nlist ? flist[lane] : 0;
+            const int wa = w0 + 2 * fcell;
+            const uint64_t bits0 = ((uint64_t)wbuf[wa + 1] << 32) | wbuf[wa];
+            const uint64_t bits1 = ((uint64_t)wbuf[wa + 3] << 32) | wbuf[wa + 2];
+            const uint64_t bits2 = ((uint64_t)wbuf[wa + 5] << 32) | wbuf[wa + 4];
+            const int i0 = (int)(bits0 & 0xff);
+            const double u0 = u2d((bits0 >> 12) | 0x4000000000000000ull) - 3.0;
+            const double x0 = u0 * T.x[i0];
+            const double u01 = (double)(bits1 >> 11) * (1.0 / 9007199254740992.0);
+            const bool wedge = T.f[i0 + 1] + (T.f[i0] - T.f[i0 + 1]) * u01 < dexp(-x0 * x0 / 2.0);
+            const int i2 = (int)(bits2 & 0xff);
+            const double u2 = u2d((bits2 >> 12) | 0x4000000000000000ull) - 3.0;
+            const double x2 = u2 * T.x[i2];
+            const bool ok2 = __builtin_fabs(x2) < T.x[i2 + 1];
+            sp_r = wedge ? 1 : 2;
+            sp_x = wedge ? x0 : x2;
+            sp_scalar = i0 == 0 || fcell + 2 >= nc || (!wedge && !ok2);
+        }
+        NM_MARK_F(9)
+        NM_MARK_F(12)
+        // 3. walk over the rejected cells in stream order: next unconsumed cell `cur`, samples so far `j`.  Lane q keeps
+        // two 64-bit masks over the cells of pass q: `sw` = swallowed by a slow path, `nk` = swallowed or rejected (no
+        // fast-path sample).  Lane e keeps event e: its sample index and value.
+        int cur = 0, j = 0, nf = 0;
+        uint64_t sw = 0, nk = 0;
+        int flj = 0;
+        double flx = 0.0;
+        bool open = true;
+        const uint64_t scalar_mask = __ballot(sp_scalar);
+        for (int g = 0; g < nlist; ++g) {
+            const int f = lane_get(fcell, g);
+            if (f < cur) continue;                            // swallowed by an earlier slow path
+            if (j + (f - cur) >= need) { cur += need - j; j = need; open = false; break; }
+            j += f - cur;
+            int r;
+            double xs;
+            if ((scalar_mask >> g) & 1ull) {
+                const uint32_t lo = (uint32_t)uniform_i32((int)wbuf[w0 + 2 * f]);
+                const uint32_t hi = (uint32_t)uniform_i32((int)wbuf[w0 + 2 * f + 1]);
+                rng.pos = pos0 + 2ull * (uint64_t)(f + 1);
+                xs = normal_slow_path(rng, ((uint64_t)hi << 32) | lo, T);
+                r = (int)((rng.pos - pos0) >> 1) - (f + 1);
+            } else {
+                r = lane_get(sp_r, g);
+                xs = lane_get_f64(sp_x, g);
+            }
+            // cells [f, f+1+r) give no fast-path sample, [f+1, f+1+r) are swallowed.  The bit ranges are scalar work;
+            // only the update of the owning lane's masks touches vector registers.
+            for (int a = f, end = (f + 1 + r < 64 * P ? f + 1 + r : 64 * P); a < end;) {
+                const int q = a >> 6, off = a & 63;
+                const int take = (end - a) < (64 - off) ? (end - a) : (64 - off);
+                const uint64_t bits = (take >= 64 ? ~0ull : ((1ull << take) - 1ull)) << off;
+                const uint64_t sbits = a == f ? (bits & ~(1ull << off)) : bits;
+                nk |= lane == q ? bits : 0ull;
+                sw |= lane == q ? sbits : 0ull;
+                a += take;
+            }
+            flj = lane == nf ? j : flj;
+            flx = lane == nf ? xs : flx;
+            nf += 1;
+            j += 1;
+            cur = f + 1 + r;
+            if (j >= need || cur >= nc) { open = false; break; }
+        }
+        if (nrej > nlist) open = false;                       // more rejections than list slots: the rest next chunk
+        if (open && cur < nc) {                               // tail after the last event
+            const int take = (nc - cur) < (need - j) ? (nc - cur) : (need - j);
+            j += take; cur += take;
+        }
+        rng.pos = pos0 + 2ull * (uint64_t)cur;
+        NM_MARK_F(10)
+        // 4. scatter, branch-free: a surviving cell's sample index is its index minus the swallowed cells before it;
+        // lanes with nothing to store write to a dummy slot.  Then the slow-path samples, one lane per event.
+        {
+            double* const dummy = reinterpret_cast<double*>(small_cache) + 64 + lane;
+            const int swlo = (int)(uint32_t)sw, swhi = (int)(uint32_t)(sw >> 32);
+            const int nklo = (int)(uint32_t)nk, nkhi = (int)(uint32_t)(nk >> 32);
+            int base = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const uint32_t s_lo = (uint32_t)lane_get(swlo, p), s_hi = (uint32_t)lane_get(swhi, p);
+                const uint64_t n_p = ((uint64_t)(uint32_t)lane_get(nkhi, p) << 32) | (uint32_t)lane_get(nklo, p);
+                const int c = 64 * p + lane;
+                const int below = (int)__builtin_amdgcn_mbcnt_hi(s_hi, __builtin_amdgcn_mbcnt_lo(s_lo, 0u));
+                const bool keep = !((n_p >> lane) & 1ull) && c < cur;
+                double* dst = keep ? samp + (produced + c - base - below) : dummy;
+                *dst = xr[p];
+                base += (int)__builtin_popcount(s_lo) + (int)__builtin_popcount(s_hi);
+            }
+            double* dst = lane < nf ? samp + (produced + flj) : dummy;
+            *dst = flx;
+        }
+        produced += j;
+        __syncthreads();
+        NM_MARK_F(11)
+    }
+    rng.cache = small_cache;
+    rng.base = rng.pos + 16;      // the small cache holds nothing useful any more
+    rng.cap = RNG_CACHE_WORDS;
 }
 
 }  // namespace nm

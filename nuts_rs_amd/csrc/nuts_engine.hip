@@ -209,6 +209,7 @@ struct nm_engine {
     double* d_svec = nullptr;     // [n_waves][nsslot][dpad]
     unsigned n_waves = 0;         // resident waves of the draw kernel = its grid
     ChainScalars* d_sc = nullptr;
+    unsigned long long* d_prof = nullptr;   // 32 cycle counters for NM_PROF builds
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
     double* d_x0 = nullptr;
@@ -225,6 +226,7 @@ static void engine_free(nm_engine* e) {
     if (e->d_pvec) (void)hipFree(e->d_pvec);
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
+    if (e->d_prof) (void)hipFree(e->d_prof);
     if (e->d_zig) (void)hipFree(e->d_zig);
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->d_x0) (void)hipFree(e->d_x0);
@@ -294,6 +296,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMalloc(&e->d_svec, svec_bytes));
     E_TRY(hipMemsetAsync(e->d_svec, 0, svec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_sc, n_chains * sizeof(ChainScalars)));
+    E_TRY(hipMalloc(&e->d_prof, 32 * sizeof(unsigned long long)));
+    E_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
     E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
     E_TRY(hipMalloc(&e->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
@@ -331,7 +335,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     memset(&P, 0, sizeof P);
     P.s = s;
     P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nsslot = nsslot;
-    P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
+    P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.prof = e->d_prof; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
     P.early_end = early_end;
     P.final_step_size_window = s.num_tune >= step_size_window ? s.num_tune - step_size_window : 0;   // saturating_sub
     P.ln_max_step = dlog(s.da_max_step_size);
@@ -472,6 +476,16 @@ extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, doub
     nm_draw_outputs h = {};
     h.d_positions = h_positions; h.d_stats = h_stats;
     return nm_engine_draw_ex_to_host(e, n_draws, &h);
+}
+
+// Development aid (not part of include/nuts_amd.h): cycle counters of NM_PROF builds; reading clears them.
+extern "C" nm_status nm_debug_read_prof(nm_engine* e, unsigned long long out[32]) {
+    if (!e || !out) return fail(NM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out, e->d_prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
+    return NM_OK;
 }
 
 static nm_status read_slot(nm_engine* e, int slot, double* h_out) {

@@ -115,8 +115,24 @@ struct KParams {
     double *out_gradient, *out_tpos, *out_tgrad, *out_mm_inv, *out_mm_mu;
     double *out_div_start, *out_div_start_grad, *out_div_end;
     uint64_t n_draws;
+    unsigned long long* prof;    // NM_PROF builds: cycle counters of block 0 (tools/prof_phases.py)
     const double* x0;            // init kernel: [n_chains][dim]
 };
+
+// Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
+#ifndef NM_PROF
+#define NM_PROF 0
+#endif
+#if NM_PROF
+#define NM_MARK(C, slot)                                                                  \
+    {                                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) (C).P.prof[slot] += now_ - (C).prof_t;   \
+        (C).prof_t = now_;                                                                \
+    }
+#else
+#define NM_MARK(C, slot)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // register tiles
@@ -344,7 +360,9 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     double mu[64 * W * DPL];      // DiagMassMatrix mean
     double red[2 * RED_MAX_VALUES * W];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
-    double l1_v[NM_LDS_L1 ? 64 * W * DPL : 2];    // end point (written every 4th leaf, read two leaves later) never leaves the CU
+    double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
+    // Between trees both arrays are free: the momentum refresh uses l1_v as its ChaCha word buffer (hence the 72
+    // extra doubles: 64 spare cells + one block of alignment) and l1_z as the stream-ordered sample vector.
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
@@ -368,6 +386,7 @@ struct ChainCtx {
     int dim;
     int maxdepth_cfg;
     ChainScalars& sc;   // LDS
+    unsigned long long prof_t;
 
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     rsrc_t rp, rs;      // buffer descriptors of this chain's persistent slots / this block's tree scratch
@@ -564,10 +583,22 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
     t2 = __builtin_fma(s, ve, t2);
 }
 
-// momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577).  The stream-ordered samples are
-// staged through `stage` (a [64*DPL] scratch vector in HBM/L2 owned by this wave) and re-read in tile order.
+// momentum refresh (array_gaussian, reference src/math/cpu_math.rs:561-577).  The stream-ordered samples are produced
+// in LDS (fill_standard_normals_bulk) and read back in tile order; STAGE_V (HBM) keeps a copy because the initial
+// point's velocity is the v of main-tree edge id 0.
 template <int DPL, int W, class Dens>
 NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
+#if NM_LDS_L1
+    fill_standard_normals_bulk<(DPL * W + 1 < 64 ? DPL * W + 1 : 64)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, C.dim, C.zig, 64 * W, C.P.prof, C.prof_t);
+    const double2* s2 = C.tptr(C.l1z);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 q = s2[m * 64 * W];
+        v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+        v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+    }
+    C.storeS(v, STAGE_V);
+#else
     fill_standard_normals(C.rng, C.sslot(STAGE_V), C.dim, C.zig);
     const int so = C.soS(STAGE_V);
 #pragma unroll
@@ -576,6 +607,7 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
         v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
         v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
+#endif
     __syncthreads();
 }
 
@@ -983,7 +1015,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
+    NM_MARK(C, 0)
     sample_velocity(C, E.v);
+    NM_MARK(C, 1)
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
         Tile<DPL> x, gx, isig, sig, mu;
         C.loadP(x, P_X);
@@ -1351,6 +1385,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     DrawResult R;
     Tile<DPL> x, gx, z, gz;
     uint64_t st = nuts_transition(C, col, R, z);
+    NM_MARK(C, 2)
     nm_draw_stats out;
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     if (st != NM_CHAIN_OK) {
@@ -1399,7 +1434,9 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
     const int64_t trans_id = sc.transform_id;
     sc.total_steps += col.count;
+    NM_MARK(C, 3)
     uint64_t ast = adapt(C, col, is_good, x, gx);
+    NM_MARK(C, 4)
     if (ast != NM_CHAIN_OK) sc.status = ast;
     out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
@@ -1421,6 +1458,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
         if (P.out_mm_mu) { C.load(x, C.lmu); write_row(C, P.out_mm_mu, row, x); }
     }
     sc.stats_last_id = sc.mm_id;
+    NM_MARK(C, 5)
     if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
 }
@@ -1451,6 +1489,9 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
                 C.loadP(t, P_SIG); C.store(t, C.lsig);
                 C.loadP(t, P_MU); C.store(t, C.lmu);
             }
+#if NM_PROF
+            C.prof_t = __builtin_amdgcn_s_memtime();
+#endif
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
                 if (C.sc.status != NM_CHAIN_OK) break;

@@ -1,0 +1,52 @@
+"""Phase breakdown of one draw on one block (needs a build with -DNM_PROF=1; see NM_MARK in nuts_kernels.hpp).
+
+  python tools/prof_phases.py [chains] [dim] [tune] [draws]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401  (its HIP runtime must initialise first)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nuts_rs_amd as N  # noqa: E402
+from nuts_rs_amd import _lib  # noqa: E402
+
+NAMES = {0: "between draws (store stats, loop)", 1: "momentum refresh", 2: "tree (all doublings)",
+         3: "winner x / g_x / stores / fisher", 4: "adapt", 5: "stats + mass-matrix event",
+         8: " refresh: ChaCha words -> LDS", 9: " refresh: fast-path tests", 10: " refresh: walk", 12: " refresh: parallel slow paths",
+         11: " refresh: scatter + barrier"}
+
+
+def main():
+    chains = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    dim = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    tune = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+    draws = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+    s = N.DiagNutsSettings(num_chains=chains, seed=20260928, num_tune=tune, num_draws=draws)
+    b = N.ChainBatch(s, N.LogpSpec.iid_normal(dim, 3.0), chains)
+    b.set_position(b.init_positions_uniform())
+    L = _lib.load()
+    L.nm_debug_read_prof.argtypes = [C.c_void_p, C.c_void_p]
+    buf = np.zeros(32, dtype=np.uint64)
+    b.draw_device(tune)
+    L.nm_debug_read_prof(b._h, buf.ctypes.data)
+    b.reset_counters()
+    b.draw_device(draws)
+    c = b.counters()
+    L.nm_debug_read_prof(b._h, buf.ctypes.data)
+    nblk_chains = -(-chains // 1024) if chains > 1024 else 1          # chains block 0 handled (grid = resident blocks)
+    ndraw = draws * nblk_chains
+    total = buf.sum()
+    ms = c["kernel_ms"]
+    cyc_per_us = total / (ms * 1e3)                                   # block 0 is busy for the whole launch
+    print(f"kernel {ms:.2f} ms, block 0: {ndraw} draws, {total} cycles -> {cyc_per_us:.0f} cycles/us")
+    for k in range(32):
+        if buf[k]:
+            print(f"  [{k}] {NAMES.get(k, '?'):40s} {buf[k] / ndraw / cyc_per_us:8.2f} us/draw  ({100.0 * buf[k] / total:5.1f} %)")
+    print("steps/draw", c["total_leapfrogs"] / draws / chains)
+
+
+if __name__ == "__main__":
+    main()
