@@ -421,7 +421,7 @@ NM_DEV double lane_get_f64(double v, int idx) {
 #define NM_MARK_F(slot)                                                           \
     {                                                                             \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
-        if (blockIdx.x == 0 && threadIdx.x == 0) prof[slot] += now_ - prof_t;     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) (void)__hip_atomic_fetch_add(&prof[slot], now_ - prof_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
         prof_t = now_;                                                            \
     }
 #else
@@ -437,7 +437,8 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
     __syncthreads();
     while (produced < count) {
         const int need = count - produced;
-        int nc = (need + 8 + 63) & ~63;                       // cells of this chunk: a few more than samples wanted
+        // cells of this chunk: the samples wanted plus room for the cells the slow paths will swallow (~2 % of them)
+        int nc = need + ((need >> 4) > 8 ? (need >> 4) : 8);
         if (nc > 64 * P) nc = 64 * P;
         const uint64_t pos0 = rng.pos;
         const uint64_t b0 = pos0 >> 4;
@@ -496,7 +497,8 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
         int fcell, sp_r;
         double sp_x;
         bool sp_scalar;
-        {
+        fcell = 0; sp_r = 0; sp_x = 0.0; sp_scalar = false;
+        if (nlist > 0) {
             fcell = lane < nlist ? flist[lane] : 0;
             const int wa = w0 + 2 * fcell;
             const uint64_t bits0 = ((uint64_t)wbuf[wa + 1] << 32) | wbuf[wa];
@@ -593,9 +595,26 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
         __syncthreads();
         NM_MARK_F(11)
     }
-    rng.cache = small_cache;
-    rng.base = rng.pos + 16;      // the small cache holds nothing useful any more
-    rng.cap = RNG_CACHE_WORDS;
+    // Hand the already generated words behind the final position to the small cache: the tree's direction bits
+    // and Bernoulli draws start there, and a copy is ~10x cheaper than regenerating 32 blocks.
+    const uint64_t nbase = rng.pos & ~15ull;
+    const uint64_t gen_end = rng.base + (uint64_t)rng.cap;
+    if (nbase >= rng.base && gen_end >= nbase + 16) {
+        const uint32_t avail = gen_end - nbase > (uint64_t)RNG_CACHE_WORDS ? (uint32_t)RNG_CACHE_WORDS : (uint32_t)(gen_end - nbase);
+        const uint32_t* src = wbuf + (nbase - rng.base);
+        constexpr int PER_LANE = RNG_CACHE_WORDS / 64;      // 8 words = two 16-byte moves
+        static_assert(PER_LANE == 8, "copy below moves 8 words per lane");
+        const uint32_t o = (uint32_t)lane * PER_LANE;
+        const uint4 q0 = *reinterpret_cast<const uint4*>(src + o), q1 = *reinterpret_cast<const uint4*>(src + o + 4);
+        __syncthreads();                                      // every wave has read its words before any wave stores
+        *reinterpret_cast<uint4*>(small_cache + o) = q0;
+        *reinterpret_cast<uint4*>(small_cache + o + 4) = q1;
+        rng.cache = small_cache; rng.base = nbase; rng.cap = avail;
+    } else {
+        rng.cache = small_cache;
+        rng.base = rng.pos + 16;  // nothing usable: refill on first use
+        rng.cap = RNG_CACHE_WORDS;
+    }
 }
 
 }  // namespace nm

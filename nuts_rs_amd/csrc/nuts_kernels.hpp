@@ -127,7 +127,8 @@ struct KParams {
 #define NM_MARK(C, slot)                                                                  \
     {                                                                                     \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
-        if (blockIdx.x == 0 && threadIdx.x == 0) (C).P.prof[slot] += now_ - (C).prof_t;   \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                          \
+            (void)__hip_atomic_fetch_add(&(C).P.prof[slot], now_ - (C).prof_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
         (C).prof_t = now_;                                                                \
     }
 #else
@@ -589,7 +590,14 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
 template <int DPL, int W, class Dens>
 NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
 #if NM_LDS_L1
-    fill_standard_normals_bulk<(DPL * W + 1 < 64 ? DPL * W + 1 : 64)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, C.dim, C.zig, 64 * W, C.P.prof, C.prof_t);
+    // at most 17 passes (1088 cells) per chunk: wider tilings take several chunks, which keeps the refresh's register
+    // footprint (4 values per pass and lane in flight) the same for every kernel.  A vector that fits one 64-lane
+    // pass with room to spare is cheaper with the simple pass-at-a-time routine (K4: +10 %).
+    if (DPL == 2 && C.dim <= 48) {
+        fill_standard_normals(C.rng, C.l1z, C.dim, C.zig);
+    } else {
+        fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, C.dim, C.zig, 64 * W, C.P.prof, C.prof_t);
+    }
     const double2* s2 = C.tptr(C.l1z);
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
@@ -1083,6 +1091,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             extra_left -= 1;
             check = false;
         }
+        NM_MARK(C, 24)
         const bool fwd = sign > 0;
         const int64_t edge_idx = fwd ? right_idx : left_idx;
         const uint64_t nleaf = 1ull << depth;
@@ -1122,6 +1131,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(E, O, sub_log_size)
+            NM_MARK(C, 27)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
@@ -1131,7 +1141,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
+                NM_MARK(C, 16)
                 leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                NM_MARK(C, 17)
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_LEAF_ACCOUNT(O, E, wE)
                 if (stop != STOP_NONE) break;
@@ -1141,11 +1153,14 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     C.storeS(E.v, fs + 1);
                 }
                 // ---- odd leaf n + 1
+                NM_MARK(C, 18)
                 leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                NM_MARK(C, 19)
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
                 NM_LEAF_ACCOUNT(E, O, wO)
                 if (stop != STOP_NONE) break;
                 // ---- level-1 merge: A = {E}, B = {O}, everything in registers
+                NM_MARK(C, 20)
                 {
                     const bool turning = check ? turning_regs(E, O, fwd, C.red) : false;
                     double total;
@@ -1155,6 +1170,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     if (fatal) { stop = STOP_FATAL; break; }
                     if (turning) { stop = STOP_TURNING; break; }
                 }
+                NM_MARK(C, 21)
                 const uint64_t nn = n + 1;
                 const int t = (int)__builtin_ctzll(~nn);           // trailing ones of the odd leaf: merges up to level t
                 for (int k = 2; k <= t; ++k) {
@@ -1234,6 +1250,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     if (turning) { stop = STOP_TURNING; break; }
                 }
                 if (stop != STOP_NONE) break;
+                NM_MARK(C, 22)
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
                     if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
@@ -1245,6 +1262,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
                     C.pend[t] = e;
                 }
+                NM_MARK(C, 23)
             }
         }
 #undef NM_LEAF_ACCOUNT
@@ -1256,6 +1274,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             continue;
         }
         // ---- `other` is complete (its last leaf is O): top-level turning tests, then merge into the main tree
+        NM_MARK(C, 25)
         bool turning = false;
         if (check) {
             double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
@@ -1305,6 +1324,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
             }
         }
+        NM_MARK(C, 26)
         double total;
         const bool take = merge_weights(C, log_size, sub_log_size, true, total, fatal);
         if (fatal) break;
@@ -1324,6 +1344,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;
         }
+        NM_MARK(C, 28)
         if (fwd) right_idx = O.idx; else left_idx = O.idx;
         depth += 1;
         log_size = total;

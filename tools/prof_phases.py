@@ -15,6 +15,11 @@ from nuts_rs_amd import _lib  # noqa: E402
 
 NAMES = {0: "between draws (store stats, loop)", 1: "momentum refresh", 2: "tree (all doublings)",
          3: "winner x / g_x / stores / fisher", 4: "adapt", 5: "stats + mass-matrix event",
+         16: " tree: pair-loop head", 17: " tree: leapfrog (even leaf)", 18: " tree: account + F store (even)",
+         19: " tree: leapfrog (odd leaf)", 20: " tree: account (odd)", 21: " tree: level-1 merge (regs)",
+         22: " tree: level>=2 merges + U-turn loads", 23: " tree: pending sub-tree stores", 24: " tree: doubling head (rng bool)",
+         25: " tree: sub-tree done", 26: " tree: top-level U-turn tests", 27: " tree: depth-0 leaf",
+         28: " tree: top-level merge + edge store",
          8: " refresh: ChaCha words -> LDS", 9: " refresh: fast-path tests", 10: " refresh: walk", 12: " refresh: parallel slow paths",
          11: " refresh: scatter + barrier"}
 
