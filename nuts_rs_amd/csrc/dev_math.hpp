@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "detmath_tables.hpp"
 
 namespace nm {
 
@@ -124,99 +125,99 @@ NM_DEV double uniform_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// ---- deterministic exp / ln (Sun fdlibm e_exp.c / e_log.c algorithms) ---------------------------
-static __host__ __device__ __noinline__ double dexp(double x) {
-    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00;
-    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-                 P5 = 4.13813679705723846039e-08;
+// ---- deterministic exp / ln / ln_1p ---------------------------------------------------------------
+// Table-driven (Tang-style) reductions with tables from tools/gen_detmath_tables.py; every step is one IEEE-754
+// binary64 operation (+, -, *, fma, round-to-nearest-even, power-of-two scaling), no division, ~12 dependent
+// operations: these run on the latency-critical scalar path of every tree merge.  oracle/nmo_math.hpp executes
+// the same sequence on the host (bit-identical results); tests bound both against libm (< 1 ulp).
+//   exp:  x = n (ln2/64) + r, n = 64 k + j:  exp x = 2^k T[j] (1 + p(r))
+//   ln :  x = 2^k m, m in [sqrt 1/2, sqrt 2), j = rint(64 m), z = m R[j] - 1:  ln x = k ln2 - ln R[j] + log1p(z)
+static constexpr double DM_T_HI[64] = DM_EXP_T_HI, DM_T_LO[64] = DM_EXP_T_LO;
+static constexpr double DM_R[47] = DM_LOG_R, DM_F_HI[47] = DM_LOG_F_HI, DM_F_LO[47] = DM_LOG_F_LO;
+
+// U = true: the argument is wave-uniform; the table index is moved to a scalar register so that the lookups are
+// scalar loads (their own counter) instead of vector loads, which would queue behind every outstanding store.
+template <bool U>
+static __host__ __device__ __forceinline__ int dm_index(int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (U) return __builtin_amdgcn_readfirstlane(j);
+#endif
+    return j;
+}
+
+template <bool U>
+static __host__ __device__ __forceinline__ double dexp_impl(double x) {
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return __builtin_inf();
     if (x < -7.45133219101941108420e+02) return 0.0;
-    double ax = __builtin_fabs(x);
-    double hi = x, lo = 0.0;
-    int k = 0;
-    if (ax > 0.34657359027997264) {
-        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
-        double t = (double)k;
-        hi = x - t * ln2HI;
-        lo = t * ln2LO;
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {
-        return 1.0 + x;
-    }
-    double t = x * x;
-    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-    if (k >= -1021) {
-        if (k == 1024) return y * 2.0 * u2d((uint64_t)(1023 + 1023) << 52);
-        return y * u2d((uint64_t)(1023 + k) << 52);
-    }
-    return y * u2d((uint64_t)(1023 + k + 1000) << 52) * 9.33263618503218878990e-302;
+    const double nf = __builtin_rint(x * DM_EXP_INV_L);
+    const double r1 = __builtin_fma(-nf, DM_EXP_L_HI, x);
+    const double r = __builtin_fma(-nf, DM_EXP_L_LO, r1);
+    const int n = dm_index<U>((int)nf);
+    const int j = n & 63, k = n >> 6;
+    const double r2 = r * r;
+    const double a = __builtin_fma(r, DM_EXP_E3, DM_EXP_E2);
+    const double b = __builtin_fma(r, DM_EXP_E5, DM_EXP_E4);
+    const double q = __builtin_fma(r2, __builtin_fma(r2, DM_EXP_E6, b), a);
+    const double p = __builtin_fma(r2, q, r);                 // expm1(r)
+    const double th = DM_T_HI[j];
+    const double sum = __builtin_fma(th, p, DM_T_LO[j]);
+    return __builtin_ldexp(th + sum, k);
 }
+static __host__ __device__ __noinline__ double dexp(double x) { return dexp_impl<false>(x); }
 
-static __host__ __device__ __noinline__ double dlog(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
+// ln(x) + c / x for finite x > 0 (c = 0: plain ln; ln_1p passes the rounding error of 1 + t)
+template <bool U>
+static __host__ __device__ __forceinline__ double dlog_core(double x, double c) {
     uint64_t u = d2u(x);
-    int32_t hx = (int32_t)(u >> 32);
-    uint32_t lx = (uint32_t)u;
     int k = 0;
-    if (hx < 0x00100000) {
-        if (((hx & 0x7fffffff) | lx) == 0) return -__builtin_inf();
-        if (hx < 0) return __builtin_nan("");
-        k -= 54;
-        x *= 1.80143985094819840000e+16;
+    if (u < 0x0010000000000000ull) {                          // subnormal
+        x *= 1.80143985094819840000e+16;                      // 2^54
         u = d2u(x);
-        hx = (int32_t)(u >> 32);
+        k = -54;
     }
-    if (hx >= 0x7ff00000) return x + x;
-    k += (hx >> 20) - 1023;
-    hx &= 0x000fffff;
-    int32_t i = (hx + 0x95f64) & 0x100000;
-    u = (u & 0xffffffffull) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
-    x = u2d(u);
-    k += (i >> 20);
-    double f = x - 1.0;
-    double dk = (double)k;
-    if ((0x000fffff & (2 + hx)) < 3) {
-        if (f == 0.0) {
-            if (k == 0) return 0.0;
-            return dk * ln2_hi + dk * ln2_lo;
-        }
-        double R = f * f * (0.5 - 0.33333333333333333 * f);
-        if (k == 0) return f - R;
-        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
-    }
-    double s = f / (2.0 + f);
-    double z = s * s;
-    i = hx - 0x6147a;
-    double w = z * z;
-    int32_t j = 0x6b851 - hx;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
-    i |= j;
-    double R = t2 + t1;
-    if (i > 0) {
-        double hfsq = 0.5 * f * f;
-        if (k == 0) return f - (hfsq - s * (hfsq + R));
-        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
-    }
-    if (k == 0) return f - s * (f - R);
-    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+    const uint64_t mant = u & 0x000fffffffffffffull;
+    const int up = mant >= 0x6a09e667f3bcdull;                // mantissa >= sqrt(2): halve it
+    k += (int)(u >> 52) - 1023 + up;
+    const double m = u2d(mant | ((uint64_t)(1023 - up) << 52));    // [sqrt 1/2, sqrt 2)
+    const int j = dm_index<U>((int)__builtin_rint(m * 64.0) - DM_LOG_J0);
+    const double rj = DM_R[j];
+    const double z = __builtin_fma(m, rj, -1.0);
+    const double dk = (double)k;
+    const double z2 = z * z, z4 = z2 * z2;
+    const double p01 = __builtin_fma(z, DM_LOG_C3, DM_LOG_C2), p23 = __builtin_fma(z, DM_LOG_C5, DM_LOG_C4);
+    const double p45 = __builtin_fma(z, DM_LOG_C7, DM_LOG_C6), p67 = __builtin_fma(z, DM_LOG_C9, DM_LOG_C8);
+    const double q0 = __builtin_fma(z2, p23, p01), q1 = __builtin_fma(z2, p67, p45);
+    const double Q = __builtin_fma(z4, __builtin_fma(z4, DM_LOG_C10, q1), q0);
+    const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
+    const double corr = (c * rj) * u2d((uint64_t)(1023 - kc) << 52);
+    const double lo = __builtin_fma(dk, DM_LN2_LO, DM_F_LO[j]) + corr;
+    const double t = __builtin_fma(z2, Q, lo);
+    const double hk = dk * DM_LN2_HI;                         // exact
+    const double fh = DM_F_HI[j];
+    const double s1 = hk + fh, e1 = (hk - s1) + fh;
+    const double s2 = s1 + z, e2 = (s1 - s2) + z;
+    return s2 + ((e1 + e2) + t);
 }
 
-NM_DEV double dlog1p(double x) {
-    double u = 1.0 + x;
-    if (u == 1.0) return x;
-    if (!(u == u) || __builtin_isinf(u)) return dlog(u);
-    return dlog(u) * (x / (u - 1.0));
+template <bool U>
+static __host__ __device__ __forceinline__ double dlog_impl(double x) {
+    if (x != x) return x;
+    if (x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_inf();
+    if (__builtin_isinf(x)) return x;
+    return dlog_core<U>(x, 0.0);
 }
+// ln(1 + x): ln of the rounded sum plus the first-order term of its rounding error
+template <bool U>
+static __host__ __device__ __forceinline__ double dlog1p_impl(double x) {
+    const double u = 1.0 + x;
+    if (u == 1.0) return x;
+    if (!(u == u) || __builtin_isinf(u) || !(u > 0.0)) return dlog_impl<U>(u);
+    return dlog_core<U>(u, x - (u - 1.0));
+}
+static __host__ __device__ __noinline__ double dlog(double x) { return dlog_impl<false>(x); }
+static __host__ __device__ __noinline__ double dlog1p(double x) { return dlog1p_impl<false>(x); }
 // per-lane logaddexp (reference src/math/util.rs:6-19)
 NM_DEV double logaddexp_lane(double a, double b) {
     if (a == b) return a + dlog(2.0);
@@ -226,14 +227,11 @@ NM_DEV double logaddexp_lane(double a, double b) {
     return diff;
 }
 // wave-uniform variants: same arithmetic, result marked uniform
+// (calls, not inlined copies with scalar table loads: measured, the inlined form is 3 % slower on K2 — the waits it
+// removes from the calls reappear at the next memory operation, and the extra code costs registers)
 NM_DEV double uexp(double x) { return uniform_f64(dexp(x)); }
 NM_DEV double ulog(double x) { return uniform_f64(dlog(x)); }
-NM_DEV double ulog1p(double x) {
-    double u = 1.0 + x;
-    if (u == 1.0) return x;
-    if (!(u == u) || __builtin_isinf(u)) return ulog(u);
-    return ulog(u) * (x / (u - 1.0));
-}
+NM_DEV double ulog1p(double x) { return uniform_f64(dlog1p(x)); }
 // reference src/math/util.rs:6-19
 NM_DEV double logaddexp(double a, double b) {
     if (a == b) return a + ulog(2.0);

@@ -974,10 +974,15 @@ enum TreeStop { STOP_NONE = 0, STOP_TURNING = 1, STOP_DIVERGING = 2, STOP_FATAL 
 // multinomial merge weights (reference merge_into, src/nuts.rs:172-207).  Returns take_B.
 template <int DPL, int W, class Dens>
 NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
+    NM_MARK(C, 13)
     total = logaddexp(a_log_size, b_log_size);
+    NM_MARK(C, 14)
     const double self_log_size = is_main ? a_log_size : total;
     if (b_log_size >= self_log_size) return true;
-    int b = C.rng.random_bool(uexp(b_log_size - self_log_size));
+    const double p_ = uexp(b_log_size - self_log_size);
+    NM_MARK(C, 15)
+    int b = C.rng.random_bool(p_);
+    NM_MARK(C, 29)
     if (b < 0) { fatal = true; return false; }
     return b == 1;
 }

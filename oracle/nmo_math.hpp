@@ -39,103 +39,84 @@ static inline uint64_t f2u(double x) { uint64_t u; std::memcpy(&u, &x, 8); retur
 static inline double u2f(uint64_t u) { double x; std::memcpy(&x, &u, 8); return x; }
 
 // ---------------------------------------------------------------------------------------------
-// Deterministic transcendental functions (algorithms: Sun fdlibm e_exp.c / e_log.c, restated).
-// Every operation is a single IEEE-754 binary64 operation; no contraction (built with
-// -ffp-contract=off), so the same sequence on the GPU gives the same bits.
+// Deterministic transcendental functions: table-driven exp / ln / ln_1p (Tang-style reductions, tables from
+// tools/gen_detmath_tables.py), written so that every step is ONE IEEE-754 binary64 operation (+, -, *, fma,
+// round-to-nearest-even integer, scaling by a power of two) and no division: the HIP engine executes the same
+// sequence, so GPU and oracle agree bit for bit, and the dependent chain is ~12 operations long (these functions
+// sit on the latency-critical scalar path of every tree merge).  Accuracy: < 1 ulp (tests bound it against libm).
+//   exp:  x = n (ln2/64) + r, n = 64 k + j:  exp x = 2^k T[j] (1 + p(r)),  p = expm1 by a degree-6 polynomial
+//   ln :  x = 2^k m, m in [sqrt 1/2, sqrt 2), j = rint(64 m), z = m R[j] - 1 (one fma):
+//         ln x = k ln2 + (-ln R[j]) + log1p(z),  log1p by a degree-10 polynomial, hi/lo sums kept apart
 // ---------------------------------------------------------------------------------------------
+#include "nmo_detmath_tables.hpp"
+static const double DM_T_HI[64] = DM_EXP_T_HI, DM_T_LO[64] = DM_EXP_T_LO;
+static const double DM_R[47] = DM_LOG_R, DM_F_HI[47] = DM_LOG_F_HI, DM_F_LO[47] = DM_LOG_F_LO;
+
 static inline double det_exp(double x) {
-    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00;
-    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-                 P5 = 4.13813679705723846039e-08;
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return INFINITY;
     if (x < -7.45133219101941108420e+02) return 0.0;
-    double ax = std::fabs(x);
-    double hi = x, lo = 0.0;
+    const double nf = std::nearbyint(x * DM_EXP_INV_L);
+    const double r1 = std::fma(-nf, DM_EXP_L_HI, x);
+    const double r = std::fma(-nf, DM_EXP_L_LO, r1);
+    const int n = (int)nf;
+    const int j = n & 63, k = n >> 6;
+    const double r2 = r * r;
+    const double a = std::fma(r, DM_EXP_E3, DM_EXP_E2);
+    const double b = std::fma(r, DM_EXP_E5, DM_EXP_E4);
+    const double q = std::fma(r2, std::fma(r2, DM_EXP_E6, b), a);
+    const double p = std::fma(r2, q, r);                   // expm1(r)
+    const double sum = std::fma(DM_T_HI[j], p, DM_T_LO[j]);
+    return std::ldexp(DM_T_HI[j] + sum, k);
+}
+
+// ln(x) + c / x for finite x > 0 (c = 0: plain ln; ln_1p passes the rounding error of 1 + t)
+static inline double det_log_core(double x, double c) {
+    uint64_t u = f2u(x);
     int k = 0;
-    if (ax > 0.34657359027997264) {                    // |x| > 0.5 ln2
-        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
-        double t = (double)k;
-        hi = x - t * ln2HI;
-        lo = t * ln2LO;
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {           // |x| < 2^-28
-        return 1.0 + x;
+    if (u < 0x0010000000000000ull) {                       // subnormal
+        x *= 1.80143985094819840000e+16;                   // 2^54
+        u = f2u(x);
+        k = -54;
     }
-    double t = x * x;
-    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-    // scale by 2^k
-    if (k >= -1021) {
-        if (k == 1024) return y * 2.0 * u2f((uint64_t)(1023 + 1023) << 52);
-        return y * u2f((uint64_t)(1023 + k) << 52);
-    }
-    return y * u2f((uint64_t)(1023 + k + 1000) << 52) * 9.33263618503218878990e-302;  // 2^-1000
+    const uint64_t mant = u & 0x000fffffffffffffull;
+    const int up = mant >= 0x6a09e667f3bcdull;             // mantissa >= sqrt(2): halve it
+    k += (int)(u >> 52) - 1023 + up;
+    const double m = u2f(mant | ((uint64_t)(1023 - up) << 52));   // [sqrt 1/2, sqrt 2)
+    const int j = (int)std::nearbyint(m * 64.0) - DM_LOG_J0;
+    const double rj = DM_R[j];
+    const double z = std::fma(m, rj, -1.0);
+    const double dk = (double)k;
+    const double z2 = z * z, z4 = z2 * z2;
+    const double p01 = std::fma(z, DM_LOG_C3, DM_LOG_C2), p23 = std::fma(z, DM_LOG_C5, DM_LOG_C4);
+    const double p45 = std::fma(z, DM_LOG_C7, DM_LOG_C6), p67 = std::fma(z, DM_LOG_C9, DM_LOG_C8);
+    const double q0 = std::fma(z2, p23, p01), q1 = std::fma(z2, p67, p45);
+    const double Q = std::fma(z4, std::fma(z4, DM_LOG_C10, q1), q0);
+    // c / x ~ c * R[j] * 2^-k (c is a rounding error: a 1 % reciprocal is plenty)
+    const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);       // c != 0 only from ln_1p, where |k| <= 1024
+    const double corr = (c * rj) * u2f((uint64_t)(1023 - kc) << 52);
+    const double lo = std::fma(dk, DM_LN2_LO, DM_F_LO[j]) + corr;
+    const double t = std::fma(z2, Q, lo);
+    const double hk = dk * DM_LN2_HI;                      // exact
+    const double s1 = hk + DM_F_HI[j], e1 = (hk - s1) + DM_F_HI[j];
+    const double s2 = s1 + z, e2 = (s1 - s2) + z;
+    return s2 + ((e1 + e2) + t);
 }
 
 static inline double det_log(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    uint64_t u = f2u(x);
-    int32_t hx = (int32_t)(u >> 32);
-    uint32_t lx = (uint32_t)u;
-    int k = 0;
-    if (hx < 0x00100000) {                             // x < 2^-1022, zero or negative
-        if (((hx & 0x7fffffff) | lx) == 0) return -INFINITY;
-        if (hx < 0) return NAN;
-        k -= 54;
-        x *= 1.80143985094819840000e+16;               // 2^54
-        u = f2u(x);
-        hx = (int32_t)(u >> 32);
-    }
-    if (hx >= 0x7ff00000) return x + x;
-    k += (hx >> 20) - 1023;
-    hx &= 0x000fffff;
-    int32_t i = (hx + 0x95f64) & 0x100000;
-    u = (u & 0xffffffffull) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
-    x = u2f(u);
-    k += (i >> 20);
-    double f = x - 1.0;
-    double dk = (double)k;
-    if ((0x000fffff & (2 + hx)) < 3) {                 // |f| < 2^-20
-        if (f == 0.0) {
-            if (k == 0) return 0.0;
-            return dk * ln2_hi + dk * ln2_lo;
-        }
-        double R = f * f * (0.5 - 0.33333333333333333 * f);
-        if (k == 0) return f - R;
-        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
-    }
-    double s = f / (2.0 + f);
-    double z = s * s;
-    i = hx - 0x6147a;
-    double w = z * z;
-    int32_t j = 0x6b851 - hx;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
-    i |= j;
-    double R = t2 + t1;
-    if (i > 0) {
-        double hfsq = 0.5 * f * f;
-        if (k == 0) return f - (hfsq - s * (hfsq + R));
-        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
-    }
-    if (k == 0) return f - s * (f - R);
-    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+    if (x != x) return x;
+    if (x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (std::isinf(x)) return x;
+    return det_log_core(x, 0.0);
 }
 
-// ln(1+x) for x > -1 by the (1+x)-1 correction; ~1-2 ulp, enough for logaddexp (|x| <= 1 there).
+// ln(1 + x): ln of the rounded sum plus the first-order term of its rounding error
 static inline double det_log1p(double x) {
-    double u = 1.0 + x;
+    const double u = 1.0 + x;
     if (u == 1.0) return x;
-    if (!(u == u) || std::isinf(u)) return det_log(u);
-    return det_log(u) * (x / (u - 1.0));
+    if (!(u == u) || std::isinf(u) || !(u > 0.0)) return det_log(u);
+    return det_log_core(u, x - (u - 1.0));
 }
 
 struct Ctx {

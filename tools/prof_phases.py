@@ -20,6 +20,8 @@ NAMES = {0: "between draws (store stats, loop)", 1: "momentum refresh", 2: "tree
          22: " tree: level>=2 merges + U-turn loads", 23: " tree: pending sub-tree stores", 24: " tree: doubling head (rng bool)",
          25: " tree: sub-tree done", 26: " tree: top-level U-turn tests", 27: " tree: depth-0 leaf",
          28: " tree: top-level merge + edge store",
+         13: " (before merge_weights)", 14: " merge: logaddexp (exp + log1p)", 15: " merge: exp for Bernoulli",
+         29: " merge: Bernoulli draw",
          8: " refresh: ChaCha words -> LDS", 9: " refresh: fast-path tests", 10: " refresh: walk", 12: " refresh: parallel slow paths",
          11: " refresh: scatter + barrier"}
 
