@@ -10,6 +10,8 @@ from .sampler import (AdamOptions, ChainBatch, DiagAdaptExpSettings, DiagNutsSet
                       LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS,
                       STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED)
 
-__all__ = ["AdamOptions", "ChainBatch", "DiagNutsSettings", "EuclideanAdaptOptions", "StepSizeSettings", "DualAverageOptions",
+from .controller import ChainProgress, ProgressCallback, Sampler, SamplerWaitResult  # noqa: F401
+
+__all__ = ["ChainProgress", "ProgressCallback", "Sampler", "SamplerWaitResult", "AdamOptions", "ChainBatch", "DiagNutsSettings", "EuclideanAdaptOptions", "StepSizeSettings", "DualAverageOptions",
            "DiagAdaptExpSettings", "LogpSpec", "Progress", "sample", "NutsAmdError", "STATS_DTYPE", "VECTOR_STATS",
            "load_library"]
