@@ -120,6 +120,12 @@ struct KParams {
     const double* x0;            // init kernel: [n_chains][dim]
 };
 
+// Also run the top-level U-turn test of a finished sub-tree before its last merges?  Measured: no (118 spilled registers
+// at DPL 16, K2 1.57e11 instead of 1.68e11), and the <8,2> tiling then disagrees with the oracle on one test seed for a
+// reason not yet understood — kept only as an experiment switch.
+#ifndef NM_TOP_EARLY
+#define NM_TOP_EARLY 0
+#endif
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
 #ifndef NM_PROF
 #define NM_PROF 0
@@ -1128,6 +1134,57 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             }                                                                                             \
         }
 
+        // top-level U-turn tests of the finished `other` sub-tree against the main tree (src/nuts.rs:143-161); O is its
+        // last leaf.  Reads end points only, so it can run before the sub-tree's own last merges (see the pair loop).
+        auto top_level_turning = [&]() __attribute__((always_inline)) -> bool {
+                double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+                const auto mlz = C.edge_z(left_slot), mlv = C.edge_v(left_slot);
+                const auto mrz = C.edge_z(right_slot), mrv = C.edge_v(right_slot);
+                if (depth == 0) {
+#if NM_TRIM_FIRST
+                    return turning_regs(E, O, fwd, C.red);        // (initial point, leaf): both in registers
+#else
+#pragma unroll
+                    for (int m = 0; m < DPL / 2; ++m) {
+                        double2 az = fwd ? C.ld2(mlz.r, mlz.so, m) : C.ld2(mrz.r, mrz.so, m);
+                        double2 av = fwd ? C.ld2(mlv.r, mlv.so, m) : C.ld2(mrv.r, mrv.so, m);
+                        if (fwd) { turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2); turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2); }
+                        else { turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2); turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2); }
+                    }
+                    C.red.sum2(s1, s2);
+                    return (s1 < 0.) | (s2 < 0.);
+#endif
+                } else {
+                    // other.first (leaf 0 of this doubling): F[depth]; at depth 1 it is still E
+                    const int so_ofz = C.soS(slot_F((int)depth)), so_ofv = C.soS(slot_F((int)depth) + 1);
+                    const bool of_in_regs = NM_TRIM_FIRST && depth == 1;
+#pragma unroll
+                    for (int m = 0; m < DPL / 2; ++m) {
+                        double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
+                        double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
+                        double2 oz, ov;
+                        if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
+                        else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
+                        const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
+                        const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
+                        if (fwd) {
+                            // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
+                            turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
+                            turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
+                            turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6);
+                        } else {
+                            // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
+                            turn_acc(cz0, cv0, rz.x, rv.x, s1, s2); turn_acc(cz1, cv1, rz.y, rv.y, s1, s2);
+                            turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
+                            turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
+                        }
+                        NM_GROUP_BARRIER(m);
+                    }
+                    { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
+                    return (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+                }
+        };
+        bool top_turning = false, top_done = false;
         if (depth == 0) {
             // a single leaf from the initial point, which E has held since initialize_trajectory: E -> O
 #if !NM_TRIM_FIRST
@@ -1165,24 +1222,18 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
                 NM_LEAF_ACCOUNT(E, O, wO)
                 if (stop != STOP_NONE) break;
-                // ---- level-1 merge: A = {E}, B = {O}, everything in registers
-                NM_MARK(C, 20)
-                {
-                    const bool turning = check ? turning_regs(E, O, fwd, C.red) : false;
-                    double total;
-                    const bool take = merge_weights(C, wE, wO, false, total, fatal);
-                    sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
-                    sub_log_size = total;
-                    if (fatal) { stop = STOP_FATAL; break; }
-                    if (turning) { stop = STOP_TURNING; break; }
-                }
-                NM_MARK(C, 21)
                 const uint64_t nn = n + 1;
                 const int t = (int)__builtin_ctzll(~nn);           // trailing ones of the odd leaf: merges up to level t
-                for (int k = 2; k <= t; ++k) {
-                    const PendEntry A = C.pend[k - 1];
-                    bool turning = false;
-                    if (check) {
+                // ---- every U-turn test this leaf completes (levels 1..t, and the top-level one when it is the last leaf
+                // of the doubling) BEFORE any merge arithmetic: the tests only read fixed end points, so their HBM round
+                // trips overlap each other instead of alternating with the merges' long scalar chains (exp, ln_1p,
+                // Bernoulli), which run afterwards on the recorded bits.  A turning level ends the doubling, so higher
+                // levels are not even loaded.  Bit k of turn_bits: the level-k test says "turning".
+                uint32_t turn_bits = 0;
+                NM_MARK(C, 20)
+                if (check) {
+                    if (turning_regs(E, O, fwd, C.red)) turn_bits |= 2u;
+                    for (int k = 2; k <= t && turn_bits == 0; ++k) {
                         // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
                         const uint64_t a_first = nn + 1 - (1ull << k);
                         const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
@@ -1241,8 +1292,24 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                             }
                         }
                         { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                        turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+                        if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
                     }
+#if NM_TOP_EARLY
+                    if (turn_bits == 0 && n + 2 == nleaf) { top_turning = top_level_turning(); top_done = true; }
+#endif
+                }
+                NM_MARK(C, 21)
+                // ---- level-1 merge: A = {E}, B = {O}
+                {
+                    double total;
+                    const bool take = merge_weights(C, wE, wO, false, total, fatal);
+                    sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if (turn_bits & 2u) { stop = STOP_TURNING; break; }
+                }
+                for (int k = 2; k <= t; ++k) {
+                    const PendEntry A = C.pend[k - 1];
                     double total;
                     const bool take = merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
                     if (take) {
@@ -1253,7 +1320,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     }
                     sub_log_size = total;
                     if (fatal) { stop = STOP_FATAL; break; }
-                    if (turning) { stop = STOP_TURNING; break; }
+                    if ((turn_bits >> k) & 1u) { stop = STOP_TURNING; break; }
                 }
                 if (stop != STOP_NONE) break;
                 NM_MARK(C, 22)
@@ -1282,54 +1349,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         // ---- `other` is complete (its last leaf is O): top-level turning tests, then merge into the main tree
         NM_MARK(C, 25)
         bool turning = false;
-        if (check) {
-            double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-            const auto mlz = C.edge_z(left_slot), mlv = C.edge_v(left_slot);
-            const auto mrz = C.edge_z(right_slot), mrv = C.edge_v(right_slot);
-            if (depth == 0) {
-#if NM_TRIM_FIRST
-                turning = turning_regs(E, O, fwd, C.red);        // (initial point, leaf): both in registers
-#else
-#pragma unroll
-                for (int m = 0; m < DPL / 2; ++m) {
-                    double2 az = fwd ? C.ld2(mlz.r, mlz.so, m) : C.ld2(mrz.r, mrz.so, m);
-                    double2 av = fwd ? C.ld2(mlv.r, mlv.so, m) : C.ld2(mrv.r, mrv.so, m);
-                    if (fwd) { turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2); turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2); }
-                    else { turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2); turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2); }
-                }
-                C.red.sum2(s1, s2);
-                turning = (s1 < 0.) | (s2 < 0.);
-#endif
-            } else {
-                // other.first (leaf 0 of this doubling): F[depth]; at depth 1 it is still E
-                const int so_ofz = C.soS(slot_F((int)depth)), so_ofv = C.soS(slot_F((int)depth) + 1);
-                const bool of_in_regs = NM_TRIM_FIRST && depth == 1;
-#pragma unroll
-                for (int m = 0; m < DPL / 2; ++m) {
-                    double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
-                    double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
-                    double2 oz, ov;
-                    if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
-                    else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
-                    const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
-                    const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
-                    if (fwd) {
-                        // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
-                        turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
-                        turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
-                        turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6);
-                    } else {
-                        // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
-                        turn_acc(cz0, cv0, rz.x, rv.x, s1, s2); turn_acc(cz1, cv1, rz.y, rv.y, s1, s2);
-                        turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
-                        turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
-                    }
-                    NM_GROUP_BARRIER(m);
-                }
-                { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
-            }
-        }
+        if (check) turning = top_done ? top_turning : top_level_turning();
         NM_MARK(C, 26)
         double total;
         const bool take = merge_weights(C, log_size, sub_log_size, true, total, fatal);
