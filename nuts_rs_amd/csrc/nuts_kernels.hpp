@@ -1349,7 +1349,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         // ---- `other` is complete (its last leaf is O): top-level turning tests, then merge into the main tree
         NM_MARK(C, 25)
         bool turning = false;
+#if NM_TOP_EARLY && NM_TRIM_FIRST
+        // every doubling of depth >= 1 has its flag from the pair loop; only the single-leaf doubling is tested here
+        if (check) turning = top_done ? top_turning : turning_regs(E, O, fwd, C.red);
+#else
         if (check) turning = top_done ? top_turning : top_level_turning();
+#endif
         NM_MARK(C, 26)
         double total;
         const bool take = merge_weights(C, log_size, sub_log_size, true, total, fatal);
