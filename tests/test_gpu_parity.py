@@ -275,3 +275,29 @@ def test_expanded_draw_vector_statistics_bit_exact(oracle, case):
     assert (np.isnan(vec_g["divergence_start"]).all(axis=2) == ~div).all()
     assert (np.isnan(vec_g["mass_matrix_inv"]).all(axis=2) == ~upd).all()
     assert upd[0].all() and not upd[-1].any()                    # first extraction compares with -1; none after tuning
+
+
+def test_multi_wave_tilings_seed_sweep(oracle):
+    """Chains that span 2 or 4 wavefronts (cross-wave sums through LDS, shared RNG cache, barriers): a sweep over
+    seeds, dims with and without padding and both densities, each draw for draw against the oracle."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for i in range(14):
+        wpc = 2 if i % 2 == 0 else 4
+        dpl = int(rng.choice([8, 16] if wpc == 2 else [4, 16]))
+        cap = 64 * wpc * dpl
+        dim = int(rng.integers(cap // 2 + 1, cap + 1)) if i % 3 else cap
+        cases.append((dpl, wpc, dim, 1000 + i, "diag" if i % 4 == 1 else "iid"))
+    for dpl, wpc, dim, seed, dens in cases:
+        s = N.DiagNutsSettings(num_chains=2, seed=seed, num_tune=25)
+        logp = (N.LogpSpec.iid_normal(dim, 3.0) if dens == "iid"
+                else N.LogpSpec.diag_normal(np.exp(np.random.default_rng(seed).uniform(-4, 4, dim))))
+        x0 = oracle.init_positions_uniform(seed, 0, 2, dim)
+        pos_g, st_g, ex = run_engine(s, logp, 2, x0, 36, dims_per_lane=dpl, waves_per_chain=wpc)
+        assert ex["threads_per_chain"] == 64 * wpc
+        pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, 2, x0, 36, gpu_threads=64 * wpc)
+        assert failed == 0
+        try:
+            assert_bit_exact(pos_g, st_g, pos_o, st_o)
+        except AssertionError as e:
+            raise AssertionError(f"tiling (dpl {dpl}, waves {wpc}) dim {dim} seed {seed} {dens}: {e}") from None
