@@ -132,8 +132,32 @@ NM_DEV double uniform_f64(double x) {
 // the same sequence on the host (bit-identical results); tests bound both against libm (< 1 ulp).
 //   exp:  x = n (ln2/64) + r, n = 64 k + j:  exp x = 2^k T[j] (1 + p(r))
 //   ln :  x = 2^k m, m in [sqrt 1/2, sqrt 2), j = rint(64 m), z = m R[j] - 1:  ln x = k ln2 - ln R[j] + log1p(z)
+// On the device the tables live in LDS (2.1 KiB per block, copied in by dm_init_lds() at the start of every kernel):
+// a lookup costs an LDS read instead of a trip to L2 (two dependent ones per logaddexp, ~1 us in the tree's merges).
 static constexpr double DM_T_HI[64] = DM_EXP_T_HI, DM_T_LO[64] = DM_EXP_T_LO;
 static constexpr double DM_R[47] = DM_LOG_R, DM_F_HI[47] = DM_LOG_F_HI, DM_F_LO[47] = DM_LOG_F_LO;
+constexpr int DM_OFF_T_HI = 0, DM_OFF_T_LO = 64, DM_OFF_R = 128, DM_OFF_F_HI = 175, DM_OFF_F_LO = 222, DM_LDS_DOUBLES = 269;
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ double dm_lds[DM_LDS_DOUBLES];
+#define DM_TAB(name, off, idx) dm_lds[(off) + (idx)]
+#else
+#define DM_TAB(name, off, idx) name[idx]
+#endif
+// every kernel that may evaluate exp / ln calls this first (all threads)
+static __device__ __forceinline__ void dm_init_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = (int)threadIdx.x; i < DM_LDS_DOUBLES; i += (int)blockDim.x) {
+        double v;
+        if (i < DM_OFF_T_LO) v = DM_T_HI[i];
+        else if (i < DM_OFF_R) v = DM_T_LO[i - DM_OFF_T_LO];
+        else if (i < DM_OFF_F_HI) v = DM_R[i - DM_OFF_R];
+        else if (i < DM_OFF_F_LO) v = DM_F_HI[i - DM_OFF_F_HI];
+        else v = DM_F_LO[i - DM_OFF_F_LO];
+        dm_lds[i] = v;
+    }
+    __syncthreads();
+#endif
+}
 
 // U = true: the argument is wave-uniform; the table index is moved to a scalar register so that the lookups are
 // scalar loads (their own counter) instead of vector loads, which would queue behind every outstanding store.
@@ -160,8 +184,8 @@ static __host__ __device__ __forceinline__ double dexp_impl(double x) {
     const double b = __builtin_fma(r, DM_EXP_E5, DM_EXP_E4);
     const double q = __builtin_fma(r2, __builtin_fma(r2, DM_EXP_E6, b), a);
     const double p = __builtin_fma(r2, q, r);                 // expm1(r)
-    const double th = DM_T_HI[j];
-    const double sum = __builtin_fma(th, p, DM_T_LO[j]);
+    const double th = DM_TAB(DM_T_HI, DM_OFF_T_HI, j);
+    const double sum = __builtin_fma(th, p, DM_TAB(DM_T_LO, DM_OFF_T_LO, j));
     return __builtin_ldexp(th + sum, k);
 }
 static __host__ __device__ __noinline__ double dexp(double x) { return dexp_impl<false>(x); }
@@ -181,7 +205,7 @@ static __host__ __device__ __forceinline__ double dlog_core(double x, double c) 
     k += (int)(u >> 52) - 1023 + up;
     const double m = u2d(mant | ((uint64_t)(1023 - up) << 52));    // [sqrt 1/2, sqrt 2)
     const int j = dm_index<U>((int)__builtin_rint(m * 64.0) - DM_LOG_J0);
-    const double rj = DM_R[j];
+    const double rj = DM_TAB(DM_R, DM_OFF_R, j);
     const double z = __builtin_fma(m, rj, -1.0);
     const double dk = (double)k;
     const double z2 = z * z, z4 = z2 * z2;
@@ -191,10 +215,10 @@ static __host__ __device__ __forceinline__ double dlog_core(double x, double c) 
     const double Q = __builtin_fma(z4, __builtin_fma(z4, DM_LOG_C10, q1), q0);
     const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
     const double corr = (c * rj) * u2d((uint64_t)(1023 - kc) << 52);
-    const double lo = __builtin_fma(dk, DM_LN2_LO, DM_F_LO[j]) + corr;
+    const double lo = __builtin_fma(dk, DM_LN2_LO, DM_TAB(DM_F_LO, DM_OFF_F_LO, j)) + corr;
     const double t = __builtin_fma(z2, Q, lo);
     const double hk = dk * DM_LN2_HI;                         // exact
-    const double fh = DM_F_HI[j];
+    const double fh = DM_TAB(DM_F_HI, DM_OFF_F_HI, j);
     const double s1 = hk + fh, e1 = (hk - s1) + fh;
     const double s2 = s1 + z, e2 = (s1 - s2) + z;
     return s2 + ((e1 + e2) + t);

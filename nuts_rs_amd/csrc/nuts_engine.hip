@@ -567,6 +567,7 @@ NM_DEV void store_row(const Tile<DPL>& t, double* row, int dim) {
 }
 template <int DPL, class Dens>
 __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
+    dm_init_lds();
     const uint64_t i = blockIdx.x;
     const int dim = (int)A.P.dim;
     __shared__ double lsig[64 * DPL], lmu[64 * DPL], lred[2 * RED_MAX_VALUES];
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(64) void turning_batch_kernel(uint64_t dim, const d
     if (lane_id() == 0) { out[2 * i] = t1; out[2 * i + 1] = t2; }
 }
 __global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, const double* b, double* out) {
+    dm_init_lds();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double x = a[i], y = b ? b[i] : 0.0, r;
@@ -626,6 +628,7 @@ __global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, con
 }
 __global__ __launch_bounds__(64) void normal_batch_kernel(uint64_t count, const uint32_t* keys, const double* zig_x,
                                                           const double* zig_f, double* out, uint64_t* words) {
+    dm_init_lds();
     __shared__ uint32_t cache[RNG_CACHE_WORDS];
     __shared__ double stage[1024];   // LDS staging in this test kernel (the engine stages through its HBM scratch)
     const uint64_t i = blockIdx.x;

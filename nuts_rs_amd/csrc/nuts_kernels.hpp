@@ -1541,6 +1541,7 @@ constexpr int draw_min_waves() { return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DP
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W> sh;
+    dm_init_lds();
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
@@ -1567,6 +1568,7 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W> sh;
+    dm_init_lds();
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
