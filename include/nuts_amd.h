@@ -118,6 +118,9 @@ void nm_settings_default(nm_settings* s);
                                     (the diagonal-P case of the MvNormal fixture, src/transform/mod.rs:98-112) */
 #define NM_LOGP_FUNNEL 2         /* Neal's funnel, dim = 1 + n (defined by this repo) */
 #define NM_LOGP_EIGHT_SCHOOLS 3  /* non-centered 8 schools, dim = 10 (defined by this repo) */
+#define NM_LOGP_MVN_PREC 4       /* params[dim*dim] = symmetric precision P, row-major.  logp = -0.5 x'Px (no constant),
+                                    g = -Px, (Px)_d = sum_j fma(P[j][d], x_j, .) with j ascending (the
+                                    full-P form of the MvNormal fixture, src/transform/mod.rs:98-112; defined by this repo) */
 
 typedef struct nm_logp_spec {
     uint64_t      kind;

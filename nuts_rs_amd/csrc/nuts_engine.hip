@@ -144,6 +144,7 @@ static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, co
     case NM_LOGP_DIAG_NORMAL: return launch_diag_normal(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_FUNNEL: return launch_funnel(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_MVN_PREC: return launch_mvn_prec(dpl, w, kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }
@@ -176,6 +177,13 @@ static nm_status check_logp(const nm_logp_spec* l) {
         return NM_OK;
     case NM_LOGP_EIGHT_SCHOOLS:
         if (l->dim != 10 || l->n_params != 16 || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_EIGHT_SCHOOLS: dim 10, params = y[8], sigma[8]");
+        return NM_OK;
+    case NM_LOGP_MVN_PREC:
+        if (l->n_params != l->dim * l->dim || !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MVN_PREC takes dim*dim parameters (the precision matrix, row-major)");
+        if (l->dim > 2048) return fail(NM_ERR_UNSUPPORTED, "NM_LOGP_MVN_PREC: dim %llu > 2048 (the position is kept in LDS)", (unsigned long long)l->dim);
+        for (uint64_t i = 0; i < l->dim; ++i)
+            for (uint64_t j = 0; j < i; ++j)
+                if (l->h_params[i * l->dim + j] != l->h_params[j * l->dim + i]) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MVN_PREC: the precision matrix must be symmetric (entry %llu,%llu)", (unsigned long long)i, (unsigned long long)j);
         return NM_OK;
     }
     return fail(NM_ERR_INVALID_ARG, "unknown logp kind %llu", (unsigned long long)l->kind);
@@ -572,10 +580,12 @@ __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
     const int dim = (int)A.P.dim;
     __shared__ double lsig[64 * DPL], lmu[64 * DPL], lred[2 * RED_MAX_VALUES];
     __shared__ ChainScalars lsc;
+    __shared__ double ldens[Dens::kNeedsLdsVector ? 64 * DPL : 2];
     ChainCtx<DPL, 1, Dens> C(A.P, lsc);
     C.dim = dim;
     C.red.init(lred);
     C.dens.init(A.P.logp_params, dim, C.red);
+    C.dens.set_lds(ldens);
     C.lsig = lsig; C.lmu = lmu;
     {
         Tile<DPL> t;
@@ -689,6 +699,7 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
     case NM_LOGP_IID_NORMAL: er = launch_lf_d<IidNormal>(dpl, A, n, (hipStream_t)stream); break;
     case NM_LOGP_DIAG_NORMAL: er = launch_lf_d<DiagNormal>(dpl, A, n, (hipStream_t)stream); break;
     case NM_LOGP_FUNNEL: er = launch_lf_d<Funnel>(dpl, A, n, (hipStream_t)stream); break;
+    case NM_LOGP_MVN_PREC: er = launch_lf_d<MvnPrec>(dpl, A, n, (hipStream_t)stream); break;
     default: er = launch_lf_d<EightSchools>(2, A, n, (hipStream_t)stream); break;
     }
     if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);

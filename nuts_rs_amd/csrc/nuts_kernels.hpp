@@ -214,7 +214,9 @@ NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
 // densities: eval(x, gx, dim) -> logp (wave-uniform), fills gx; padded elements (index >= dim) must give
 // zero terms and zero gradient.
 // ---------------------------------------------------------------------------------------------
-struct IidNormal {   // reference benches/sample.rs:49-62
+struct IidNormal {
+    static constexpr bool kNeedsLdsVector = false;
+    NM_DEV void set_lds(double*) {}   // reference benches/sample.rs:49-62
     double mu;
     template <int W>
     NM_DEV void init(const double* params, int, Reducer<W>&) { mu = params[0]; }
@@ -233,7 +235,9 @@ struct IidNormal {   // reference benches/sample.rs:49-62
     }
 };
 
-struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/transform/mod.rs:98-112
+struct DiagNormal {
+    static constexpr bool kNeedsLdsVector = false;
+    NM_DEV void set_lds(double*) {}  // diagonal-P case of the MvNormal fixture, reference src/transform/mod.rs:98-112
     const double* prec;
     double norm;
     template <int W>
@@ -269,6 +273,8 @@ struct DiagNormal {  // diagonal-P case of the MvNormal fixture, reference src/t
 // x[i] | v ~ N(0, e^v), i = 1..dim-1.  logp = -v^2/18 - (k/2) v - e^{-v}/2 * sum x_i^2  (k = dim - 1).
 // Same operation order as oracle/nmo_nuts.hpp LOGP_FUNNEL.
 struct Funnel {
+    static constexpr bool kNeedsLdsVector = false;
+    NM_DEV void set_lds(double*) {}
     template <int W>
     NM_DEV void init(const double*, int, Reducer<W>&) {}
     template <int DPL, int W>
@@ -298,7 +304,55 @@ struct Funnel {
 // Non-centered eight schools (defined by this repo): x = (mu, log tau, theta~[8]), params = y[8], sigma[8].
 // mu ~ N(0,5^2), tau ~ HalfCauchy(5) (+ log-Jacobian), theta~ ~ N(0,1), y_i ~ N(mu + tau theta~_i, sigma_i^2).
 // Same operation order as oracle/nmo_nuts.hpp LOGP_EIGHT_SCHOOLS (dim = 10: elements 2l, 2l+1 in lane l).
+// Normal with a full (symmetric) precision matrix P: logp = -1/2 x'Px, grad = -Px (BASELINE config K5; the reference's
+// MvNormal fixture, src/transform/mod.rs:98-112, has this form but only diagonal P — the definition with a full P and
+// no normalising constant is this repo's).  One chain's gradient is a GEMV; it is computed column by column,
+// y_d = sum_j P[j][d] x_j with j ascending and one fma per term (P symmetric, so row j read contiguously IS column j):
+// every lane streams its own elements of row j (coalesced, L2-resident: P is shared by all chains) and x_j is an LDS
+// broadcast.  MFMA does not apply: one chain has one right-hand side, and chains do not run in lockstep.
+struct MvnPrec {
+    static constexpr bool kNeedsLdsVector = true;
+    const double* P;
+    double* xs;          // LDS [64*W*DPL]: the position, visible to all lanes
+    template <int W>
+    NM_DEV void init(const double* params, int, Reducer<W>&) { P = params; }
+    NM_DEV void set_lds(double* lds) { xs = lds; }
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
+        __syncthreads();                                   // the previous evaluation's readers are done
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = elem_index<W>(k);
+            xs[d] = d < dim ? x.a[k] : 0.0;
+        }
+        __syncthreads();
+        double y[DPL];
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) y[k] = 0.0;
+        for (int j = 0; j < dim; ++j) {
+            const double xj = xs[j];
+            const double* row = P + (size_t)j * (size_t)dim;
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) {
+                const int d = elem_index<W>(k);
+                const double p = d < dim ? row[d] : 0.0;
+                y[k] = __builtin_fma(p, xj, y[k]);
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const bool valid = elem_index<W>(k) < dim;
+            gx.a[k] = valid ? -y[k] : 0.0;
+            acc = acc + (valid ? x.a[k] * y[k] : 0.0);
+        }
+        return -0.5 * R.sum(acc);
+    }
+};
+
 struct EightSchools {
+    static constexpr bool kNeedsLdsVector = false;
+    NM_DEV void set_lds(double*) {}
     const double* par;
     template <int W>
     NM_DEV void init(const double* params, int, Reducer<W>&) { par = params; }
@@ -361,7 +415,7 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
     int pad;
 };
 
-template <int DPL, int W>
+template <int DPL, int W, class Dens>
 struct BlockShared {      // LDS of one block (one block = W waves = one resident chain)
     uint32_t rng_cache[RNG_CACHE_WORDS];
     double sig[64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
@@ -374,6 +428,7 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
+    double dens_lds[Dens::kNeedsLdsVector ? 64 * W * DPL : 2];   // a density's block-visible vector (MvnPrec: the position)
     ChainScalars sc[W];       // the resident chain's scalars (copied in at ctx_begin; wave 0's copy goes back at ctx_end)
 };
 
@@ -451,7 +506,7 @@ struct ChainCtx {
 };
 
 template <int DPL, int W, class Dens>
-NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64_t chain, uint64_t wave) {
+NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, uint64_t chain, uint64_t wave) {
     const KParams& P = C.P;
     C.dim = (int)P.dim;
     C.maxdepth_cfg = (int)P.s.maxdepth;
@@ -479,6 +534,7 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W>& sh, uint64
     C.red.init(sh.red);
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
     C.dens.init(P.logp_params, C.dim, C.red);
+    C.dens.set_lds(sh.dens_lds);
 }
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_end(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
@@ -1540,7 +1596,7 @@ constexpr int draw_min_waves() { return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DP
 
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
-    __shared__ BlockShared<DPL, W> sh;
+    __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
@@ -1567,7 +1623,7 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
 // NutsChain::set_position (reference src/chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119)
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
-    __shared__ BlockShared<DPL, W> sh;
+    __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);

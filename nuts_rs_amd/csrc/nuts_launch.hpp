@@ -32,7 +32,9 @@ inline hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, un
     case 208: return launch_t<8, 2, Dens>(kind, P, grid, stream, occ);
     case 216: return launch_t<16, 2, Dens>(kind, P, grid, stream, occ);
     case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
-    case 416: return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
+    case 416:   // 138 KiB of LDS already: no room for a density that keeps a block-visible vector there
+        if constexpr (!Dens::kNeedsLdsVector) return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
+        else return hipErrorInvalidValue;
 #endif
     }
     return hipErrorInvalidValue;
@@ -43,4 +45,5 @@ hipError_t launch_iid_normal(int dpl, int w, KernelKind kind, const KParams& P, 
 hipError_t launch_diag_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_funnel(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_eight_schools(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_mvn_prec(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 }  // namespace nm

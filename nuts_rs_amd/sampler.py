@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, VECTOR_STATS,
                    check)
 
-LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS = 0, 1, 2, 3
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC = 0, 1, 2, 3, 4
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
 
 
@@ -150,6 +150,14 @@ class LogpSpec:
     def eight_schools(y=(28., 8., -3., 7., -1., 1., 18., 12.), sigma=(15., 10., 16., 11., 9., 11., 10., 18.)):
         """Non-centered 8 schools (mu, log tau, theta~[8]) (BASELINE config K4, defined by this repo)."""
         return LogpSpec(LOGP_EIGHT_SCHOOLS, 10, np.array(list(y) + list(sigma), dtype=np.float64))
+
+    @staticmethod
+    def mvn_precision(precision):
+        """N(0, P^-1) with a full symmetric precision matrix: logp = -x'Px/2 (BASELINE config K5, defined by this repo)."""
+        p = np.ascontiguousarray(precision, dtype=np.float64)
+        if p.ndim != 2 or p.shape[0] != p.shape[1] or not (p == p.T).all():
+            raise ValueError("precision must be a symmetric square matrix")
+        return LogpSpec(LOGP_MVN_PREC, p.shape[0], p.reshape(-1))
 
     def to_c(self):
         self._keep = np.ascontiguousarray(self.params, dtype=np.float64)

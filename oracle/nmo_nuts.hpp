@@ -66,7 +66,8 @@ struct DrawVectors {
     double* divergence_end = nullptr;
 };
 
-enum { LOGP_IID_NORMAL = 0, LOGP_DIAG_NORMAL = 1, LOGP_FUNNEL = 2, LOGP_EIGHT_SCHOOLS = 3, LOGP_HOST_CALLBACK = 100 };
+enum { LOGP_IID_NORMAL = 0, LOGP_DIAG_NORMAL = 1, LOGP_FUNNEL = 2, LOGP_EIGHT_SCHOOLS = 3, LOGP_MVN_PREC = 4,
+       LOGP_HOST_CALLBACK = 100 };
 enum { ST_OK = 0, ST_BAD_INIT = 1, ST_LOGP_FATAL = 2 };
 
 // CpuLogpFunc::logp shape (reference src/math/cpu_math.rs:885-891): 0 ok, 1 recoverable, 2 fatal
@@ -105,6 +106,17 @@ struct Density {
             double log_det_p = m.sum_terms(lt.data(), n);
             double norm = -0.5 * ((double)n * m.ln(6.283185307179586) - log_det_p);
             *out = quad + norm;
+            return 0;
+        }
+        case LOGP_MVN_PREC: {     // params = symmetric precision P [n][n]; logp = -x'Px/2, g = -Px
+            Vec t(n);
+            for (size_t d = 0; d < n; ++d) {
+                double y = 0.0;
+                for (size_t j = 0; j < n; ++j) y = std::fma(params[j * n + d], x[j], y);   // column d, j ascending
+                g[d] = -y;
+                t[d] = x[d] * y;
+            }
+            *out = -0.5 * m.sum_terms(t.data(), n);
             return 0;
         }
         case LOGP_FUNNEL: {       // v~N(0,3^2), x_i|v ~ N(0, e^v), i=1..n-1

@@ -66,7 +66,7 @@ class MathCfg(C.Structure):
 
 
 REDUCE_REF_SIMD, REDUCE_GPU = 0, 1
-LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS = 0, 1, 2, 3
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC = 0, 1, 2, 3, 4
 
 
 def ref_cfg(simd_lanes=4):

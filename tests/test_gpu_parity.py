@@ -57,6 +57,11 @@ PARITY_CASES = [
     ("dim2000_w2_dpl16", dict(seed=24, num_tune=30), 2000, 2, 40, "iid", (16, 2)),
     ("dim4096_w4_dpl16", dict(seed=25, num_tune=25), 4096, 2, 32, "iid", (16, 4)),
     ("funnel_dim300_w4", dict(seed=26, num_tune=60), 300, 4, 90, "funnel", (4, 4)),
+    # full precision matrix (BASELINE config K5's density): per-chain GEMV, position published through LDS
+    ("mvn_dim64", dict(seed=27, num_tune=80), 64, 4, 130, "mvn", 0),
+    ("mvn_dim100_pad", dict(seed=28, num_tune=80), 100, 3, 120, "mvn", 0),
+    ("mvn_k5_dim256", dict(seed=29, num_tune=60), 256, 3, 90, "mvn", 0),
+    ("mvn_dim300_w2", dict(seed=30, num_tune=40), 300, 2, 60, "mvn", (8, 2)),
 ]
 
 
@@ -72,6 +77,10 @@ def test_chain_parity_bit_exact(oracle, case):
         logp = N.LogpSpec.funnel(dim)
     elif dens == "schools":
         logp = N.LogpSpec.eight_schools()
+    elif dens == "mvn":
+        a = rng.normal(size=(dim, dim))
+        p = a @ a.T / dim + np.eye(dim)
+        logp = N.LogpSpec.mvn_precision((p + p.T) / 2)
     else:
         logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-6, 6, dim)))        # scales e^-3 .. e^3: deep, ragged trees
     x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)

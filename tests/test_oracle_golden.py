@@ -290,7 +290,8 @@ def test_other_densities_gradients(oracle):
     y = [28., 8., -3., 7., -1., 1., 18., 12.]
     sig = [15., 10., 16., 11., 9., 11., 10., 18.]
     for kind, dim, params in ((oracle.LOGP_FUNNEL, 11, [0.0]), (oracle.LOGP_EIGHT_SCHOOLS, 10, y + sig),
-                              (oracle.LOGP_DIAG_NORMAL, 4, [1.0, 0.25, 4.0, 2.0])):
+                              (oracle.LOGP_DIAG_NORMAL, 4, [1.0, 0.25, 4.0, 2.0]),
+                              (oracle.LOGP_MVN_PREC, 3, [2.0, 0.5, -0.3, 0.5, 1.0, 0.2, -0.3, 0.2, 3.0])):
         p = np.array(params)
         x = rng.normal(size=dim) * 0.5
         g = np.empty(dim)

@@ -1,6 +1,6 @@
 """Throughput and tree statistics of BASELINE.json's other configurations on one GPU (K1 for scale).
 
-  python tools/bench_configs.py [k3|k4|k1|all] [--draws N]
+  python tools/bench_configs.py [k3|k4|k5|k1|all] [--draws N]
 
 Prints one JSON line per configuration: M1 = leapfrog-steps*dims/s and M2 = draws/s/chain for the post-warm-up
 draws, depth histogram, divergence rate, and the "lane utilisation" SURVEY asks for on the ragged config
@@ -18,9 +18,18 @@ import torch  # before the engine: both bring a HIP runtime and torch's must be 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nuts_rs_amd as N  # noqa: E402
 
+def _k5_precision(d):
+    """Sigma = I + 0.5 * 11' scaled like tests/sample_normal.rs:29-45 of the reference; its inverse is the precision."""
+    sigma = np.eye(d) + 0.5 * np.ones((d, d)) / d
+    p = np.linalg.inv(sigma)
+    return (p + p.T) / 2
+
+
 CONFIGS = {
     "k1": dict(name="K1 iid N(3,1) dim 10", logp=lambda: N.LogpSpec.iid_normal(10, 3.0), chains=4, tune=400),
     "k3": dict(name="K3 Neal's funnel dim 101", logp=lambda: N.LogpSpec.funnel(101), chains=8192, tune=400),
+    "k5": dict(name="K5 normal with a full precision matrix dim 256 (per-chain GEMV)", logp=lambda: N.LogpSpec.mvn_precision(_k5_precision(256)),
+               chains=4096, tune=400),
     "k4": dict(name="K4 8 schools non-centered dim 10 (one GPU's shard of 65536)", logp=N.LogpSpec.eight_schools,
                chains=8192, tune=400),
 }
@@ -67,5 +76,5 @@ def run(key, draws):
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "all"
     draws = int(sys.argv[sys.argv.index("--draws") + 1]) if "--draws" in sys.argv else 200
-    for k in (["k1", "k3", "k4"] if which == "all" else [which]):
+    for k in (["k1", "k3", "k4", "k5"] if which == "all" else [which]):
         run(k, draws)
