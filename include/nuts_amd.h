@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 2
+#define NM_ABI_VERSION 3
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -122,12 +122,34 @@ void nm_settings_default(nm_settings* s);
                                     g = -Px, (Px)_d = sum_j fma(P[j][d], x_j, .) with j ascending (the
                                     full-P form of the MvNormal fixture, src/transform/mod.rs:98-112; defined by this repo) */
 
+#define NM_LOGP_MODULE 5         /* a user density compiled into its own shared object (see below) */
+
 typedef struct nm_logp_spec {
     uint64_t      kind;
     uint64_t      dim;
     uint64_t      n_params;
     const double* h_params;      /* host pointer, n_params doubles, copied at engine creation */
+    const char*   module_path;   /* NM_LOGP_MODULE: path of the density module (.so); NULL otherwise */
 } nm_logp_spec;
+
+/* ---------------------------------------------------------------------------------------------
+ * User densities (the device-side answer to `CpuLogpFunc`, reference src/math/cpu_math.rs:885-970).
+ * A density is a small HIP functor with the interface of the built-in ones (nuts_rs_amd/csrc/nuts_kernels.hpp,
+ * e.g. `struct DiagNormal`): `init(params, dim, reducer)`, `set_lds(ptr)`, and
+ *     template <int DPL, int W> double eval(const Tile<DPL>& x, Tile<DPL>& grad, int dim, Reducer<W>& R) const
+ * returning logp and filling the gradient (thread t of the 64*W threads owns elements 2(m*64W + t) + {0,1}).  It is
+ * compiled together with the engine's kernels into a module:
+ *     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+ *           -DNM_MODULE_DENSITY=MyDensity -DNM_MODULE_HEADER='"my_density.hpp"' -DNM_MODULE_DPL=<d> -DNM_MODULE_W=<w>
+ *           -I <repo>/nuts_rs_amd/csrc -I <repo>/include  <repo>/nuts_rs_amd/csrc/density_module.hip -o my_density.so
+ * for the tiling nm_pick_tiling(dim, ...) names (one tiling per module keeps the build at ~20 s), and selected with
+ * kind = NM_LOGP_MODULE, module_path = "my_density.so".  `python -m nuts_rs_amd.build` has a helper
+ * (nuts_rs_amd.build.build_density_module).  The module exports nm_module_launch / nm_module_info; the engine checks
+ * that it was built against the same kernel-parameter layout.
+ * ------------------------------------------------------------------------------------------- */
+/* The tiling the engine uses for `dim` (requested_* = 0: automatic): doubles per lane and waves per chain. */
+nm_status nm_pick_tiling(uint64_t dim, uint64_t requested_dims_per_lane, uint64_t requested_waves_per_chain,
+                         uint64_t* dims_per_lane, uint64_t* waves_per_chain);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-draw, per-chain statistics.  Union of the reference's `Progress` (src/sampler.rs:165-174)

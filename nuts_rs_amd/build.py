@@ -54,5 +54,31 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):
+    """(doubles per lane, waves per chain) the engine uses for `dim` — the same table as nm_pick_tiling."""
+    for dpl, w in ((2, 1), (4, 1), (8, 1), (16, 1), (8, 2), (16, 2), (4, 4), (16, 4)):
+        if dims_per_lane and dpl != dims_per_lane:
+            continue
+        if waves_per_chain and w != waves_per_chain:
+            continue
+        if dpl * 64 * w >= dim:
+            return dpl, w
+    raise ValueError(f"no tiling for dim {dim}")
+
+
+def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=()):
+    """Compile a user density (a functor `struct_name` defined in `header`, see include/nuts_amd.h "User densities")
+    with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s)."""
+    dpl, w = pick_tiling(dim, dims_per_lane, waves_per_chain)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    header = os.path.abspath(header)
+    cmd = [hipcc] + FLAGS + list(extra_flags) + [
+        "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
+        f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),
+        os.path.join(CSRC, "density_module.hip"), "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -138,7 +139,12 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 // kernel dispatch
 // ---------------------------------------------------------------------------------------------
 
-static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr) {
+typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ);
+typedef void (*module_info_fn)(uint64_t out[4]);
+
+static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
+                         module_launch_fn module = nullptr) {
+    if (logp_kind == NM_LOGP_MODULE) return module ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
     switch (logp_kind) {
     case NM_LOGP_IID_NORMAL: return launch_iid_normal(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_DIAG_NORMAL: return launch_diag_normal(dpl, w, kind, P, grid, stream, occ);
@@ -157,6 +163,13 @@ static bool pick_tiling(uint64_t dim, uint64_t requested_dpl, uint64_t requested
         if ((uint64_t)c[0] * 64 * c[1] >= dim) { *dpl_out = c[0]; *w_out = c[1]; return true; }
     }
     return false;
+}
+extern "C" nm_status nm_pick_tiling(uint64_t dim, uint64_t requested_dpl, uint64_t requested_w, uint64_t* dpl_out, uint64_t* w_out) {
+    int d = 0, w = 0;
+    if (!dpl_out || !w_out) return fail(NM_ERR_INVALID_ARG, "null output");
+    if (!pick_tiling(dim, requested_dpl, requested_w, &d, &w)) return fail(NM_ERR_UNSUPPORTED, "no tiling for dim %llu", (unsigned long long)dim);
+    *dpl_out = (uint64_t)d; *w_out = (uint64_t)w;
+    return NM_OK;
 }
 static int pick_dpl(uint64_t dim, uint64_t requested) {
     int dpl = 0, w = 0;
@@ -184,6 +197,11 @@ static nm_status check_logp(const nm_logp_spec* l) {
         for (uint64_t i = 0; i < l->dim; ++i)
             for (uint64_t j = 0; j < i; ++j)
                 if (l->h_params[i * l->dim + j] != l->h_params[j * l->dim + i]) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MVN_PREC: the precision matrix must be symmetric (entry %llu,%llu)", (unsigned long long)i, (unsigned long long)j);
+        return NM_OK;
+    }
+    if (l->kind == NM_LOGP_MODULE) {
+        if (!l->module_path) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MODULE needs module_path");
+        if (l->n_params && !l->h_params) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MODULE: n_params without h_params");
         return NM_OK;
     }
     return fail(NM_ERR_INVALID_ARG, "unknown logp kind %llu", (unsigned long long)l->kind);
@@ -221,6 +239,8 @@ struct nm_engine {
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
     double* d_x0 = nullptr;
+    void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
+    module_launch_fn module_launch = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -231,6 +251,7 @@ struct nm_engine {
 
 static void engine_free(nm_engine* e) {
     if (!e) return;
+    if (e->module_handle) dlclose(e->module_handle);
     if (e->d_pvec) (void)hipFree(e->d_pvec);
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
@@ -284,6 +305,17 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         hipError_t _e = (expr);                                                                     \
         if (_e != hipSuccess) { engine_free(e); return fail(NM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } \
     } while (0)
+    if (logp->kind == NM_LOGP_MODULE) {
+        e->module_handle = dlopen(logp->module_path, RTLD_NOW | RTLD_LOCAL);
+        if (!e->module_handle) { const char* why = dlerror(); std::string msg = why ? why : "?"; engine_free(e); return fail(NM_ERR_INVALID_ARG, "cannot load density module %s: %s", logp->module_path, msg.c_str()); }
+        module_info_fn info = (module_info_fn)dlsym(e->module_handle, "nm_module_info");
+        e->module_launch = (module_launch_fn)dlsym(e->module_handle, "nm_module_launch");
+        if (!info || !e->module_launch) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "%s is not a density module (nm_module_info / nm_module_launch missing)", logp->module_path); }
+        uint64_t mi[4] = {0, 0, 0, 0};
+        info(mi);
+        if (mi[0] != sizeof(KParams) || mi[1] != NM_ABI_VERSION) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module built against another engine (kernel parameters %llu bytes / ABI %llu, engine %zu / %d)", (unsigned long long)mi[0], (unsigned long long)mi[1], sizeof(KParams), NM_ABI_VERSION); }
+        if ((int)mi[2] != dpl || (int)mi[3] != wv) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module was built for tiling (%llu doubles per lane, %llu waves) but dim %llu uses (%d, %d): rebuild it with nm_pick_tiling's answer", (unsigned long long)mi[2], (unsigned long long)mi[3], (unsigned long long)logp->dim, dpl, wv); }
+    }
     E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     E_TRY(hipEventCreate(&e->ev0));
     E_TRY(hipEventCreate(&e->ev1));
@@ -291,7 +323,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         int occ = 0, cus = 0;
         KParams dummy;
         memset(&dummy, 0, sizeof dummy);
-        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ));
+        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch));
         E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
@@ -376,7 +408,7 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     KParams P = e->P;
-    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
@@ -408,7 +440,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
     e->kernel_launches += 1;
@@ -679,6 +711,7 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
                                        double* d_logp_out, double* d_kinetic_out, double* d_energy_error_out,
                                        void* stream) {
     nm_status st = check_logp(logp);
+    if (st == NM_OK && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "nm_leapfrog_batch covers the built-in densities only");
     if (st != NM_OK) return st;
     st = ensure_device(-1);
     if (st != NM_OK) return st;

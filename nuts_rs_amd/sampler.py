@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, VECTOR_STATS,
                    check)
 
-LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC = 0, 1, 2, 3, 4
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE = 0, 1, 2, 3, 4, 5
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
 
 
@@ -131,6 +131,7 @@ class LogpSpec:
     kind: int
     dim: int
     params: np.ndarray
+    module_path: Optional[str] = None
 
     @staticmethod
     def iid_normal(dim, mu=3.0):
@@ -159,9 +160,16 @@ class LogpSpec:
             raise ValueError("precision must be a symmetric square matrix")
         return LogpSpec(LOGP_MVN_PREC, p.shape[0], p.reshape(-1))
 
+    @staticmethod
+    def module(dim, module_path, params=()):
+        """A user density compiled into its own module (include/nuts_amd.h "User densities";
+        nuts_rs_amd.build.build_density_module builds one from a header that defines the functor)."""
+        return LogpSpec(LOGP_MODULE, int(dim), np.asarray(params, dtype=np.float64), module_path=str(module_path))
+
     def to_c(self):
         self._keep = np.ascontiguousarray(self.params, dtype=np.float64)
-        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data if len(self._keep) else None)
+        path = self.module_path.encode() if self.module_path else None
+        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data if len(self._keep) else None, path)
 
 
 class ChainBatch:

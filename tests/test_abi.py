@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/nuts_amd.h but not exported"
     assert set(names) == set(_lib.ABI_SYMBOLS)
-    assert L.nm_abi_version() == 2
+    assert L.nm_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 37
     assert _lib.STATS_DTYPE.itemsize == 8 * 21
     assert C.sizeof(_lib.NmDrawOutputs) == 8 * 16
-    assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 32
+    assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 40
 
 
 def test_defaults_are_the_references():

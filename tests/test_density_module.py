@@ -1,0 +1,71 @@
+"""User densities as modules (include/nuts_amd.h "User densities"; the device-side answer to the reference's `CpuLogpFunc`,
+src/math/cpu_math.rs:885-970): a functor written against the kernel headers, compiled into its own shared object and
+selected with NM_LOGP_MODULE.  The CPU test builds the module (hipcc cross-compiles) and checks its exports; the GPU test
+runs it against the built-in density it re-implements and against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import nuts_rs_amd as N
+from nuts_rs_amd import build as B
+from helpers import assert_bit_exact, run_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "user_density", "my_diag_normal.hpp")
+MODDIR = os.path.join(HERE, "_modules")
+DIM = 40
+
+
+def module_path(dim=DIM):
+    dpl, w = B.pick_tiling(dim)
+    return os.path.join(MODDIR, f"my_diag_normal_dpl{dpl}_w{w}.so")
+
+
+def ensure_module(dim=DIM):
+    out = module_path(dim)
+    srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        os.makedirs(MODDIR, exist_ok=True)
+        B.build_density_module(HEADER, "MyDiagNormal", dim, out)
+    return out
+
+
+def test_module_builds_and_exports():
+    path = ensure_module()
+    m = C.CDLL(path)
+    info = (C.c_uint64 * 4)()
+    m.nm_module_info(info)
+    assert info[1] == N.load_library().nm_abi_version() and (info[2], info[3]) == B.pick_tiling(DIM) == (2, 1)
+    assert hasattr(m, "nm_module_launch")
+    L = N.load_library()
+    d, w = C.c_uint64(), C.c_uint64()
+    for dim in (1, 128, 129, 1024, 1025, 4096):                     # the Python table is the library's
+        assert L.nm_pick_tiling(dim, 0, 0, C.byref(d), C.byref(w)) == 0 and (d.value, w.value) == B.pick_tiling(dim)
+    assert L.nm_pick_tiling(4097, 0, 0, C.byref(d), C.byref(w)) == 4
+
+
+@pytest.mark.gpu
+def test_user_density_module_matches_builtin_and_oracle(oracle):
+    path = ensure_module()
+    prec = np.exp(np.random.default_rng(3).uniform(-3, 3, DIM))
+    s = N.DiagNutsSettings(num_chains=5, seed=77, num_tune=80)
+    x0 = oracle.init_positions_uniform(77, 0, 5, DIM)
+    out = {}
+    for name, logp in (("module", N.LogpSpec.module(DIM, path, prec)), ("builtin", N.LogpSpec.diag_normal(prec))):
+        b = N.ChainBatch(s, logp, 5)
+        b.set_position(x0)
+        out[name] = b.draw_many(140)
+        b.close()
+    assert (out["module"][0].view(np.uint64) == out["builtin"][0].view(np.uint64)).all()
+    pos_o, st_o, _, failed = run_oracle(oracle, s, N.LogpSpec.diag_normal(prec), 5, x0, 140)
+    assert failed == 0
+    assert_bit_exact(out["module"][0], out["module"][1], pos_o, st_o)
+    # a module is tied to one tiling: the engine says so instead of launching the wrong kernel
+    with pytest.raises(N.NutsAmdError) as e:
+        N.ChainBatch(s, N.LogpSpec.module(200, path, np.ones(200)), 5)
+    assert e.value.status == 1 and "tiling" in str(e.value)
+    with pytest.raises(N.NutsAmdError) as e:
+        N.ChainBatch(s, N.LogpSpec.module(DIM, os.path.join(HERE, "no_such_module.so"), prec), 5)
+    assert e.value.status == 1 and "cannot load" in str(e.value)

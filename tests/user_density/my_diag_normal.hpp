@@ -1,0 +1,39 @@
+// A USER density for the module mechanism (include/nuts_amd.h, "User densities"): the diagonal normal again, written
+// the way a user of the engine would write a density of their own.  Interface: init / set_lds / eval.
+//   thread t of the 64*W threads of a chain owns elements d = 2*(m*64*W + t) + j  (m = 0..DPL/2-1, j = 0,1) = elem_index<W>(k)
+//   eval returns logp (a block-wide sum through the Reducer) and fills the gradient tile; padding elements get 0.
+#pragma once
+#include "nuts_kernels.hpp"
+
+struct MyDiagNormal {
+    static constexpr bool kNeedsLdsVector = false;   // no block-visible vector needed
+    const double* prec;
+    double norm;
+    NM_DEV void set_lds(double*) {}
+    template <int W>
+    NM_DEV void init(const double* params, int dim, nm::Reducer<W>& R) {
+        prec = params;
+        double acc = 0.0;
+        for (int m = 0; m < (dim + 128 * W - 1) / (128 * W); ++m)
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * (m * 64 * W + nm::tid()) + j;
+                acc = acc + (d < dim ? nm::dlog(params[d < dim ? d : 0]) : 0.0);
+            }
+        const double log_det_p = R.sum(acc);
+        norm = -0.5 * ((double)dim * nm::ulog(6.283185307179586) - log_det_p);
+    }
+    template <int DPL, int W>
+    NM_DEV double eval(const nm::Tile<DPL>& x, nm::Tile<DPL>& gx, int dim, nm::Reducer<W>& R) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = nm::elem_index<W>(k);
+            const bool valid = d < dim;
+            const double p = valid ? prec[d] : 0.0;
+            const double px = p * x.a[k];
+            gx.a[k] = valid ? -px : 0.0;
+            acc = acc + (valid ? x.a[k] * px : 0.0);
+        }
+        return -0.5 * R.sum(acc) + norm;
+    }
+};
