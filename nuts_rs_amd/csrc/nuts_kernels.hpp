@@ -203,6 +203,18 @@ NM_DEV double2 buf_load2(rsrc_t r, int voff, int soff) {
     v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_double2(__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z));
 }
+// cache-policy bits of the raw buffer intrinsics on gfx940+: sc0 = 1, nt = 2, sc1 = 16
+#ifndef NM_NT_STORES
+#define NM_NT_STORES 1
+#endif
+constexpr int NM_AUX_NT = NM_NT_STORES ? 2 : 0;
+template <int AUX>
+NM_DEV void buf_store2_aux(rsrc_t r, int voff, int soff, double a, double b) {
+    v4u q;
+    q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
+    q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, AUX);
+}
 NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
     v4u q;
     q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
@@ -473,6 +485,14 @@ struct ChainCtx {
     }
     NM_DEV void loadP(Tile<DPL>& t, int s) const { loadR(t, rp, s); }
     NM_DEV void storeP(const Tile<DPL>& t, int s) const { storeR(t, rp, s); }
+    // streaming variants: data that is read back late or never (candidates, per-draw state, edge gradients) should
+    // not push the soon-to-be-re-read end points (F, L) out of the 4 MiB L2 that 128 resident chains share
+    NM_DEV void storeR_nt(const Tile<DPL>& t, rsrc_t r, int so) const {
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m) buf_store2_aux<NM_AUX_NT>(r, voff + m * (64 * W * 16), so, t.a[2 * m], t.a[2 * m + 1]);
+    }
+    NM_DEV void storeP_nt(const Tile<DPL>& t, int s) const { storeR_nt(t, rp, force_sgpr(s * slot_bytes)); }
+    NM_DEV void storeS_nt(const Tile<DPL>& t, int s) const { storeR_nt(t, rs, force_sgpr(s * slot_bytes)); }
     NM_DEV void loadS(Tile<DPL>& t, int s) const { loadR(t, rs, s); }
     NM_DEV void storeS(const Tile<DPL>& t, int s) const { storeR(t, rs, s); }
     // one pair of a slot (U-turn operand streams); so = slot byte offset (wave-uniform)
@@ -494,6 +514,7 @@ struct ChainCtx {
             t.a[2 * m] = q.x; t.a[2 * m + 1] = q.y;
         }
     }
+    NM_DEV void storeRef_nt(const Tile<DPL>& t, SlotRef f) const { storeR_nt(t, f.r, f.so); }
     NM_DEV void storeRef(const Tile<DPL>& t, SlotRef f) const {
         const int so = f.so;
 #pragma unroll
@@ -1078,7 +1099,7 @@ template <int DPL, int W, class Dens>
 NM_DEV int cand_to_pool(ChainCtx<DPL, W, Dens>& C, uint32_t& used, const Tile<DPL>& z) {
     const int p = (int)__builtin_ctz(~used);
     used |= 1u << p;
-    C.storeS(z, slot_C(C.maxdepth_cfg, p));
+    C.storeS_nt(z, slot_C(C.maxdepth_cfg, p));
     return p;
 }
 
@@ -1532,7 +1553,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
         // search), by the divergence statistics and by the host after the launch; in between they are skipped
         // (sc.px_stale) and, should a later draw stay on its initial point, rebuilt from P_Z exactly as here.
         const bool need_x = sc.tuning || t_out + 1 == P.n_draws || P.out_div_start || P.out_div_start_grad;
-        if (need_x) { C.storeP(x, P_X); C.storeP(gx, P_GX); }
+        if (need_x) { C.storeP_nt(x, P_X); C.storeP_nt(gx, P_GX); }
         sc.px_stale = need_x ? 0 : 1;
         C.storeP(z, P_Z); C.storeP(gz, P_GZ);
         sc.logp = R.chosen.logp;
