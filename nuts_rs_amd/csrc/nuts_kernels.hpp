@@ -1153,6 +1153,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 
     uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
     if (s.has_target_integration_time) {                         // src/nuts.rs:300-320
+        // (`as u64` saturates, NaN -> 0; the reference then panics on log2(0) — here that case counts as 1 step)
         double q = __builtin_ceil(s.target_integration_time / sc.step_size);
         uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
         uint64_t fl = 63 - __builtin_clzll(max_steps | 1ull);

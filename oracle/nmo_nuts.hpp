@@ -497,10 +497,17 @@ static inline int nuts_draw(const Ctx& m, State& init, ChaCha8Rng& rng, Hamilton
     tree.left = tree.right = tree.draw = init;
     uint64_t mindepth = options.mindepth, maxdepth = options.maxdepth;
     if (options.has_target_time) {                                                 // :300-320
-        uint64_t max_steps = (uint64_t)std::ceil(options.target_time / h.step_size);
-        uint64_t md = (uint64_t)std::floor(std::log2((double)max_steps));
+        // `as u64` saturates (NaN -> 0).  For max_steps == 0 (a NaN step size, e.g. after a draw of zero leapfrogs)
+        // the reference's `.log2().floor().to_u64().unwrap()` panics; here and on the device that case counts as
+        // max_steps = 1 (depth limits 0), so the chain keeps returning its current point.
+        const double q = std::ceil(options.target_time / h.step_size);
+        uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
+        if (max_steps == 0) max_steps = 1;
+        uint64_t fl = 0;
+        while ((max_steps >> (fl + 1)) != 0) ++fl;                                  // floor(log2)
+        const uint64_t md = fl;
         mindepth = md > options.mindepth ? md : options.mindepth;
-        uint64_t xd = (uint64_t)std::ceil(std::log2((double)max_steps));
+        uint64_t xd = (max_steps & (max_steps - 1)) == 0 ? fl : fl + 1;             // ceil(log2)
         xd = xd > mindepth ? xd : mindepth;
         maxdepth = xd < options.maxdepth ? xd : options.maxdepth;
     }

@@ -310,3 +310,46 @@ def test_multi_wave_tilings_seed_sweep(oracle):
             assert_bit_exact(pos_g, st_g, pos_o, st_o)
         except AssertionError as e:
             raise AssertionError(f"tiling (dpl {dpl}, waves {wpc}) dim {dim} seed {seed} {dens}: {e}") from None
+
+
+def test_random_settings_sweep(oracle):
+    """Randomised sweep over the sampler's option space (tree limits, U-turn switches, extra doublings, target
+    integration time, energy threshold, step-size method / jitter, estimator kind, window schedule) on small
+    problems: every combination must agree with the oracle draw for draw."""
+    rng = np.random.default_rng(2024)
+    for i in range(80):
+        maxdepth = int(rng.integers(1, 8))
+        st = N.StepSizeSettings(
+            target_accept=float(rng.choice([0.6, 0.8, 0.9])), initial_step=float(rng.choice([0.01, 0.1, 1.0])),
+            jitter=None if rng.random() < 0.3 else float(rng.choice([0.05, 0.1, 0.3])),
+            method=int(rng.choice([N.STEP_DUAL_AVERAGE, N.STEP_DUAL_AVERAGE, N.STEP_ADAM, N.STEP_FIXED])),
+            fixed_step_size=float(rng.choice([0.2, 0.7])))
+        a = N.EuclideanAdaptOptions(
+            step_size_settings=st,
+            mass_matrix_options=N.DiagAdaptExpSettings(use_grad_based_estimate=bool(rng.random() < 0.7)),
+            early_window=float(rng.choice([0.1, 0.3, 0.5])), step_size_window=float(rng.choice([0.1, 0.15, 0.3])),
+            mass_matrix_switch_freq=int(rng.choice([10, 30, 80])), early_mass_matrix_switch_freq=int(rng.choice([5, 10])),
+            mass_matrix_update_freq=int(rng.choice([1, 1, 3])), mass_matrix_window_growth=float(rng.choice([1.0, 1.5, 2.0])))
+        kw = dict(seed=int(rng.integers(0, 2 ** 31)), num_tune=int(rng.integers(20, 90)), maxdepth=maxdepth,
+                  mindepth=int(rng.integers(0, maxdepth + 1)) if rng.random() < 0.3 else 0,
+                  check_turning=bool(rng.random() < 0.85), extra_doublings=int(rng.integers(0, 3)) if rng.random() < 0.3 else 0,
+                  max_energy_error=float(rng.choice([1000.0, 1000.0, 2.0, 0.3])),
+                  target_integration_time=None if rng.random() < 0.75 else float(rng.choice([0.5, 2.0, 8.0])),
+                  adapt_options=a)
+        dens = rng.choice(["iid", "diag", "funnel"])
+        dim = int(rng.integers(2, 150))
+        n_chains = int(rng.integers(1, 5))
+        s = N.DiagNutsSettings(num_chains=n_chains, **kw)
+        logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "funnel": lambda: N.LogpSpec.funnel(dim),
+                "diag": lambda: N.LogpSpec.diag_normal(np.exp(np.random.default_rng(i).uniform(-3, 3, dim)))}[dens]()
+        x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
+        n_draws = s.num_tune + 25
+        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws)
+        pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=ex["threads_per_chain"])
+        if failed or not (ex["status"] == 0).all():
+            assert failed == int((ex["status"] != 0).sum()), f"case {i}: init failures differ"
+            continue
+        try:
+            assert_bit_exact(pos_g, st_g, pos_o, st_o)
+        except AssertionError as e:
+            raise AssertionError(f"case {i} ({dens}, dim {dim}, {kw}): {e}") from None
