@@ -353,3 +353,20 @@ def test_random_settings_sweep(oracle):
             assert_bit_exact(pos_g, st_g, pos_o, st_o)
         except AssertionError as e:
             raise AssertionError(f"case {i} ({dens}, dim {dim}, {kw}): {e}") from None
+
+
+def test_more_chains_than_resident_blocks(oracle):
+    """Blocks stride over the chains (chain = block, block + grid, ...): tree scratch belongs to the block, state to the
+    chain.  A grid of 2 or 3 blocks serving 7 chains must give what 7 resident blocks give."""
+    s = N.DiagNutsSettings(num_chains=7, seed=41, num_tune=50)
+    for logp, wpc, dpl in ((N.LogpSpec.funnel(20), 0, 0), (N.LogpSpec.iid_normal(300, 3.0), 2, 8)):
+        x0 = oracle.init_positions_uniform(41, 0, 7, logp.dim)
+        pos_o, st_o, _, failed = run_oracle(oracle, s, logp, 7, x0, 80, gpu_threads=64 * (wpc or 1))
+        assert failed == 0
+        for grid in (2, 3):
+            b = N.ChainBatch(s, logp, 7, grid_blocks=grid, waves_per_chain=wpc, dims_per_lane=dpl)
+            b.set_position(x0)
+            pos_a, st_a = b.draw_many(30)          # two launches: the state of a non-resident chain survives in HBM
+            pos_b, st_b = b.draw_many(50)
+            b.close()
+            assert_bit_exact(np.concatenate([pos_a, pos_b]), np.concatenate([st_a, st_b]), pos_o, st_o)
