@@ -465,6 +465,8 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
         const uint64_t pos0 = rng.pos;
         const uint64_t b0 = pos0 >> 4;
         const int nb = (int)(((pos0 + 2ull * (uint64_t)nc - 1ull) >> 4) - b0) + 1;
+        uint64_t* const lmask = reinterpret_cast<uint64_t*>(small_cache + 256);    // [2][P] bit masks, see step 3
+        if (lane < 2 * P) lmask[lane] = 0ull;
         for (int b = tid(); b < nb; b += nthreads) {          // 1. the words of all cells
             uint32_t out[16];
             chacha8_block(rng.key, b0 + (uint64_t)b, 0ull, out);
@@ -550,7 +552,44 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
         double flx = 0.0;
         bool open = true;
         const uint64_t scalar_mask = __ballot(sp_scalar);
-        for (int g = 0; g < nlist; ++g) {
+        // Common case (97 %): every rejected cell is an event of its own — none needs the scalar routine, none lies in
+        // the cells an earlier one swallows, the list is complete.  Then nothing is sequential: the cells swallowed
+        // before event g are a prefix sum over the lanes (r is 1 or 2: two ballots), its sample index follows, and the
+        // per-pass masks are OR-ed together in LDS by the event lanes.
+        const int rr = lane < nlist ? sp_r : 0;
+        const uint64_t m1 = __ballot(rr == 1), m2 = __ballot(rr == 2);
+        const int s_before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
+                             2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+        const int prev_end = __builtin_amdgcn_update_dpp(-1, fcell + rr, 0x138, 0xf, 0xf, false);     // lane g-1's last swallowed cell
+        const bool chained = lane >= 1 && lane < nlist && fcell <= prev_end;
+        const bool fast = scalar_mask == 0ull && nrej <= nlist && __ballot(chained) == 0ull;
+        bool ev_active = false;
+        int ev_j = 0;
+        if (fast) {
+            ev_j = fcell - s_before;                          // sample index of event g inside the chunk
+            ev_active = lane < nlist && ev_j < need;          // events behind the last sample wanted are never reached
+            const uint64_t am = __ballot(ev_active);
+            const int s_act = (int)__builtin_popcountll(m1 & am) + 2 * (int)__builtin_popcountll(m2 & am);
+            j = (nc - s_act) < need ? (nc - s_act) : need;
+            cur = j + s_act;
+            if (ev_active) {                                  // cells [f, f+1+r) no fast-path sample, [f+1, f+1+r) swallowed
+                const int q = fcell >> 6, off = fcell & 63;
+                const uint64_t nk0 = ((1ull << (rr + 1)) - 1ull) << off;
+                const uint64_t sw0 = off == 63 ? 0ull : (((1ull << rr) - 1ull) << (off + 1));
+                (void)__hip_atomic_fetch_or(&lmask[q], sw0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(&lmask[P + q], nk0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int spill = off + rr + 1 - 64;          // cells of the range that belong to the next pass
+                if (spill > 0) {
+                    const uint64_t nx = (1ull << spill) - 1ull;
+                    (void)__hip_atomic_fetch_or(&lmask[q + 1], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_or(&lmask[P + q + 1], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            sw = lane < P ? lmask[lane] : 0ull;
+            nk = lane < P ? lmask[P + lane] : 0ull;
+            open = false;
+        }
+        for (int g = 0; g < nlist && !fast; ++g) {
             const int f = lane_get(fcell, g);
             if (f < cur) continue;                            // swallowed by an earlier slow path
             if (j + (f - cur) >= need) { cur += need - j; j = need; open = false; break; }
@@ -585,7 +624,7 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
             cur = f + 1 + r;
             if (j >= need || cur >= nc) { open = false; break; }
         }
-        if (nrej > nlist) open = false;                       // more rejections than list slots: the rest next chunk
+        if (nrej > nlist && !fast) open = false;              // more rejections than list slots: the rest next chunk
         if (open && cur < nc) {                               // tail after the last event
             const int take = (nc - cur) < (need - j) ? (nc - cur) : (need - j);
             j += take; cur += take;
@@ -610,8 +649,8 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
                 *dst = xr[p];
                 base += (int)__builtin_popcount(s_lo) + (int)__builtin_popcount(s_hi);
             }
-            double* dst = lane < nf ? samp + (produced + flj) : dummy;
-            *dst = flx;
+            double* dst = fast ? (ev_active ? samp + (produced + ev_j) : dummy) : (lane < nf ? samp + (produced + flj) : dummy);
+            *dst = fast ? sp_x : flx;
         }
         produced += j;
         __syncthreads();
