@@ -1613,11 +1613,17 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
 #ifndef NM_OCC_DPL4
 #define NM_OCC_DPL4 1
 #endif
+#ifndef NM_OCC_DPL8_W2
+#define NM_OCC_DPL8_W2 2   // (8 doubles, 2 waves): 1.62e11 on K2 against 1.81e11 for (16, 1) — used only on request
+#endif
 #ifndef NM_OCC_DPL8
 #define NM_OCC_DPL8 2    // <= 256 VGPRs (72 spilled): dims 257..512 +18 % (two chains per SIMD hide each other's latency)
 #endif
 template <int DPL, int W>
-constexpr int draw_min_waves() { return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DPL == 4 ? NM_OCC_DPL4 : DPL == 8 ? NM_OCC_DPL8 : 1; }
+constexpr int draw_min_waves() {
+    if (W == 2 && DPL == 8) return NM_OCC_DPL8_W2;
+    return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DPL == 4 ? NM_OCC_DPL4 : DPL == 8 ? NM_OCC_DPL8 : 1;
+}
 
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
