@@ -718,7 +718,7 @@ NM_DEV double sum_ln_tile(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& t) {
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         bool valid = C.elem(k) < C.dim;
-        acc = acc + (valid ? dlog(valid ? t.a[k] : 1.0) : 0.0);
+        acc = acc + (valid ? dlog_impl<false>(valid ? t.a[k] : 1.0) : 0.0);   // inlined: the DPL evaluations interleave
     }
     return C.red.sum(acc);
 }
@@ -874,6 +874,19 @@ NM_DEV void running_variance_add(ChainCtx<DPL, W, Dens>& C, int slot_mean, int s
     C.storeP(var, slot_var);
 }
 
+// the same on estimators held in registers
+template <int DPL>
+NM_DEV void running_variance_add_regs(Tile<DPL>& mean, Tile<DPL>& var, uint64_t new_count, const Tile<DPL>& value) {
+    if (new_count == 1) { mean = value; return; }
+    const double diff_scale = 1.0 / (double)new_count;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        double diff = value.a[k] - mean.a[k];
+        mean.a[k] = mean.a[k] + diff * diff_scale;
+        var.a[k] = var.a[k] + diff * diff;
+    }
+}
+
 // writes sigma / inv_sigma / mu (HBM + the LDS copy of the resident chain), logdet, id
 template <int DPL, int W, class Dens>
 NM_DEV void commit_mass_matrix(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& sig, const Tile<DPL>& isig, const Tile<DPL>& mu) {
@@ -909,17 +922,13 @@ NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x,
 // Strategy::adapt -> update_diag_draw_grad / update_diag_draw (reference adapt/diagonal.rs:161-196,
 // diagonal.rs:85-131, cpu_math.rs:633-708).  Returns did_change.
 template <int DPL, int W, class Dens>
-NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C) {
+NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& dm, const Tile<DPL>& dv, const Tile<DPL>& gm,
+                              const Tile<DPL>& gv) {     // the foreground estimators (draw mean / var, grad mean / var)
     if (C.sc.cnt_fg < 3) return false;
-    Tile<DPL> sig, isig, mu, dm, dv;
+    Tile<DPL> sig, isig, mu;
     C.load(sig, C.lsig);
     C.loadP(isig, P_ISIG);
-    C.loadP(dm, E_DM);
-    C.loadP(dv, E_DV);
     if (C.P.s.use_grad_based_estimate) {
-        Tile<DPL> gm, gv;
-        C.loadP(gm, E_GM);
-        C.loadP(gv, E_GV);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             bool valid = C.elem(k) < C.dim;
@@ -986,13 +995,21 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
         if (!is_early && draw == C.P.early_end)
             sc.current_window_size = sc.current_window_size > sc.cnt_bg ? sc.current_window_size : sc.cnt_bg;
         const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
+        // The four estimators (foreground / background x draws / gradients: 8 vectors) are read once, updated,
+        // switched and used for the new mass matrix in registers, and written back once: one HBM round trip per
+        // draw instead of one per add_sample / copy / adapt step.
+        Tile<DPL> fdm, fdv, fgm, fgv, bdm, bdv, bgm, bgv;
+        C.loadP(fdm, E_DM); C.loadP(fdv, E_DV); C.loadP(fgm, E_GM); C.loadP(fgv, E_GV);
+        C.loadP(bdm, B_DM); C.loadP(bdv, B_DV); C.loadP(bgm, B_GM); C.loadP(bgv, B_GV);
+        bool dirty = false;
         if (is_good) {                                           // update_estimators (adapt/diagonal.rs:134-141)
             sc.cnt_fg += 1;
             sc.cnt_bg += 1;
-            running_variance_add(C, E_DM, E_DV, sc.cnt_fg, x);
-            running_variance_add(C, E_GM, E_GV, sc.cnt_fg, gx);
-            running_variance_add(C, B_DM, B_DV, sc.cnt_bg, x);
-            running_variance_add(C, B_GM, B_GV, sc.cnt_bg, gx);
+            running_variance_add_regs(fdm, fdv, sc.cnt_fg, x);
+            running_variance_add_regs(fgm, fgv, sc.cnt_fg, gx);
+            running_variance_add_regs(bdm, bdv, sc.cnt_bg, x);
+            running_variance_add_regs(bgm, bgv, sc.cnt_bg, gx);
+            dirty = true;
         }
         const bool could_switch = sc.cnt_bg >= switch_freq;
         uint64_t next_window_size;
@@ -1007,20 +1024,21 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
         const bool is_late = next_window_size + draw > C.P.final_step_size_window;
         bool force_update = false;
         if (could_switch && !is_late) {                          // switch (adapt/diagonal.rs:143-148)
-            copy_slot(C, E_DM, B_DM); copy_slot(C, E_DV, B_DV);
-            copy_slot(C, E_GM, B_GM); copy_slot(C, E_GV, B_GV);
+            fdm = bdm; fdv = bdv; fgm = bgm; fgv = bgv;
             sc.cnt_fg = sc.cnt_bg;
             sc.cnt_bg = 0;
-            Tile<DPL> zero;
 #pragma unroll
-            for (int k = 0; k < DPL; ++k) zero.a[k] = 0.0;
-            C.storeP(zero, B_DM); C.storeP(zero, B_DV);
-            C.storeP(zero, B_GM); C.storeP(zero, B_GV);
+            for (int k = 0; k < DPL; ++k) { bdm.a[k] = 0.0; bdv.a[k] = 0.0; bgm.a[k] = 0.0; bgv.a[k] = 0.0; }
             force_update = true;
+            dirty = true;
             if (!is_early) sc.current_window_size = next_window_size;
         }
+        if (dirty) {                                             // written back before the mass matrix needs registers
+            C.storeP(bdm, B_DM); C.storeP(bdv, B_DV); C.storeP(bgm, B_GM); C.storeP(bgv, B_GV);
+            C.storeP(fdm, E_DM); C.storeP(fdv, E_DV); C.storeP(fgm, E_GM); C.storeP(fgv, E_GV);
+        }
         bool did_change = false;
-        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = mass_matrix_adapt(C);
+        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
         if (did_change) sc.last_update = draw;
         update_estimator(C, is_late);
         if (did_change & (sc.has_initial_mass_matrix != 0)) {

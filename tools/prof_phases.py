@@ -37,22 +37,25 @@ def main():
     L = _lib.load()
     L.nm_debug_read_prof.argtypes = [C.c_void_p, C.c_void_p]
     buf = np.zeros(32, dtype=np.uint64)
+    L.nm_debug_read_prof(b._h, buf.ctypes.data)      # discard what set_position's kernel left there
     b.draw_device(tune)
+    c0 = b.counters()
     L.nm_debug_read_prof(b._h, buf.ctypes.data)
+    report("warm-up", buf, tune * (-(-chains // 1024) if chains > 1024 else 1), c0["kernel_ms"], c0["total_leapfrogs"] / tune / chains)
     b.reset_counters()
     b.draw_device(draws)
     c = b.counters()
     L.nm_debug_read_prof(b._h, buf.ctypes.data)
-    nblk_chains = -(-chains // 1024) if chains > 1024 else 1          # chains block 0 handled (grid = resident blocks)
-    ndraw = draws * nblk_chains
+    report("sampling", buf, draws * (-(-chains // 1024) if chains > 1024 else 1), c["kernel_ms"], c["total_leapfrogs"] / draws / chains)
+
+
+def report(title, buf, ndraw, ms, steps_per_draw):
     total = buf.sum()
-    ms = c["kernel_ms"]
     cyc_per_us = total / (ms * 1e3)                                   # block 0 is busy for the whole launch
-    print(f"kernel {ms:.2f} ms, block 0: {ndraw} draws, {total} cycles -> {cyc_per_us:.0f} cycles/us")
+    print(f"== {title}: kernel {ms:.2f} ms, block 0: {ndraw} draws, {total} cycles -> {cyc_per_us:.0f} cycles/us, {steps_per_draw:.2f} steps/draw")
     for k in range(32):
         if buf[k]:
             print(f"  [{k}] {NAMES.get(k, '?'):40s} {buf[k] / ndraw / cyc_per_us:8.2f} us/draw  ({100.0 * buf[k] / total:5.1f} %)")
-    print("steps/draw", c["total_leapfrogs"] / draws / chains)
 
 
 if __name__ == "__main__":
