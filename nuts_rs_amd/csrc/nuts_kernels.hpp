@@ -1629,8 +1629,8 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
 #define NM_OCC_DPL2 4    // <= 128 VGPRs: K4 +17 %, K3 +6 % (tools/bench_configs.py); DPL 4 at 3 waves: no gain
 #endif
 #ifndef NM_OCC_DPL4
-#define NM_OCC_DPL4 1
-#endif
+#define NM_OCC_DPL4 2    // the DPL 4 kernels sit at 252..262 VGPRs: pin them below 256 (neutral for the elementwise densities,
+#endif                  // x1.6 for the full-precision normal, whose GEMV needs the second wave to hide L2 latency)
 #ifndef NM_OCC_DPL8_W2
 #define NM_OCC_DPL8_W2 2   // (8 doubles, 2 waves): 1.62e11 on K2 against 1.81e11 for (16, 1) — used only on request
 #endif
