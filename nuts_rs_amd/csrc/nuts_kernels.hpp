@@ -120,12 +120,6 @@ struct KParams {
     const double* x0;            // init kernel: [n_chains][dim]
 };
 
-// Also run the top-level U-turn test of a finished sub-tree before its last merges?  Measured: no (118 spilled registers
-// at DPL 16, K2 1.57e11 instead of 1.68e11), and the <8,2> tiling then disagrees with the oracle on one test seed for a
-// reason not yet understood — kept only as an experiment switch.
-#ifndef NM_TOP_EARLY
-#define NM_TOP_EARLY 0
-#endif
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
 #ifndef NM_PROF
 #define NM_PROF 0
@@ -856,25 +850,8 @@ NM_DEV void update_estimator(ChainCtx<DPL, W, Dens>& C, bool late) {
     sc.da_count += 1;
 }
 
-// RunningVariance::add_sample (reference adapt/diagonal.rs:31-44, array_update_variance cpu_math.rs:605-631)
-template <int DPL, int W, class Dens>
-NM_DEV void running_variance_add(ChainCtx<DPL, W, Dens>& C, int slot_mean, int slot_var, uint64_t new_count, const Tile<DPL>& value) {
-    if (new_count == 1) { C.storeP(value, slot_mean); return; }
-    const double diff_scale = 1.0 / (double)new_count;
-    Tile<DPL> mean, var;
-    C.loadP(mean, slot_mean);
-    C.loadP(var, slot_var);
-#pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-        double diff = value.a[k] - mean.a[k];
-        mean.a[k] = mean.a[k] + diff * diff_scale;
-        var.a[k] = var.a[k] + diff * diff;
-    }
-    C.storeP(mean, slot_mean);
-    C.storeP(var, slot_var);
-}
-
-// the same on estimators held in registers
+// RunningVariance::add_sample (reference adapt/diagonal.rs:31-44, array_update_variance cpu_math.rs:605-631) on
+// estimators held in registers
 template <int DPL>
 NM_DEV void running_variance_add_regs(Tile<DPL>& mean, Tile<DPL>& var, uint64_t new_count, const Tile<DPL>& value) {
     if (new_count == 1) { mean = value; return; }
@@ -965,13 +942,6 @@ NM_DEV bool mass_matrix_adapt(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& dm, co
     }
     commit_mass_matrix(C, sig, isig, mu);
     return true;
-}
-
-template <int DPL, int W, class Dens>
-NM_DEV void copy_slot(ChainCtx<DPL, W, Dens>& C, int dst, int src) {
-    Tile<DPL> t;
-    C.loadP(t, src);
-    C.storeP(t, dst);
 }
 
 // GlobalStrategy::adapt (reference src/adapt_strategy.rs:121-222).  x, gx = chosen draw.
@@ -1280,7 +1250,6 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     return (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
                 }
         };
-        bool top_turning = false, top_done = false;
         if (depth == 0) {
             // a single leaf from the initial point, which E has held since initialize_trajectory: E -> O
 #if !NM_TRIM_FIRST
@@ -1390,9 +1359,6 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
                         if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
                     }
-#if NM_TOP_EARLY
-                    if (turn_bits == 0 && n + 2 == nleaf) { top_turning = top_level_turning(); top_done = true; }
-#endif
                 }
                 NM_MARK(C, 21)
                 // ---- level-1 merge: A = {E}, B = {O}
@@ -1445,12 +1411,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         // ---- `other` is complete (its last leaf is O): top-level turning tests, then merge into the main tree
         NM_MARK(C, 25)
         bool turning = false;
-#if NM_TOP_EARLY && NM_TRIM_FIRST
-        // every doubling of depth >= 1 has its flag from the pair loop; only the single-leaf doubling is tested here
-        if (check) turning = top_done ? top_turning : turning_regs(E, O, fwd, C.red);
-#else
-        if (check) turning = top_done ? top_turning : top_level_turning();
-#endif
+        if (check) turning = top_level_turning();
         NM_MARK(C, 26)
         double total;
         const bool take = merge_weights(C, log_size, sub_log_size, true, total, fatal);
