@@ -23,6 +23,13 @@ namespace nm {
 NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+// Block-wide synchronisation point.  With one wavefront per block the LDS pipeline is already in order (a lane sees
+// what another lane of its wave wrote earlier), so nothing has to be waited for: __syncthreads() would still stall
+// on every outstanding global store (s_waitcnt vmcnt(0)) — a compiler-level barrier is all that is needed.
+NM_DEV void block_sync(bool single_wave) {
+    if (single_wave) asm volatile("" ::: "memory");
+    else __syncthreads();
+}
 NM_DEV int tid() { return (int)threadIdx.x; }          // thread within the chain's block (64*W threads)
 // wave index inside the block; IS wave-uniform, but anything derived from threadIdx is divergent to the compiler
 // unless it goes through readfirstlane (guide T20) — and values loaded through a "divergent" index poison everything
@@ -316,7 +323,7 @@ struct DevRng {
     }
     NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)cap; }
     NM_DEV void refill() {
-        __syncthreads();
+        block_sync(blockDim.x == 64);
         base = pos & ~15ull;
         cap = RNG_CACHE_WORDS;
         if (tid() < RNG_CACHE_WORDS / 16) {
@@ -328,7 +335,7 @@ struct DevRng {
             dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
             dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
         }
-        __syncthreads();
+        block_sync(blockDim.x == 64);
     }
     NM_DEV uint32_t next_u32() {
         if (!has(1)) refill();
@@ -456,7 +463,7 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
     const int lane = lane_id();
     uint32_t* const small_cache = rng.cache;
     int produced = 0;
-    __syncthreads();
+    block_sync(nthreads == 64);
     while (produced < count) {
         const int need = count - produced;
         // cells of this chunk: the samples wanted plus room for the cells the slow paths will swallow (~2 % of them)
@@ -476,7 +483,7 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
             dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
             dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
         }
-        __syncthreads();
+        block_sync(nthreads == 64);
         NM_MARK_F(8)
         rng.cache = wbuf; rng.base = b0 << 4; rng.cap = (uint32_t)nb * 16u;     // the slow path reads the same words
         const int w0 = (int)(pos0 - rng.base);
@@ -653,7 +660,7 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
             *dst = fast ? sp_x : flx;
         }
         produced += j;
-        __syncthreads();
+        block_sync(nthreads == 64);
         NM_MARK_F(11)
     }
     // Hand the already generated words behind the final position to the small cache: the tree's direction bits
@@ -667,7 +674,7 @@ NM_DEV void fill_standard_normals_bulk(DevRng& rng, uint32_t* wbuf, double* samp
         static_assert(PER_LANE == 8, "copy below moves 8 words per lane");
         const uint32_t o = (uint32_t)lane * PER_LANE;
         const uint4 q0 = *reinterpret_cast<const uint4*>(src + o), q1 = *reinterpret_cast<const uint4*>(src + o + 4);
-        __syncthreads();                                      // every wave has read its words before any wave stores
+        block_sync(nthreads == 64);                                      // every wave has read its words before any wave stores
         *reinterpret_cast<uint4*>(small_cache + o) = q0;
         *reinterpret_cast<uint4*>(small_cache + o + 4) = q1;
         rng.cache = small_cache; rng.base = nbase; rng.cap = avail;

@@ -325,13 +325,13 @@ struct MvnPrec {
     NM_DEV void set_lds(double* lds) { xs = lds; }
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
-        __syncthreads();                                   // the previous evaluation's readers are done
+        block_sync(W == 1);                                // the previous evaluation's readers are done
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             const int d = elem_index<W>(k);
             xs[d] = d < dim ? x.a[k] : 0.0;
         }
-        __syncthreads();
+        block_sync(W == 1);
         double y[DPL];
 #pragma unroll
         for (int k = 0; k < DPL; ++k) y[k] = 0.0;
@@ -694,7 +694,7 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
         v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
 #endif
-    __syncthreads();
+    block_sync(W == 1);
 }
 
 template <int DPL, int W>
