@@ -239,6 +239,8 @@ struct nm_engine {
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
     double* d_x0 = nullptr;
+    void* staging[10] = {};                 // device staging of the *_to_host calls, one per output array, grow-only
+    size_t staging_bytes[10] = {};
     void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
     module_launch_fn module_launch = nullptr;
     hipStream_t stream = nullptr;
@@ -252,6 +254,7 @@ struct nm_engine {
 static void engine_free(nm_engine* e) {
     if (!e) return;
     if (e->module_handle) dlclose(e->module_handle);
+    for (void* q : e->staging) if (q) (void)hipFree(q);
     if (e->d_pvec) (void)hipFree(e->d_pvec);
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
@@ -491,17 +494,25 @@ extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, c
         {h_out->d_divergence_end, (void**)&d.d_divergence_end, vec_bytes, true},
     };
     nm_status st = NM_OK;
+    int idx = 0;
     for (Item& it : items) {
+        const int k = idx++;
         if (!it.host || !it.bytes) continue;
-        hipError_t er = hipMalloc(it.dev, it.bytes);
+        hipError_t er = hipSuccess;
+        if (e->staging_bytes[k] < it.bytes) {              // a controller calls this once per chunk of draws: keep the buffers
+            if (e->staging[k]) (void)hipFree(e->staging[k]);
+            e->staging[k] = nullptr; e->staging_bytes[k] = 0;
+            er = hipMalloc(&e->staging[k], it.bytes);
+            if (er == hipSuccess) e->staging_bytes[k] = it.bytes;
+        }
+        *it.dev = e->staging[k];
         if (er == hipSuccess && it.event) er = hipMemsetAsync(*it.dev, 0xFF, it.bytes, e->stream);   // all-ones = NaN
-        if (er != hipSuccess) { st = fail(NM_ERR_HIP, "device buffer of %zu bytes: %s", it.bytes, hipGetErrorString(er)); break; }
+        if (er != hipSuccess) { *it.dev = nullptr; st = fail(NM_ERR_HIP, "device buffer of %zu bytes: %s", it.bytes, hipGetErrorString(er)); break; }
     }
     if (st == NM_OK) st = nm_engine_draw_ex(e, n_draws, &d);
     for (Item& it : items) {
         if (st == NM_OK && *it.dev && hipMemcpy(it.host, *it.dev, it.bytes, hipMemcpyDeviceToHost) != hipSuccess)
             st = fail(NM_ERR_HIP, "copy of a result array to the host failed");
-        if (*it.dev) (void)hipFree(*it.dev);
     }
     if (st != NM_OK) return st;
     // surface chain failures the way Chain::draw's Result does
