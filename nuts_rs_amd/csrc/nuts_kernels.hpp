@@ -1275,11 +1275,6 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_LEAF_ACCOUNT(O, E, wE)
                 if (stop != STOP_NONE) break;
-                if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {     // at depth 1 leaf 0 is still in E when it is needed (top-level tests)
-                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
-                    C.storeS(E.z, fs);
-                    C.storeS(E.v, fs + 1);
-                }
                 // ---- odd leaf n + 1
                 NM_MARK(C, 18)
                 leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
@@ -1386,6 +1381,14 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 }
                 if (stop != STOP_NONE) break;
                 NM_MARK(C, 22)
+                // F: the even leaf (still in E) is the first leaf of the sub-trees of level >= 2 that start at n.  Stored here,
+                // after the merges: every call of the merge arithmetic waits for all stores in flight, and nothing reads F
+                // before the next pair.  (At depth 1 leaf 0 is still in E when the top-level tests need it.)
+                if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {
+                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
+                    C.storeS(E.z, fs);
+                    C.storeS(E.v, fs + 1);
+                }
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
                     if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
