@@ -1,6 +1,8 @@
 """GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the same seeds — draw for draw,
 bit for bit (positions and every sampler statistic).  north_star's tolerance is 1e-9 relative; the engine is
 built to do better: identical arithmetic contract => identical bits => identical discrete decisions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -317,7 +319,7 @@ def test_random_settings_sweep(oracle):
     integration time, energy threshold, step-size method / jitter, estimator kind, window schedule) on small
     problems: every combination must agree with the oracle draw for draw."""
     rng = np.random.default_rng(2024)
-    for i in range(80):
+    for i in range(int(os.environ.get("NM_SWEEP_CASES", "80"))):
         maxdepth = int(rng.integers(1, 8))
         st = N.StepSizeSettings(
             target_accept=float(rng.choice([0.6, 0.8, 0.9])), initial_step=float(rng.choice([0.01, 0.1, 1.0])),
@@ -336,15 +338,25 @@ def test_random_settings_sweep(oracle):
                   max_energy_error=float(rng.choice([1000.0, 1000.0, 2.0, 0.3])),
                   target_integration_time=None if rng.random() < 0.75 else float(rng.choice([0.5, 2.0, 8.0])),
                   adapt_options=a)
-        dens = rng.choice(["iid", "diag", "funnel"])
-        dim = int(rng.integers(2, 150))
+        dens = rng.choice(["iid", "diag", "funnel", "mvn", "schools"], p=[0.3, 0.3, 0.2, 0.1, 0.1])
+        dim = 10 if dens == "schools" else int(rng.integers(2, 40)) if dens == "mvn" else int(rng.integers(2, 150))
         n_chains = int(rng.integers(1, 5))
         s = N.DiagNutsSettings(num_chains=n_chains, **kw)
-        logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "funnel": lambda: N.LogpSpec.funnel(dim),
+
+        def mvn():
+            a_ = np.random.default_rng(i).normal(size=(dim, dim))
+            p_ = a_ @ a_.T / dim + np.eye(dim)
+            return N.LogpSpec.mvn_precision((p_ + p_.T) / 2)
+        logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "funnel": lambda: N.LogpSpec.funnel(dim), "mvn": mvn,
+                "schools": N.LogpSpec.eight_schools,
                 "diag": lambda: N.LogpSpec.diag_normal(np.exp(np.random.default_rng(i).uniform(-3, 3, dim)))}[dens]()
+        # now and then a wider tiling than the dim needs (more doubles per lane, or several waves per chain)
+        dpl, wpc = 0, 0
+        if dens != "schools" and rng.random() < 0.3:
+            dpl, wpc = [(4, 1), (8, 1), (16, 1), (8, 2), (4, 4)][int(rng.integers(0, 5))]
         x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
         n_draws = s.num_tune + 25
-        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws)
+        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl, waves_per_chain=wpc)
         pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=ex["threads_per_chain"])
         if failed or not (ex["status"] == 0).all():
             assert failed == int((ex["status"] != 0).sum()), f"case {i}: init failures differ"
