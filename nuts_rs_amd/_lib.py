@@ -56,7 +56,8 @@ class NmLogpSpec(C.Structure):
 
 class NmEngineConfig(C.Structure):
     _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
-                ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("lane_groups", C.c_uint64),
+                ("reserved", C.c_uint64 * 2)]
 
 
 STATS_DTYPE = np.dtype([

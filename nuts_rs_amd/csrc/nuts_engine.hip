@@ -234,6 +234,7 @@ struct nm_engine {
     double* d_pvec = nullptr;     // [n_chains][NUM_PSLOT][dpad]
     double* d_svec = nullptr;     // [n_waves][nsslot][dpad]
     unsigned n_waves = 0;         // resident waves of the draw kernel = its grid
+    unsigned group_grid = 0;      // > 0: the 8-lanes-per-chain kernel (nuts_group.hpp) may serve post-warm-up launches
     ChainScalars* d_sc = nullptr;
     unsigned long long* d_prof = nullptr;   // 32 cycle counters for NM_PROF builds
     double* d_zig = nullptr;      // x[257] then f[257]
@@ -331,9 +332,18 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
+        // small chains: 8 lanes per chain, 8 chains per wave (nuts_group.hpp) once the warm-up is over
+        const bool group_density = logp->kind == NM_LOGP_IID_NORMAL || logp->kind == NM_LOGP_DIAG_NORMAL || logp->kind == NM_LOGP_EIGHT_SCHOOLS;
+        if (cfg.lane_groups != 1 && group_density && logp->dim <= 16 && dpl == 2 && wv == 1 && s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains >= 64 || cfg.lane_groups == 2)) {
+            int gocc = 0;
+            E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, nullptr));
+            uint64_t gres = (uint64_t)(gocc > 0 ? gocc : 1) * (uint64_t)(cus > 0 ? cus : 1);
+            const uint64_t need = (n_chains + grp::GPW - 1) / grp::GPW;
+            e->group_grid = (unsigned)(need < gres ? need : gres);
+        }
     }
     const size_t pvec_bytes = (size_t)n_chains * NUM_PSLOT * dpad * sizeof(double);
-    const size_t svec_bytes = (size_t)e->n_waves * nsslot * dpad * sizeof(double);
+    const size_t svec_bytes = (size_t)(e->n_waves > e->group_grid ? e->n_waves : e->group_grid) * nsslot * dpad * sizeof(double);
     E_TRY(hipMalloc(&e->d_pvec, pvec_bytes));
     E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_svec, svec_bytes));
@@ -443,7 +453,14 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
+    // every chain is past its warm-up (all chains have drawn draws_total times) and only positions / scalar statistics
+    // are wanted: the small-chain kernel computes the same draws with 8 chains per wavefront
+    const bool only_basic = !out->d_gradient && !out->d_transformed_position && !out->d_transformed_gradient && !out->d_mass_matrix_inv &&
+                            !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
+    if (e->group_grid && only_basic && e->draws_total >= e->s.num_tune)
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
+    else
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
     e->kernel_launches += 1;

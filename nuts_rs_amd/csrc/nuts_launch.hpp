@@ -2,15 +2,30 @@
 // are compiled in their own .hip file so the build parallelises).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "nuts_kernels.hpp"
+#include "nuts_group.hpp"
 
 namespace nm {
-enum KernelKind { K_INIT, K_DRAW, K_QUERY };   // K_QUERY: resident blocks per CU of the draw kernel
+enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
+                  K_GROUP_DRAW, K_GROUP_QUERY };  // the 8-lanes-per-chain kernel of nuts_group.hpp (dim <= 16)
 
+// the 8-lanes-per-chain kernel exists for the densities that have a group form (nuts_group.hpp)
+template <class Dens>
+inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
+    if constexpr (!std::is_void<typename grp::GroupDensity<Dens>::type>::value) {
+        if (kind == K_GROUP_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, grp::nuts_group_draw_kernel<Dens>, 64, 0);
+        hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens>), dim3(grid_blocks), dim3(64), 0, stream, P);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
 // grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
 // hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
 template <int DPL, int W, class Dens>
 inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
+    if (kind == K_GROUP_DRAW || kind == K_GROUP_QUERY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
     if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
     dim3 grid(grid_blocks), block(64 * W);
     if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);

@@ -177,7 +177,7 @@ class ChainBatch:
 
     def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
                  chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0, waves_per_chain: int = 0,
-                 grid_blocks: int = 0):
+                 grid_blocks: int = 0, lane_groups: int = 0):
         self.settings = settings
         self.logp = logp
         self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
@@ -186,7 +186,7 @@ class ChainBatch:
         cfg = NmEngineConfig()
         L.nm_engine_config_default(C.byref(cfg))
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
-        cfg.waves_per_chain, cfg.grid_blocks = waves_per_chain, grid_blocks
+        cfg.waves_per_chain, cfg.grid_blocks, cfg.lane_groups = waves_per_chain, grid_blocks, lane_groups
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()
