@@ -249,6 +249,7 @@ struct nm_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     uint64_t steps_base = 0, draws_total = 0;
+    uint64_t draws_launched = 0;            // draws every chain has been asked for since creation (never reset)
     bool pending_timing = false;
 };
 
@@ -453,11 +454,11 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    // every chain is past its warm-up (all chains have drawn draws_total times) and only positions / scalar statistics
+    // every chain is past its warm-up (all chains have drawn draws_launched times) and only positions / scalar statistics
     // are wanted: the small-chain kernel computes the same draws with 8 chains per wavefront
     const bool only_basic = !out->d_gradient && !out->d_transformed_position && !out->d_transformed_gradient && !out->d_mass_matrix_inv &&
                             !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
-    if (e->group_grid && only_basic && e->draws_total >= e->s.num_tune)
+    if (e->group_grid && only_basic && e->draws_launched >= e->s.num_tune)
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
     else
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
@@ -465,6 +466,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     e->pending_timing = true;
     e->kernel_launches += 1;
     e->draws_total += n_draws;
+    e->draws_launched += n_draws;
     return NM_OK;
 }
 extern "C" nm_status nm_engine_synchronize(nm_engine* e) {

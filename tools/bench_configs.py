@@ -1,6 +1,6 @@
 """Throughput and tree statistics of BASELINE.json's other configurations on one GPU (K1 for scale).
 
-  python tools/bench_configs.py [k3|k4|k5|k1|all] [--draws N]
+  python tools/bench_configs.py [k3|k4|k5|k1|all] [--draws N] [--chains C] [--lane-groups 0|1|2]
 
 Prints one JSON line per configuration: M1 = leapfrog-steps*dims/s and M2 = draws/s/chain for the post-warm-up
 draws, depth histogram, divergence rate, and the "lane utilisation" SURVEY asks for on the ragged config
@@ -35,12 +35,12 @@ CONFIGS = {
 }
 
 
-def run(key, draws):
+def run(key, draws, chains=0, lane_groups=0):
     cfg = CONFIGS[key]
     logp = cfg["logp"]()
-    C, D = cfg["chains"], logp.dim
+    C, D = chains or cfg["chains"], logp.dim
     s = N.DiagNutsSettings(num_chains=C, seed=20260928, num_tune=cfg["tune"], num_draws=draws)
-    b = N.ChainBatch(s, logp, C)
+    b = N.ChainBatch(s, logp, C, lane_groups=lane_groups)
     b.set_position(b.init_positions_uniform())
     t = time.time()
     _, st_w = b.draw_many(cfg["tune"], positions=False)
@@ -59,7 +59,7 @@ def run(key, draws):
     util = float((st["n_steps"].sum(axis=1) / (C * st["n_steps"].max(axis=1))).mean())
     out = {
         "config": cfg["name"], "chains": C, "dim": D, "draws": draws, "threads_per_chain": b.threads_per_chain(),
-        "dims_per_lane": b.dims_per_lane(),
+        "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups,
         "M1_steps_dims_per_s": steps * D / dt, "M2_draws_per_s_per_chain": draws / dt,
         "leapfrogs_per_s": steps / dt, "kernel_ms": c["kernel_ms"], "warmup_s": t_warm,
         "warmup_divergence_rate": float(st_w["diverging"].mean()),
@@ -77,4 +77,5 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "all"
     draws = int(sys.argv[sys.argv.index("--draws") + 1]) if "--draws" in sys.argv else 200
     for k in (["k1", "k3", "k4", "k5"] if which == "all" else [which]):
-        run(k, draws)
+        run(k, draws, chains=int(sys.argv[sys.argv.index("--chains") + 1]) if "--chains" in sys.argv else 0,
+            lane_groups=int(sys.argv[sys.argv.index("--lane-groups") + 1]) if "--lane-groups" in sys.argv else 0)
