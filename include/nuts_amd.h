@@ -289,6 +289,8 @@ uint64_t  nm_engine_num_chains(const nm_engine* e);
  * the oracle reproduces it with gpu_cfg(threads_per_chain). */
 uint64_t  nm_engine_threads_per_chain(const nm_engine* e);
 uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
+/* draw launches served by the 8-chains-per-wavefront kernel so far (nm_engine_config.lane_groups) */
+uint64_t  nm_engine_group_launches(const nm_engine* e);
 /* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */
 void*     nm_engine_stream(nm_engine* e);
 

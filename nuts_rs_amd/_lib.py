@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
     "nm_engine_draw_ex_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
-    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
+    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
     "nm_pick_tiling",
 ]
@@ -129,6 +129,8 @@ def load():
     L.nm_engine_threads_per_chain.restype = u64
     L.nm_engine_dims_per_lane.argtypes = [vp]
     L.nm_engine_dims_per_lane.restype = u64
+    L.nm_engine_group_launches.argtypes = [vp]
+    L.nm_engine_group_launches.restype = u64
     L.nm_engine_stream.argtypes = [vp]
     L.nm_engine_stream.restype = vp
     L.nm_leapfrog_batch.argtypes = [C.POINTER(NmLogpSpec), u64, u64] + [vp] * 16 + [vp]

@@ -249,6 +249,7 @@ struct nm_engine {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     uint64_t steps_base = 0, draws_total = 0;
+    uint64_t group_launches = 0;
     uint64_t draws_launched = 0;            // draws every chain has been asked for since creation (never reset)
     bool pending_timing = false;
 };
@@ -339,6 +340,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
             int gocc = 0;
             E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, nullptr));
             uint64_t gres = (uint64_t)(gocc > 0 ? gocc : 1) * (uint64_t)(cus > 0 ? cus : 1);
+            if (cfg.grid_blocks) gres = cfg.grid_blocks;
             const uint64_t need = (n_chains + grp::GPW - 1) / grp::GPW;
             e->group_grid = (unsigned)(need < gres ? need : gres);
         }
@@ -458,9 +460,10 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     // are wanted: the small-chain kernel computes the same draws with 8 chains per wavefront
     const bool only_basic = !out->d_gradient && !out->d_transformed_position && !out->d_transformed_gradient && !out->d_mass_matrix_inv &&
                             !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
-    if (e->group_grid && only_basic && e->draws_launched >= e->s.num_tune)
+    if (e->group_grid && only_basic && e->draws_launched >= e->s.num_tune) {
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
-    else
+        e->group_launches += 1;
+    } else
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
@@ -614,6 +617,7 @@ extern "C" uint64_t nm_engine_dim(const nm_engine* e) { return e ? e->dim : 0; }
 extern "C" uint64_t nm_engine_num_chains(const nm_engine* e) { return e ? e->n_chains : 0; }
 extern "C" uint64_t nm_engine_threads_per_chain(const nm_engine* e) { return e ? 64ull * (uint64_t)e->wpc : 0; }
 extern "C" uint64_t nm_engine_dims_per_lane(const nm_engine* e) { return e ? (uint64_t)e->dpl : 0; }
+extern "C" uint64_t nm_engine_group_launches(const nm_engine* e) { return e ? e->group_launches : 0; }
 extern "C" void* nm_engine_stream(nm_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 // ---------------------------------------------------------------------------------------------

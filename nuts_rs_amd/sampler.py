@@ -210,6 +210,10 @@ class ChainBatch:
     def dims_per_lane(self):
         return int(_lib.load().nm_engine_dims_per_lane(self._h))
 
+    def group_launches(self) -> int:
+        """Draw launches served by the 8-chains-per-wavefront kernel (small chains, after warm-up)."""
+        return int(_lib.load().nm_engine_group_launches(self._h))
+
     def init_positions_uniform(self):
         """x0 ~ U(-1,1) from each chain's outer generator: `CpuMath::init_position` in Sampler order."""
         x0 = np.empty((self.n_chains, self.logp.dim))

@@ -18,12 +18,20 @@ def oracle_settings(O, settings: N.DiagNutsSettings):
     return s
 
 
-def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0, waves_per_chain=0):
+def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0, waves_per_chain=0,
+               lane_groups=0, grid_blocks=0, splits=()):
+    """`splits`: draw counts at which the launch is cut (the lane-group kernel only serves launches that start after
+    the warm-up); the pieces are concatenated."""
     b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane,
-                     waves_per_chain=waves_per_chain)
+                     waves_per_chain=waves_per_chain, lane_groups=lane_groups, grid_blocks=grid_blocks)
     status = b.set_position(x0, raise_on_error=False)
-    pos, st = b.draw_many(n_draws) if (status == 0).all() else (None, None)
-    extra = dict(status=status, threads_per_chain=b.threads_per_chain(), dims_per_lane=b.dims_per_lane())
+    pos, st = None, None
+    if (status == 0).all():
+        cuts = [0] + [c for c in splits if 0 < c < n_draws] + [n_draws]
+        parts = [b.draw_many(hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        pos, st = np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
+    extra = dict(status=status, threads_per_chain=b.threads_per_chain(), dims_per_lane=b.dims_per_lane(),
+                 group_launches=b.group_launches())
     if pos is not None:
         sd, mu = b.mass_matrix()
         extra.update(stds=sd, mean=mu, step_sizes=b.step_sizes(), x=b.positions(), gx=b.gradients(),

@@ -382,3 +382,59 @@ def test_more_chains_than_resident_blocks(oracle):
             pos_b, st_b = b.draw_many(50)
             b.close()
             assert_bit_exact(np.concatenate([pos_a, pos_b]), np.concatenate([st_a, st_b]), pos_o, st_o)
+
+
+def test_lane_group_kernel_sweep(oracle):
+    """Chains with dim <= 16 are drawn 8 per wavefront once the warm-up is over (nuts_group.hpp): randomised settings,
+    ragged chain counts (partial wavefronts, more chains than resident groups) — the same bits as the oracle, which
+    knows nothing of the grouping, for the warm-up (wave kernel) and the sampling launches (group kernel) alike."""
+    rng = np.random.default_rng(77)
+    for i in range(int(os.environ.get("NM_GROUP_SWEEP_CASES", "40"))):
+        maxdepth = int(rng.integers(1, 9))
+        st = N.StepSizeSettings(
+            target_accept=float(rng.choice([0.6, 0.8, 0.9])),
+            jitter=None if rng.random() < 0.3 else float(rng.choice([0.05, 0.1, 0.3])),
+            method=int(rng.choice([N.STEP_DUAL_AVERAGE, N.STEP_DUAL_AVERAGE, N.STEP_ADAM, N.STEP_FIXED])),
+            fixed_step_size=float(rng.choice([0.2, 0.7])))
+        kw = dict(seed=int(rng.integers(0, 2 ** 31)), num_tune=int(rng.integers(20, 70)), maxdepth=maxdepth,
+                  mindepth=int(rng.integers(0, maxdepth + 1)) if rng.random() < 0.3 else 0,
+                  check_turning=bool(rng.random() < 0.85), extra_doublings=int(rng.integers(0, 3)) if rng.random() < 0.3 else 0,
+                  max_energy_error=float(rng.choice([1000.0, 1000.0, 2.0, 0.3])),
+                  target_integration_time=None if rng.random() < 0.75 else float(rng.choice([0.5, 2.0, 8.0])),
+                  adapt_options=N.EuclideanAdaptOptions(step_size_settings=st))
+        dens = rng.choice(["iid", "diag", "schools"], p=[0.4, 0.4, 0.2])
+        dim = 10 if dens == "schools" else int(rng.integers(1, 17))
+        n_chains = int(rng.integers(1, 40))
+        s = N.DiagNutsSettings(num_chains=n_chains, **kw)
+        logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "schools": N.LogpSpec.eight_schools,
+                "diag": lambda: N.LogpSpec.diag_normal(np.exp(np.random.default_rng(i).uniform(-3, 3, dim)))}[dens]()
+        x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
+        n_draws = s.num_tune + 40
+        grid = int(rng.integers(1, 4)) if rng.random() < 0.3 else 0
+        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, lane_groups=2, grid_blocks=grid,
+                                     splits=(s.num_tune, s.num_tune + 1, s.num_tune + 17))
+        pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=64)
+        if failed or not (ex["status"] == 0).all():
+            assert failed == int((ex["status"] != 0).sum()), f"case {i}: init failures differ"
+            continue
+        try:
+            assert_bit_exact(pos_g, st_g, pos_o, st_o)
+            assert ex["counters"]["total_leapfrogs"] == steps
+            assert ex["group_launches"] == 3
+        except AssertionError as e:
+            raise AssertionError(f"case {i} ({dens}, dim {dim}, {n_chains} chains, grid {grid}, {kw}): {e}") from None
+
+
+def test_lane_group_kernel_is_the_default_for_small_chains(oracle):
+    """Automatic choice (n_chains >= 64): same draws as with the grouping switched off, and the final state the host
+    reads back (positions, gradients, step sizes) is the same too."""
+    s = N.DiagNutsSettings(num_chains=100, seed=5, num_tune=60)
+    logp = N.LogpSpec.eight_schools()
+    x0 = oracle.init_positions_uniform(s.seed, 0, 100, 10)
+    a = run_engine(s, logp, 100, x0, 110, lane_groups=0, splits=(60,))
+    b = run_engine(s, logp, 100, x0, 110, lane_groups=1, splits=(60,))
+    assert_bit_exact(a[0], a[1], b[0], b[1])
+    assert a[2]["group_launches"] == 1 and b[2]["group_launches"] == 0
+    for k in ("x", "gx", "step_sizes", "stds", "mean"):
+        assert (a[2][k].view(np.uint64) == b[2][k].view(np.uint64)).all(), k
+    assert a[2]["counters"]["total_leapfrogs"] == b[2]["counters"]["total_leapfrogs"]
