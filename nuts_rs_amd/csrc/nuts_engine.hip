@@ -234,7 +234,7 @@ struct nm_engine {
     double* d_pvec = nullptr;     // [n_chains][NUM_PSLOT][dpad]
     double* d_svec = nullptr;     // [n_waves][nsslot][dpad]
     unsigned n_waves = 0;         // resident waves of the draw kernel = its grid
-    unsigned group_grid = 0;      // > 0: the 8-lanes-per-chain kernel (nuts_group.hpp) may serve post-warm-up launches
+    unsigned group_grid = 0;      // > 0: the 8-lanes-per-chain kernel (nuts_group.hpp) serves the draw launches
     ChainScalars* d_sc = nullptr;
     unsigned long long* d_prof = nullptr;   // 32 cycle counters for NM_PROF builds
     double* d_zig = nullptr;      // x[257] then f[257]
@@ -334,7 +334,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
-        // small chains: 8 lanes per chain, 8 chains per wave (nuts_group.hpp) once the warm-up is over
+        // small chains: 8 lanes per chain, 8 chains per wave (nuts_group.hpp)
         const bool group_density = logp->kind == NM_LOGP_IID_NORMAL || logp->kind == NM_LOGP_DIAG_NORMAL || logp->kind == NM_LOGP_EIGHT_SCHOOLS;
         if (cfg.lane_groups != 1 && group_density && logp->dim <= 16 && dpl == 2 && wv == 1 && s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains >= 64 || cfg.lane_groups == 2)) {
             int gocc = 0;
@@ -456,12 +456,12 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    // every chain is past its warm-up (all chains have drawn draws_launched times) and only positions / scalar statistics
-    // are wanted: the small-chain kernel computes the same draws with 8 chains per wavefront
+    // small chains, positions / scalar statistics only: the 8-chains-per-wavefront kernel computes the same draws
     const bool only_basic = !out->d_gradient && !out->d_transformed_position && !out->d_transformed_gradient && !out->d_mass_matrix_inv &&
                             !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
-    if (e->group_grid && only_basic && e->draws_launched >= e->s.num_tune) {
-        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
+    if (e->group_grid && only_basic) {
+        // a launch that starts inside the warm-up takes the kernel with the adaptation compiled in
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
         e->group_launches += 1;
     } else
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));

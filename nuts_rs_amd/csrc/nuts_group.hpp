@@ -11,8 +11,8 @@
 //   * the same exp / ln, the same ChaCha stream and ziggurat, the same tree (ported from nuts_transition), the same
 //     memory layout (pvec slots per chain; a block's tree scratch holds its 8 chains side by side, 16 doubles each).
 // The doubling loop is naturally lockstep (every group is at depth d in iteration d); groups whose tree ended wait for
-// the wave's longest tree.  Scope: post-warm-up draws (no adaptation inside), positions + scalar statistics, the
-// elementwise densities and 8 schools, maxdepth <= 10; the engine falls back to the wave kernel otherwise.
+// the wave's longest tree.  Scope: warm-up and sampling draws, positions + scalar statistics, the elementwise densities
+// and 8 schools, maxdepth <= 10; the engine uses the wave kernel otherwise (and for set_position).
 #pragma once
 #include "nuts_kernels.hpp"
 
@@ -600,8 +600,265 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
     return NM_CHAIN_OK;
 }
 
-// NutsChain::draw after warm-up (chain_draw restricted to draw_count >= num_tune: no estimator / mass-matrix work)
+// ---- warm-up (group forms of the adaptation in nuts_kernels.hpp: the same operations on per-lane scalars) ----
+NM_DEV bool gall(bool ok) {
+    const uint64_t m = __ballot(ok);
+    return ((uint32_t)(m >> (8 * gg())) & 0xffu) == 0xffu;
+}
+// DualAverage::new (dual_avg.rs:44-53) or Adam::new (adam.rs:56-64)
+NM_DEV void g_stepsize_adapt_reset(ChainScalars& sc, const nm_settings& s, double initial_step) {
+    sc.log_step = dlog(initial_step);
+    if (s.step_size_method == NM_STEP_ADAM) { sc.adam_m = 0.; sc.adam_v = 0.; sc.adam_t = 0; return; }
+    sc.log_step_adapted = sc.log_step;
+    sc.hbar = 0.;
+    sc.mu = dlog(10. * initial_step);
+    sc.da_count = 1;
+}
+// update_stepsize (reference src/stepsize/adapt.rs:235-267)
 template <class GD>
+NM_DEV void g_update_stepsize(GCtx<GD>& C, bool use_best_guess) {
+    const nm_settings& s = C.P.s;
+    const double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
+                      : s.step_size_method == NM_STEP_ADAM ? dexp(C.sc.log_step)
+                      : (use_best_guess ? dexp(C.sc.log_step_adapted) : dexp(C.sc.log_step));
+    if (s.has_jitter) {
+        const double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
+        const double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
+        C.sc.step_size = step * j;
+    } else {
+        C.sc.step_size = step;
+    }
+}
+// DualAverage::advance (dual_avg.rs:55-64) / Adam::advance (adam.rs:70-98)
+template <class GD>
+NM_DEV void g_update_estimator(GCtx<GD>& C, bool late) {
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) return;
+    ChainScalars& sc = C.sc;
+    const double accept_stat = late ? sc.last_sym_mean_tree_accept : sc.last_mean_tree_accept;
+    if (s.step_size_method == NM_STEP_ADAM) {
+        const double gradient = accept_stat - s.target_accept;
+        sc.adam_t += 1;
+        sc.adam_m = s.adam_beta1 * sc.adam_m + (1.0 - s.adam_beta1) * gradient;
+        sc.adam_v = s.adam_beta2 * sc.adam_v + (1.0 - s.adam_beta2) * gradient * gradient;
+        const double m_hat = sc.adam_m / (1.0 - powi_rs(s.adam_beta1, (int32_t)sc.adam_t));
+        const double v_hat = sc.adam_v / (1.0 - powi_rs(s.adam_beta2, (int32_t)sc.adam_t));
+        sc.log_step += s.adam_learning_rate * m_hat / (__builtin_sqrt(v_hat) + s.adam_epsilon);
+        return;
+    }
+    const double w = 1. / ((double)sc.da_count + s.da_t0);
+    sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
+    sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
+    sc.log_step = fmin_rs(sc.log_step, C.P.ln_max_step);
+    const double mk = dexp(-s.da_k * dlog((double)sc.da_count));
+    sc.log_step_adapted = mk * sc.log_step + (1. - mk) * sc.log_step_adapted;
+    sc.da_count += 1;
+}
+// RunningVariance::add_sample (adapt/diagonal.rs:31-44, cpu_math.rs:605-631)
+NM_DEV void g_running_variance_add(double (&mean)[2], double (&var)[2], uint64_t new_count, const double (&value)[2]) {
+    if (new_count == 1) { mean[0] = value[0]; mean[1] = value[1]; return; }
+    const double diff_scale = 1.0 / (double)new_count;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double diff = value[k] - mean[k];
+        mean[k] = mean[k] + diff * diff_scale;
+        var[k] = var[k] + diff * diff;
+    }
+}
+template <class GD>
+NM_DEV void g_commit_mass_matrix(GCtx<GD>& C, const double (&sig)[2], const double (&isig)[2], const double (&mu)[2]) {
+    C.st(sig, C.Pp(P_SIG)); C.st(isig, C.Pp(P_ISIG)); C.st(mu, C.Pp(P_MU));
+    C.sig[0] = sig[0]; C.sig[1] = sig[1]; C.mu[0] = mu[0]; C.mu[1] = mu[1];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bool valid = 2 * gl() + k < C.dim;
+        acc = acc + (valid ? dlog(valid ? isig[k] : 1.0) : 0.0);
+    }
+    C.sc.mm_logdet = gsum(acc);
+    C.sc.mm_id += 1;
+}
+// Strategy::adapt -> update_diag_draw_grad / update_diag_draw (adapt/diagonal.rs:161-196, diagonal.rs:85-131)
+template <class GD>
+NM_DEV bool g_mass_matrix_adapt(GCtx<GD>& C, const double (&dm)[2], const double (&dv)[2], const double (&gm)[2], const double (&gv)[2]) {
+    if (C.sc.cnt_fg < 3) return false;
+    double sig[2] = {C.sig[0], C.sig[1]}, isig[2], mu[2];
+    C.ld(isig, C.Pp(P_ISIG));
+    if (C.P.s.use_grad_based_estimate) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool valid = 2 * gl() + k < C.dim;
+            double val = __builtin_sqrt(dv[k] / gv[k]);
+            double sd = sig[k], isd = isig[k];
+            if (!(!is_finite(val) | (val == 0.0))) {
+                val = clampd(val, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            const double var = sd * sd;
+            double mean = var * gm[k];
+            mean = __builtin_fma(1.0, dm[k], mean);
+            sig[k] = valid ? sd : 0.0;
+            isig[k] = valid ? isd : 0.0;
+            mu[k] = valid ? mean : 0.0;
+        }
+    } else {
+        const double scale = 1.0 / (double)C.sc.cnt_fg;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool valid = 2 * gl() + k < C.dim;
+            const double d = dv[k] * scale;
+            double sd = sig[k], isd = isig[k];
+            if (!(!is_finite(d) | (d == 0.0))) {
+                const double val = clampd(d, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            sig[k] = valid ? sd : 0.0;
+            isig[k] = valid ? isd : 0.0;
+            mu[k] = valid ? dm[k] : 0.0;
+        }
+    }
+    g_commit_mass_matrix(C, sig, isig, mu);
+    return true;
+}
+// stepsize::Strategy::init (src/stepsize/adapt.rs:91-199): the step-size search at x, after the first mass-matrix update
+template <class GD>
+NM_DEV uint64_t g_stepsize_init(GCtx<GD>& C, const double (&x)[2]) {
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
+    GPt st;
+    {   // Hamiltonian::init_state (transformed_hamiltonian.rs:640-661, check_all :310-324)
+        double gx[2], isig[2];
+        st.logp = C.dens.eval(x, gx, C.dim);
+        C.ld(isig, C.Pp(P_ISIG));
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double t = __builtin_fma(-1.0, C.mu[k], x[k]);
+            st.z[k] = isig[k] * t;
+            st.g[k] = gx[k] * C.sig[k];
+            const bool valid = 2 * gl() + k < C.dim;
+            ok = ok && (!valid || (is_finite(st.z[k]) && is_finite(st.g[k]) && st.g[k] != 0.0 && is_finite(gx[k]) && is_finite(x[k])));
+        }
+        if (!gall(ok)) return NM_CHAIN_BAD_INIT;
+    }
+    const double logdet = C.sc.mm_logdet;
+    g_fill_normals(C.rng, C.samp, C.dim, C.zig);
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        st.v[k] = 2 * gl() + k < C.dim ? 1.0 * C.samp[2 * gl() + k] : 0.0;
+        kacc = __builtin_fma(st.v[k], st.v[k], kacc);
+    }
+    const double ke0 = 0.5 * gsum(kacc);
+    const double e0 = ke0 - (st.logp + logdet);
+    GAccept col;
+    C.sc.step_size = s.initial_step;
+    int dir = 0;
+    for (int it = 0; it < 101; ++it) {
+        GPt o;
+        const int sign = it == 0 ? 1 : dir;
+        col.register_init(e0);
+        g_leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0);
+        const double energy = o.ke - (o.logp + logdet);
+        const double err = energy - e0;
+        if ((err > 1000.0) | !is_finite(err)) {
+            if (it > 0) C.sc.step_size = s.initial_step;
+            return NM_CHAIN_OK;
+        }
+        col.register_ok(energy);
+        const double accept = col.mean();
+        if (it == 0) { dir = accept > s.target_accept ? 1 : -1; continue; }
+        if (dir > 0) {
+            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { g_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size *= 2.;
+        } else {
+            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { g_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size /= 2.;
+        }
+    }
+    C.sc.step_size = s.initial_step;
+    return NM_CHAIN_OK;
+}
+// GlobalStrategy::adapt (src/adapt_strategy.rs:121-222); x, gx = the chosen draw
+template <bool TUNE, class GD>
+NM_DEV uint64_t g_adapt(GCtx<GD>& C, GAccept& col, bool is_good, const double (&x)[2], const double (&gx)[2]) {
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const uint64_t draw = sc.draw_count;
+    sc.last_mean_tree_accept = col.mean();
+    sc.last_sym_mean_tree_accept = col.mean_sym();
+    sc.last_n_steps = col.count;
+    sc.last_max_energy_error = col.max_energy_error;
+    if (!TUNE || draw >= s.num_tune) {     // the sampling kernel (TUNE = false) is only launched once every chain is there
+        g_update_stepsize(C, true);
+        sc.tuning = 0;
+        return NM_CHAIN_OK;
+    }
+    if (draw < C.P.final_step_size_window) {
+        const bool is_early = draw < C.P.early_end;
+        if (!is_early && draw == C.P.early_end)
+            sc.current_window_size = sc.current_window_size > sc.cnt_bg ? sc.current_window_size : sc.cnt_bg;
+        const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
+        double fdm[2], fdv[2], fgm[2], fgv[2], bdm[2], bdv[2], bgm[2], bgv[2];
+        C.ld(fdm, C.Pp(E_DM)); C.ld(fdv, C.Pp(E_DV)); C.ld(fgm, C.Pp(E_GM)); C.ld(fgv, C.Pp(E_GV));
+        C.ld(bdm, C.Pp(B_DM)); C.ld(bdv, C.Pp(B_DV)); C.ld(bgm, C.Pp(B_GM)); C.ld(bgv, C.Pp(B_GV));
+        bool dirty = false;
+        if (is_good) {
+            sc.cnt_fg += 1;
+            sc.cnt_bg += 1;
+            g_running_variance_add(fdm, fdv, sc.cnt_fg, x);
+            g_running_variance_add(fgm, fgv, sc.cnt_fg, gx);
+            g_running_variance_add(bdm, bdv, sc.cnt_bg, x);
+            g_running_variance_add(bgm, bgv, sc.cnt_bg, gx);
+            dirty = true;
+        }
+        const bool could_switch = sc.cnt_bg >= switch_freq;
+        uint64_t next_window_size;
+        if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
+        else {
+            const double gv = (double)sc.current_window_size * s.mass_matrix_window_growth;
+            const double fl = __builtin_floor(gv);
+            const uint64_t grown = (uint64_t)((gv - fl >= 0.5) ? fl + 1.0 : fl);
+            next_window_size = sc.current_window_size + 1 > grown ? sc.current_window_size + 1 : grown;
+        }
+        const bool is_late = next_window_size + draw > C.P.final_step_size_window;
+        bool force_update = false;
+        if (could_switch && !is_late) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                fdm[k] = bdm[k]; fdv[k] = bdv[k]; fgm[k] = bgm[k]; fgv[k] = bgv[k];
+                bdm[k] = 0.0; bdv[k] = 0.0; bgm[k] = 0.0; bgv[k] = 0.0;
+            }
+            sc.cnt_fg = sc.cnt_bg;
+            sc.cnt_bg = 0;
+            force_update = true;
+            dirty = true;
+            if (!is_early) sc.current_window_size = next_window_size;
+        }
+        if (dirty) {
+            C.st(bdm, C.Pp(B_DM)); C.st(bdv, C.Pp(B_DV)); C.st(bgm, C.Pp(B_GM)); C.st(bgv, C.Pp(B_GV));
+            C.st(fdm, C.Pp(E_DM)); C.st(fdv, C.Pp(E_DV)); C.st(fgm, C.Pp(E_GM)); C.st(fgv, C.Pp(E_GV));
+        }
+        bool did_change = false;
+        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = g_mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
+        if (did_change) sc.last_update = draw;
+        g_update_estimator(C, is_late);
+        if (did_change & (sc.has_initial_mass_matrix != 0)) {
+            sc.has_initial_mass_matrix = 0;
+            return g_stepsize_init(C, x);
+        }
+        g_update_stepsize(C, false);
+        return NM_CHAIN_OK;
+    }
+    g_update_estimator(C, true);
+    g_update_stepsize(C, draw == s.num_tune - 1);
+    return NM_CHAIN_OK;
+}
+
+// NutsChain::draw (reference src/chain.rs:151-188) + the scalar statistics of expanded_draw (:190-232)
+template <bool TUNE, class GD>
 NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
@@ -633,7 +890,7 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
         (void)C.dens.eval(x, gx, C.dim);
 #pragma unroll
         for (int k = 0; k < 2; ++k) gz[k] = gx[k] * C.sig[k];
-        const bool need_x = t_out + 1 == P.n_draws;
+        const bool need_x = sc.tuning || t_out + 1 == P.n_draws;
         if (need_x) { C.st(x, C.Pp(P_X)); C.st(gx, C.Pp(P_GX)); }
         sc.px_stale = need_x ? 0 : 1;
         C.st(z, C.Pp(P_Z)); C.st(gz, C.Pp(P_GZ));
@@ -652,24 +909,9 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
     const int64_t trans_id = sc.transform_id;
     sc.total_steps += col.count;
-    // GlobalStrategy::adapt for draw >= num_tune (adapt_strategy.rs:121-140): statistics of the collector, then the step size
-    sc.last_mean_tree_accept = col.mean();
-    sc.last_sym_mean_tree_accept = col.mean_sym();
-    sc.last_n_steps = col.count;
-    sc.last_max_energy_error = col.max_energy_error;
-    {
-        const nm_settings& s = P.s;
-        const double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
-                          : s.step_size_method == NM_STEP_ADAM ? dexp(sc.log_step) : dexp(sc.log_step_adapted);
-        if (s.has_jitter) {
-            const double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
-            const double j = (v12 - 1.0) * P.jitter_scale + P.jitter_low;
-            sc.step_size = step * j;
-        } else {
-            sc.step_size = step;
-        }
-        sc.tuning = 0;
-    }
+    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);     // DrawGradCollector (adapt/diagonal.rs:73-83)
+    const uint64_t ast = g_adapt<TUNE>(C, col, is_good, x, gx);
+    if (ast != NM_CHAIN_OK) sc.status = ast;
     out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
     out.index_in_trajectory = idx; out.transformation_index = trans_id;
@@ -681,7 +923,7 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
     out.fisher_distance = fd;
     out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
-    out.chain_status = NM_CHAIN_OK;
+    out.chain_status = ast;
     out.transformation_update_id = -1;
     if (sc.mm_id != sc.stats_last_id) out.transformation_update_id = sc.mm_id;
     sc.stats_last_id = sc.mm_id;
@@ -689,8 +931,10 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     sc.draw_count += 1;
 }
 
-template <class Dens>
-__global__ __launch_bounds__(64) void nuts_group_draw_kernel(const KParams P) {
+// TUNE = true: the whole adaptation is compiled in (any launch that starts inside the warm-up); TUNE = false: launches
+// after it, with the registers the adaptation would cost left to the tree
+template <class Dens, bool TUNE>
+__global__ __launch_bounds__(64, 2) void nuts_group_draw_kernel(const KParams P) {
     using GD = typename GroupDensity<Dens>::type;
     __shared__ GroupShared sh;
     dm_init_lds();
@@ -719,7 +963,7 @@ __global__ __launch_bounds__(64) void nuts_group_draw_kernel(const KParams P) {
             C.dens.init(P.logp_params, C.dim);
             if (C.sc.status == NM_CHAIN_OK) {
                 for (uint64_t t = 0; t < P.n_draws; ++t) {
-                    g_chain_draw(C, chain, t);
+                    g_chain_draw<TUNE>(C, chain, t);
                     if (C.sc.status != NM_CHAIN_OK) break;
                 }
             }

@@ -8,14 +8,22 @@
 
 namespace nm {
 enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
-                  K_GROUP_DRAW, K_GROUP_QUERY };  // the 8-lanes-per-chain kernel of nuts_group.hpp (dim <= 16)
+                  K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY };  // the 8-lanes-per-chain kernels of nuts_group.hpp (dim <= 16): sampling / warm-up
 
 // the 8-lanes-per-chain kernel exists for the densities that have a group form (nuts_group.hpp)
 template <class Dens>
 inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
     if constexpr (!std::is_void<typename grp::GroupDensity<Dens>::type>::value) {
-        if (kind == K_GROUP_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, grp::nuts_group_draw_kernel<Dens>, 64, 0);
-        hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens>), dim3(grid_blocks), dim3(64), 0, stream, P);
+        if (kind == K_GROUP_QUERY) {       // both kernels share the block's tree scratch: the grid is sized for the roomier one
+            int a = 0, b = 0;
+            hipError_t st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, grp::nuts_group_draw_kernel<Dens, false>, 64, 0);
+            if (st != hipSuccess) return st;
+            st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, grp::nuts_group_draw_kernel<Dens, true>, 64, 0);
+            *occ = a > b ? a : b;
+            return st;
+        }
+        if (kind == K_GROUP_TUNE) hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens, true>), dim3(grid_blocks), dim3(64), 0, stream, P);
+        else hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens, false>), dim3(grid_blocks), dim3(64), 0, stream, P);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
@@ -25,7 +33,7 @@ inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_
 // hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
 template <int DPL, int W, class Dens>
 inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
-    if (kind == K_GROUP_DRAW || kind == K_GROUP_QUERY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
+    if (kind == K_GROUP_DRAW || kind == K_GROUP_TUNE || kind == K_GROUP_QUERY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
     if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
     dim3 grid(grid_blocks), block(64 * W);
     if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);

@@ -20,8 +20,7 @@ def oracle_settings(O, settings: N.DiagNutsSettings):
 
 def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0, waves_per_chain=0,
                lane_groups=0, grid_blocks=0, splits=()):
-    """`splits`: draw counts at which the launch is cut (the lane-group kernel only serves launches that start after
-    the warm-up); the pieces are concatenated."""
+    """`splits`: draw counts at which the run is cut into separate launches; the pieces are concatenated."""
     b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane,
                      waves_per_chain=waves_per_chain, lane_groups=lane_groups, grid_blocks=grid_blocks)
     status = b.set_position(x0, raise_on_error=False)

@@ -385,14 +385,14 @@ def test_more_chains_than_resident_blocks(oracle):
 
 
 def test_lane_group_kernel_sweep(oracle):
-    """Chains with dim <= 16 are drawn 8 per wavefront once the warm-up is over (nuts_group.hpp): randomised settings,
-    ragged chain counts (partial wavefronts, more chains than resident groups) — the same bits as the oracle, which
-    knows nothing of the grouping, for the warm-up (wave kernel) and the sampling launches (group kernel) alike."""
+    """Chains with dim <= 16 can be drawn 8 per wavefront (nuts_group.hpp): randomised settings, ragged chain counts
+    (partial wavefronts, more chains than resident groups), launches cut at and after the end of the warm-up — the same
+    bits as the oracle, which knows nothing of the grouping."""
     rng = np.random.default_rng(77)
     for i in range(int(os.environ.get("NM_GROUP_SWEEP_CASES", "40"))):
         maxdepth = int(rng.integers(1, 9))
         st = N.StepSizeSettings(
-            target_accept=float(rng.choice([0.6, 0.8, 0.9])),
+            target_accept=float(rng.choice([0.6, 0.8, 0.9])), initial_step=float(rng.choice([0.01, 0.1, 1.0])),
             jitter=None if rng.random() < 0.3 else float(rng.choice([0.05, 0.1, 0.3])),
             method=int(rng.choice([N.STEP_DUAL_AVERAGE, N.STEP_DUAL_AVERAGE, N.STEP_ADAM, N.STEP_FIXED])),
             fixed_step_size=float(rng.choice([0.2, 0.7])))
@@ -401,7 +401,12 @@ def test_lane_group_kernel_sweep(oracle):
                   check_turning=bool(rng.random() < 0.85), extra_doublings=int(rng.integers(0, 3)) if rng.random() < 0.3 else 0,
                   max_energy_error=float(rng.choice([1000.0, 1000.0, 2.0, 0.3])),
                   target_integration_time=None if rng.random() < 0.75 else float(rng.choice([0.5, 2.0, 8.0])),
-                  adapt_options=N.EuclideanAdaptOptions(step_size_settings=st))
+                  adapt_options=N.EuclideanAdaptOptions(
+                      step_size_settings=st,
+                      mass_matrix_options=N.DiagAdaptExpSettings(use_grad_based_estimate=bool(rng.random() < 0.7)),
+                      early_window=float(rng.choice([0.1, 0.3, 0.5])), step_size_window=float(rng.choice([0.1, 0.15, 0.3])),
+                      mass_matrix_switch_freq=int(rng.choice([10, 30, 80])), early_mass_matrix_switch_freq=int(rng.choice([5, 10])),
+                      mass_matrix_update_freq=int(rng.choice([1, 1, 3])), mass_matrix_window_growth=float(rng.choice([1.0, 1.5, 2.0]))))
         dens = rng.choice(["iid", "diag", "schools"], p=[0.4, 0.4, 0.2])
         dim = 10 if dens == "schools" else int(rng.integers(1, 17))
         n_chains = int(rng.integers(1, 40))
@@ -420,7 +425,7 @@ def test_lane_group_kernel_sweep(oracle):
         try:
             assert_bit_exact(pos_g, st_g, pos_o, st_o)
             assert ex["counters"]["total_leapfrogs"] == steps
-            assert ex["group_launches"] == 3
+            assert ex["group_launches"] == 4
         except AssertionError as e:
             raise AssertionError(f"case {i} ({dens}, dim {dim}, {n_chains} chains, grid {grid}, {kw}): {e}") from None
 
@@ -434,7 +439,7 @@ def test_lane_group_kernel_is_the_default_for_small_chains(oracle):
     a = run_engine(s, logp, 100, x0, 110, lane_groups=0, splits=(60,))
     b = run_engine(s, logp, 100, x0, 110, lane_groups=1, splits=(60,))
     assert_bit_exact(a[0], a[1], b[0], b[1])
-    assert a[2]["group_launches"] == 1 and b[2]["group_launches"] == 0
+    assert a[2]["group_launches"] == 2 and b[2]["group_launches"] == 0
     for k in ("x", "gx", "step_sizes", "stds", "mean"):
         assert (a[2][k].view(np.uint64) == b[2][k].view(np.uint64)).all(), k
     assert a[2]["counters"]["total_leapfrogs"] == b[2]["counters"]["total_leapfrogs"]
