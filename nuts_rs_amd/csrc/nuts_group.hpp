@@ -22,6 +22,9 @@ namespace grp {
 constexpr int GS = 8;             // lanes per chain
 constexpr int GPW = 64 / GS;      // chains per wavefront
 constexpr int GMAXDEPTH = 10;
+#ifndef NM_GROUP_OCC
+#define NM_GROUP_OCC 2       // waves per SIMD the sampling kernel's register allocation leaves room for
+#endif
 
 NM_DEV int gl() { return (int)(threadIdx.x & 7u); }
 NM_DEV int gg() { return (int)((threadIdx.x & 63u) >> 3); }
@@ -934,7 +937,7 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
 // TUNE = true: the whole adaptation is compiled in (any launch that starts inside the warm-up); TUNE = false: launches
 // after it, with the registers the adaptation would cost left to the tree
 template <class Dens, bool TUNE>
-__global__ __launch_bounds__(64, 2) void nuts_group_draw_kernel(const KParams P) {
+__global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw_kernel(const KParams P) {
     using GD = typename GroupDensity<Dens>::type;
     __shared__ GroupShared sh;
     dm_init_lds();

@@ -45,6 +45,7 @@ def run(key, draws, chains=0, lane_groups=0):
     t = time.time()
     _, st_w = b.draw_many(cfg["tune"], positions=False)
     t_warm = time.time() - t
+    warm_kernel_ms = b.counters()["kernel_ms"]
     b.reset_counters()
     st_dev = torch.empty((draws, C, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
@@ -61,7 +62,8 @@ def run(key, draws, chains=0, lane_groups=0):
         "config": cfg["name"], "chains": C, "dim": D, "draws": draws, "threads_per_chain": b.threads_per_chain(),
         "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups,
         "M1_steps_dims_per_s": steps * D / dt, "M2_draws_per_s_per_chain": draws / dt,
-        "leapfrogs_per_s": steps / dt, "kernel_ms": c["kernel_ms"], "warmup_s": t_warm,
+        "leapfrogs_per_s": steps / dt, "kernel_ms": c["kernel_ms"], "warmup_s": t_warm, "warmup_kernel_ms": warm_kernel_ms,
+        "group_launches": b.group_launches(),
         "warmup_divergence_rate": float(st_w["diverging"].mean()),
         "mean_steps_per_draw": steps / (draws * C), "depth_histogram": depth_hist.tolist(),
         "divergence_rate": float(st["diverging"].mean()), "maxdepth_rate": float(st["maxdepth_reached"].mean()),
