@@ -148,20 +148,27 @@ template <> struct GroupDensity<DiagNormal> { using type = GDiagNormal; };
 template <> struct GroupDensity<EightSchools> { using type = GEightSchools; };
 
 // ---- the chain's generator, one copy per group (same stream as DevRng) ----
+// one refill = 8 ChaCha blocks, one per lane of the group; a call, not an inlined copy at each of the generator's uses
+// (the block function is ~400 instructions and refills are rare)
+static __device__ __noinline__ void g_refill_blocks(const uint32_t* key, uint64_t first_block, uint32_t* cache) {
+    uint32_t k[8], out[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = key[i];
+    chacha8_block(k, first_block + (uint64_t)gl(), 0ull, out);
+    uint4* dst = reinterpret_cast<uint4*>(cache + gl() * 16);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+    dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+}
 struct GRng {
-    uint32_t key[8];
+    const uint32_t* key;   // LDS: the chain's ChaCha key (ChainScalars::key of the group's copy)
     uint64_t pos, base;
     uint32_t* cache;       // LDS [128], this group's
     NM_DEV bool has(uint64_t n) const { return pos >= base && (pos - base) + n <= 128ull; }
     NM_DEV void refill() {
         base = pos & ~15ull;
-        uint32_t out[16];
-        chacha8_block(key, (base >> 4) + (uint64_t)gl(), 0ull, out);
-        uint4* dst = reinterpret_cast<uint4*>(cache + gl() * 16);
-        dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-        dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
-        dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
+        g_refill_blocks(key, base >> 4, cache);
         asm volatile("" ::: "memory");
     }
     NM_DEV uint32_t next_u32() {
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw
             C.pend = sh.pend[g];
             C.zig = {P.zig_x, P.zig_f};
             C.ld(C.sig, C.Pp(P_SIG)); C.ld(C.mu, C.Pp(P_MU));
-            for (int i = 0; i < 8; ++i) C.rng.key[i] = C.sc.key[i];
+            C.rng.key = sh.sc[g].key;
             C.rng.pos = C.sc.rng_pos; C.rng.base = C.sc.rng_pos + 16; C.rng.cache = sh.rng_cache[g];
             C.dens.init(P.logp_params, C.dim);
             if (C.sc.status == NM_CHAIN_OK) {
