@@ -336,12 +336,15 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
         // small chains: 8 lanes per chain, 8 chains per wave (nuts_group.hpp)
         const bool group_density = logp->kind == NM_LOGP_IID_NORMAL || logp->kind == NM_LOGP_DIAG_NORMAL || logp->kind == NM_LOGP_EIGHT_SCHOOLS;
-        if (cfg.lane_groups != 1 && group_density && logp->dim <= 16 && dpl == 2 && wv == 1 && s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains >= 64 || cfg.lane_groups == 2)) {
+        const int gs = grp::group_size(logp->dim);
+        if (cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
+            s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains >= 64 || cfg.lane_groups == 2)) {
             int gocc = 0;
+            dummy.dim = logp->dim;       // the group size follows the dim
             E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, nullptr));
             uint64_t gres = (uint64_t)(gocc > 0 ? gocc : 1) * (uint64_t)(cus > 0 ? cus : 1);
             if (cfg.grid_blocks) gres = cfg.grid_blocks;
-            const uint64_t need = (n_chains + grp::GPW - 1) / grp::GPW;
+            const uint64_t need = (n_chains + (64 / gs) - 1) / (64 / gs);
             e->group_grid = (unsigned)(need < gres ? need : gres);
         }
     }

@@ -1,993 +1,46 @@
-// nuts_group.hpp — the draw kernel for SMALL chains: 8 lanes per chain, 8 chains per wavefront.
+// nuts_group.hpp — the draw kernels for SMALL chains: GS = 8, 16 or 32 lanes per chain, 64 / GS chains per wavefront.
 //
 // The wave-per-chain kernel (nuts_kernels.hpp) spends ~900 vector instructions per leaf on per-chain scalar work
 // (merge arithmetic, reductions, bookkeeping) that 64 lanes execute for ONE chain; at dim 10 five lanes carry data and
-// the kernel is VALU-issue bound.  Here a chain with dim <= 16 lives in a group of 8 lanes (lane l holds
-// elements 2l, 2l+1 — the same elements thread l of the wave kernel holds), and the 8 groups of a wave execute the same
-// instruction stream with per-lane "scalars".  Everything a group computes is what the wave kernel computes for that
-// chain, bit for bit:
-//   * sums over dim: xor butterfly 1, 2, 4 inside the group; the wave kernel's further steps add the +0.0 partial sums
-//     of lanes 8..63, which changes nothing (partial sums start at +0.0 and are never -0.0);
+// the kernel is VALU-issue bound.  Here a chain with dim <= 2 GS lives in a group of GS lanes (lane l
+// holds elements 2l, 2l+1 — the same elements thread l of the wave kernel holds), and the groups of a wave execute the
+// same instruction stream with per-lane "scalars".  Everything a group computes is what the wave kernel computes for
+// that chain, bit for bit:
+//   * sums over dim: the first log2(GS) steps of the wave kernel's butterfly; its further steps add the +0.0 partial
+//     sums of the lanes beyond the chain, which changes nothing (partial sums start at +0.0 and are never -0.0);
 //   * the same exp / ln, the same ChaCha stream and ziggurat, the same tree (ported from nuts_transition), the same
-//     memory layout (pvec slots per chain; a block's tree scratch holds its 8 chains side by side, 16 doubles each).
+//     adaptation, the same memory layout (pvec slots per chain; a block's tree scratch holds its chains side by side).
 // The doubling loop is naturally lockstep (every group is at depth d in iteration d); groups whose tree ended wait for
 // the wave's longest tree.  Scope: warm-up and sampling draws, positions + scalar statistics, the elementwise densities
 // and 8 schools, maxdepth <= 10; the engine uses the wave kernel otherwise (and for set_position).
+// The implementation (nuts_group_impl.hpp) is compiled once per group size into namespaces grp8 / grp16 / grp32.
 #pragma once
+#include <type_traits>
 #include "nuts_kernels.hpp"
 
 namespace nm {
 namespace grp {
-
-constexpr int GS = 8;             // lanes per chain
-constexpr int GPW = 64 / GS;      // chains per wavefront
 constexpr int GMAXDEPTH = 10;
 #ifndef NM_GROUP_OCC
-#define NM_GROUP_OCC 2       // waves per SIMD the sampling kernel's register allocation leaves room for
+#define NM_GROUP_OCC 2       // waves per SIMD the sampling kernel's register allocation leaves room for (3: spills, slower)
 #endif
-
-NM_DEV int gl() { return (int)(threadIdx.x & 7u); }
-NM_DEV int gg() { return (int)((threadIdx.x & 63u) >> 3); }
-NM_DEV double gsum(double x) {
-    x = x + dpp_mov<0xB1>(x);    // xor 1
-    x = x + dpp_mov<0x4E>(x);    // xor 2
-    x = x + dpp_mov<0x141>(x);   // row_half_mirror = xor 4 on quad sums
-    return x;
-}
-NM_DEV void gsum2(double& a, double& b) { a = gsum(a); b = gsum(b); }
-NM_DEV double gbcast(double x, int j) {          // the value lane j of my group holds
-    const int src = (int)(threadIdx.x & 56u) | j;
-    const int lo = __shfl(__double2loint(x), src), hi = __shfl(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
-}
-NM_DEV uint64_t gbcast_u64(uint64_t x, int j) {
-    const int src = (int)(threadIdx.x & 56u) | j;
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src), hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-struct GroupShared {
-    uint32_t rng_cache[GPW][128];             // 8 ChaCha blocks per chain
-    double samp[GPW][16];                     // stream-ordered normals of the momentum refresh
-    double l1z[GPW][16], l1v[GPW][16];        // L[1] end point
-    PendEntry pend[GPW][GMAXDEPTH + 1];
-    ChainScalars sc[GPW];
-};
-
-// ---- densities (group forms of IidNormal / DiagNormal / EightSchools: same operations, group-relative lanes) ----
-struct GIidNormal {
-    double mu;
-    NM_DEV void init(const double* params, int) { mu = params[0]; }
-    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool valid = 2 * gl() + k < dim;
-            const double diff = x[k] - mu;
-            const double term = -0.5 * diff * diff;
-            gx[k] = valid ? -diff : 0.0;
-            acc = acc + (valid ? term : 0.0);
-        }
-        return gsum(acc);
-    }
-};
-struct GDiagNormal {
-    const double* prec;
-    double norm;
-    NM_DEV void init(const double* params, int dim) {
-        prec = params;
-        double acc = 0.0;
-        for (int j = 0; j < 2; ++j) {
-            const int d = 2 * gl() + j;
-            acc = acc + (d < dim ? dlog(params[d < dim ? d : 0]) : 0.0);
-        }
-        const double log_det_p = gsum(acc);
-        norm = -0.5 * ((double)dim * dlog(6.283185307179586) - log_det_p);
-    }
-    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int d = 2 * gl() + k;
-            const bool valid = d < dim;
-            const double p = valid ? prec[d] : 0.0;
-            const double px = p * x[k];
-            gx[k] = valid ? -px : 0.0;
-            acc = acc + (valid ? x[k] * px : 0.0);
-        }
-        const double quad = -0.5 * gsum(acc);
-        return quad + norm;
-    }
-};
-struct GEightSchools {
-    const double* par;
-    NM_DEV void init(const double* params, int) { par = params; }
-    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int) const {
-        const double mu = gbcast(x[0], 0), lt = gbcast(x[1], 0);
-        const double tau = dexp(lt);
-        const double t5 = (tau / 5.0) * (tau / 5.0);
-        const double prior_tau = lt - dlog1p(t5);
-        double term[2], dr[2], drth[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int d = 2 * gl() + j;
-            const bool school = d >= 2 && d < 10;
-            const int i = school ? d - 2 : 0;
-            const double th = x[j];
-            const double sg = par[8 + i];
-            const double r = (par[i] - (mu + tau * th)) / sg;
-            term[j] = -0.5 * th * th - 0.5 * r * r;
-            dr[j] = r / sg;
-            drth[j] = dr[j] * th;
-            if (!school) { term[j] = 0.0; dr[j] = 0.0; drth[j] = 0.0; }
-        }
-        double gmu = 0.0, gtl = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int l = (2 + i) >> 1, j = (2 + i) & 1;
-            gmu = gmu + gbcast(j ? dr[1] : dr[0], l);
-            gtl = gtl + gbcast(j ? drth[1] : drth[0], l);
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int d = 2 * gl() + k;
-            double t = 0.0, g = 0.0;
-            if (d == 0) { t = -mu * mu / 50.0; g = -mu / 25.0 + gmu; }
-            else if (d == 1) { t = prior_tau; g = 1.0 - 2.0 * t5 / (1.0 + t5) + gtl * tau; }
-            else if (d < 10) { t = term[k]; g = -x[k] + dr[k] * tau; }
-            gx[k] = g;
-            acc = acc + t;
-        }
-        return gsum(acc);
-    }
-};
-template <class Dens> struct GroupDensity { using type = void; };
-template <> struct GroupDensity<IidNormal> { using type = GIidNormal; };
-template <> struct GroupDensity<DiagNormal> { using type = GDiagNormal; };
-template <> struct GroupDensity<EightSchools> { using type = GEightSchools; };
-
-// ---- the chain's generator, one copy per group (same stream as DevRng) ----
-// one refill = 8 ChaCha blocks, one per lane of the group; a call, not an inlined copy at each of the generator's uses
-// (the block function is ~400 instructions and refills are rare)
-static __device__ __noinline__ void g_refill_blocks(const uint32_t* key, uint64_t first_block, uint32_t* cache) {
-    uint32_t k[8], out[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] = key[i];
-    chacha8_block(k, first_block + (uint64_t)gl(), 0ull, out);
-    uint4* dst = reinterpret_cast<uint4*>(cache + gl() * 16);
-    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-    dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
-    dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
-}
-struct GRng {
-    const uint32_t* key;   // LDS: the chain's ChaCha key (ChainScalars::key of the group's copy)
-    uint64_t pos, base;
-    uint32_t* cache;       // LDS [128], this group's
-    NM_DEV bool has(uint64_t n) const { return pos >= base && (pos - base) + n <= 128ull; }
-    NM_DEV void refill() {
-        base = pos & ~15ull;
-        g_refill_blocks(key, base >> 4, cache);
-        asm volatile("" ::: "memory");
-    }
-    NM_DEV uint32_t next_u32() {
-        if (!has(1)) refill();
-        const uint32_t w = cache[pos - base];
-        pos += 1;
-        return w;
-    }
-    NM_DEV uint64_t next_u64() {
-        if (!has(2)) refill();
-        const uint64_t lo = cache[pos - base], hi = cache[pos - base + 1];
-        pos += 2;
-        return (hi << 32) | lo;
-    }
-    NM_DEV bool random_bool_std() { return (int32_t)next_u32() < 0; }
-    NM_DEV double random_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
-    NM_DEV int random_bool(double p) {
-        if (!(p >= 0.0 && p < 1.0)) return p == 1.0 ? 1 : -1;
-        const uint64_t p_int = (uint64_t)(p * 18446744073709551616.0);
-        return next_u64() < p_int ? 1 : 0;
-    }
-};
-
-NM_DEV double g_normal_slow(GRng& rng, uint64_t bits, ZigTables T) {     // normal_slow_path, per group
-    for (;;) {
-        const int i = (int)(bits & 0xff);
-        const double u = u2d((bits >> 12) | 0x4000000000000000ull) - 3.0;
-        const double x = u * T.x[i];
-        if (__builtin_fabs(x) < T.x[i + 1]) return x;
-        if (i == 0) {
-            double xx = 1.0, yy = 0.0;
-            while (-2.0 * yy < xx * xx) {
-                const double a = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
-                const double b = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
-                xx = dlog(a) / ZIG_R;
-                yy = dlog(b);
-            }
-            return u < 0.0 ? xx - ZIG_R : ZIG_R - xx;
-        }
-        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * rng.random_f64() < dexp(-x * x / 2.0)) return x;
-        bits = rng.next_u64();
-    }
-}
-// `count` (<= 16) StandardNormal variates of the chain's stream into samp[0..count): 8 candidates per pass, the samples
-// before the first rejected lane are the sequential ones, that lane's sample finishes on the slow path.
-NM_DEV void g_fill_normals(GRng& rng, double* samp, int count, ZigTables T) {
-    const int l = gl();
-    int i = 0;
-    while (i < count) {
-        if (!rng.has(16)) rng.refill();
-        const int nvalid = (count - i) < GS ? (count - i) : GS;
-        const uint32_t off = (uint32_t)(rng.pos - rng.base) + 2u * (uint32_t)l;
-        const uint64_t bits = ((uint64_t)rng.cache[off + 1] << 32) | rng.cache[off];
-        const int zi = (int)(bits & 0xff);
-        const double u = u2d((bits >> 12) | 0x4000000000000000ull) - 3.0;
-        const double x = u * T.x[zi];
-        const bool ok = __builtin_fabs(x) < T.x[zi + 1];
-        const uint64_t fm = __ballot(l < nvalid && !ok);
-        const uint32_t fail = (uint32_t)(fm >> (8 * gg())) & 0xffu;
-        const int nacc = fail ? (int)__builtin_ctz(fail) : nvalid;
-        if (l < nacc) samp[i + l] = x;
-        rng.pos += 2ull * (uint64_t)nacc;
-        i += nacc;
-        if (fail) {
-            const uint64_t fbits = gbcast_u64(bits, nacc);
-            rng.pos += 2;
-            const double xs = g_normal_slow(rng, fbits, T);
-            if (l == 0) samp[i] = xs;
-            i += 1;
-        }
-    }
-    asm volatile("" ::: "memory");
-}
-
-struct GPt { double z[2], v[2], g[2]; double logp, ke; int64_t idx; };
-
-struct GAccept {             // AcceptCollector with the pending differences kept one per lane of the group
-    double initial_energy, sum, sum_sym, max_energy_error;
-    uint64_t count;
-    double pend_d;
-    int npend;
-    NM_DEV void register_init(double e0) { initial_energy = e0; sum = 0.; sum_sym = 0.; count = 0; max_energy_error = 0.; pend_d = 0.; npend = 0; }
-    NM_DEV void flush() {
-        if (npend == 0) return;
-        const double d = gl() < npend ? pend_d : 0.0;
-        const double e = dexp(fmin_rs(d, 0.));
-        const double es = 2. * e / (1. + dexp(d));
-        for (int i = 0; i < npend; ++i) {
-            sum = sum + gbcast(e, i);
-            sum_sym = sum_sym + gbcast(es, i);
-        }
-        npend = 0;
-    }
-    NM_DEV void register_divergent() { flush(); sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf(); }
-    NM_DEV void register_ok(double end_energy) {
-        const double diff = initial_energy - end_energy;
-        if (gl() == npend) pend_d = diff;
-        npend += 1;
-        count += 1;
-        if (__builtin_fabs(diff) > __builtin_fabs(max_energy_error)) max_energy_error = diff;
-        if (npend == GS) flush();
-    }
-    NM_DEV double mean() { flush(); return sum / (double)count; }
-    NM_DEV double mean_sym() { flush(); return sum_sym / (double)count; }
-};
-
-// ---- one chain of the group: pointers, the mass matrix elements of this lane, generator, density ----
-template <class GD>
-struct GCtx {
-    const KParams& P;
-    GD dens;
-    GRng rng;
-    ZigTables zig;
-    double* pv;            // this chain's persistent slots, at this lane's elements
-    double* sv;            // this block's scratch, at this chain's and lane's elements
-    double* l1z; double* l1v; double* samp;
-    PendEntry* pend;
-    ChainScalars& sc;
-    double sig[2], mu[2];
-    int dim, md;
-    __device__ GCtx(const KParams& p, ChainScalars& s) : P(p), sc(s) {}
-    NM_DEV double* Pp(int slot) const { return pv + (size_t)slot * P.dpad; }
-    NM_DEV double* Ss(int slot) const { return sv + (size_t)slot * P.dpad; }
-    NM_DEV void ld(double (&t)[2], const double* p) const { const double2 q = *reinterpret_cast<const double2*>(p); t[0] = q.x; t[1] = q.y; }
-    NM_DEV void st(const double (&t)[2], double* p) const { *reinterpret_cast<double2*>(p) = make_double2(t[0], t[1]); }
-    NM_DEV double* edge_z(int id) const { return id == 0 ? Pp(P_Z) : Ss(EDGE0_Z + 3 * id); }
-    NM_DEV double* edge_v(int id) const { return Ss(id == 0 ? (int)STAGE_V : EDGE0_V + 3 * id); }
-    NM_DEV double* edge_g(int id) const { return id == 0 ? Pp(P_GZ) : Ss(EDGE0_G + 3 * id); }
-};
-
-template <class GD>
-NM_DEV void g_leapfrog(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon) {
-    const double half = epsilon / 2.;
-    double x[2], gx[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double vh = __builtin_fma(half, s.g[k], s.v[k]);
-        o.v[k] = vh;
-        o.z[k] = __builtin_fma(epsilon, vh, s.z[k]);
-        const double t = o.z[k] * C.sig[k];
-        x[k] = __builtin_fma(1.0, C.mu[k], t);
-    }
-    o.logp = C.dens.eval(x, gx, C.dim);
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        o.g[k] = gx[k] * C.sig[k];
-        o.v[k] = __builtin_fma(half, o.g[k], o.v[k]);
-        acc = __builtin_fma(o.v[k], o.v[k], acc);
-    }
-    o.ke = 0.5 * gsum(acc);
-}
-
-NM_DEV bool g_turning_regs(const GPt& a, const GPt& b, bool fwd) {
-    double s1 = 0., s2 = 0.;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (fwd) turn_acc(a.z[k], a.v[k], b.z[k], b.v[k], s1, s2);
-        else turn_acc(b.z[k], b.v[k], a.z[k], a.v[k], s1, s2);
-    }
-    gsum2(s1, s2);
-    return (s1 < 0.) | (s2 < 0.);
-}
-
-template <class GD>
-NM_DEV bool g_merge_weights(GCtx<GD>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
-    total = logaddexp_lane(a_log_size, b_log_size);
-    const double self_log_size = is_main ? a_log_size : total;
-    if (b_log_size >= self_log_size) return true;
-    const int b = C.rng.random_bool(dexp(b_log_size - self_log_size));
-    if (b < 0) { fatal = true; return false; }
-    return b == 1;
-}
-
-template <class GD>
-NM_DEV int g_cand_to_pool(GCtx<GD>& C, uint32_t& used, const double (&z)[2]) {
-    const int p = (int)__builtin_ctz(~used);
-    used |= 1u << p;
-    C.st(z, C.Ss(slot_C(C.md, p)));
-    return p;
-}
-
-// nuts::draw for the group's chain: the port of nuts_transition (see there for the slot scheme and the merge order)
-template <class GD>
-NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&zc)[2]) {
-    const nm_settings& s = C.P.s;
-    ChainScalars& sc = C.sc;
-    const int MD = C.md;
-    GPt E, O;
-    g_fill_normals(C.rng, C.samp, C.dim, C.zig);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) E.v[k] = 2 * gl() + k < C.dim ? 1.0 * C.samp[2 * gl() + k] : 0.0;
-    C.st(E.v, C.Ss(STAGE_V));
-    if (sc.mm_id != sc.transform_id) {        // lazy re-whitening after the last mass-matrix update (diagonal.rs:210-221)
-        double x[2], gx[2], isig[2];
-        C.ld(x, C.Pp(P_X)); C.ld(gx, C.Pp(P_GX)); C.ld(isig, C.Pp(P_ISIG));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double t = __builtin_fma(-1.0, C.mu[k], x[k]);
-            E.z[k] = isig[k] * t;
-            E.g[k] = gx[k] * C.sig[k];
-        }
-        C.st(E.z, C.Pp(P_Z)); C.st(E.g, C.Pp(P_GZ));
-        sc.logdet = sc.mm_logdet;
-        sc.transform_id = sc.mm_id;
-    } else {
-        C.ld(E.z, C.Pp(P_Z));
-        C.ld(E.g, C.Pp(P_GZ));
-    }
-    const double logdet = sc.logdet;
-    double kacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) kacc = __builtin_fma(E.v[k], E.v[k], kacc);
-    const double ke_init = 0.5 * gsum(kacc);
-    const double e0 = ke_init - (sc.logp + logdet);
-    R.e0 = e0;
-    col.register_init(e0);
-    int left_slot = 0, right_slot = 0;
-    bool o_is_edge = false;
-    int o_edge_sign = 0;
-    uint64_t depth = 0;
-    double log_size = 0.;
-    int64_t left_idx = 0, right_idx = 0;
-    CandRef mc = {-1, sc.logp, ke_init, 0};
-    uint32_t used = 0;
-
-    uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
-    if (s.has_target_integration_time) {
-        const double q = __builtin_ceil(s.target_integration_time / sc.step_size);
-        const uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
-        const uint64_t fl = 63 - __builtin_clzll(max_steps | 1ull);
-        const uint64_t ce = ((max_steps & (max_steps - 1)) == 0) ? fl : fl + 1;
-        mindepth = fl > s.mindepth ? fl : s.mindepth;
-        const uint64_t xd = ce > mindepth ? ce : mindepth;
-        maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
-    }
-    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false;
-    R.divergence_energy_error = 0.; R.div_start_idx = 0;
-    bool fatal = false;
-    bool in_extra = false;
-    uint64_t extra_left = 0;
-    int sign = 1;
-
-    for (;;) {
-        bool check;
-        if (!in_extra) {
-            if (!(depth < maxdepth)) { R.reached_maxdepth = true; break; }
-            sign = C.rng.random_bool_std() ? 1 : -1;
-            check = (s.check_turning != 0) && !(depth < mindepth);
-        } else {
-            if (extra_left == 0) break;
-            extra_left -= 1;
-            check = false;
-        }
-        const bool fwd = sign > 0;
-        const int64_t edge_idx = fwd ? right_idx : left_idx;
-        const uint64_t nleaf = 1ull << depth;
-        const uint32_t used_before = used;
-        const double epsilon = (double)sign * sc.step_size * 1.0;
-        int stop = STOP_NONE;
-        double sub_log_size = 0.;
-        CandRef sub_cand = {-2, 0., 0., 0};
-        const bool reuse_edge = o_is_edge && o_edge_sign == sign;
-        o_is_edge = false;
-
-#define NM_G_ACCOUNT(PT, WOUT)                                                                            \
-        {                                                                                                 \
-            const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
-            const double err_ = energy_ - e0;                                                             \
-            if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
-                col.register_divergent();                                                                 \
-                R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
-                R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
-                stop = STOP_DIVERGING;                                                                    \
-            } else {                                                                                      \
-                col.register_ok(energy_);                                                                 \
-                WOUT = -err_;                                                                             \
-            }                                                                                             \
-        }
-
-        if (depth == 0) {
-            g_leapfrog(C, E, O, epsilon);
-            O.idx = edge_idx + (int64_t)sign;
-            NM_G_ACCOUNT(O, sub_log_size)
-            sub_cand = {-2, O.logp, O.ke, O.idx};
-        } else {
-            if (!reuse_edge) {
-                const int es = fwd ? right_slot : left_slot;
-                C.ld(O.z, C.edge_z(es)); C.ld(O.v, C.edge_v(es)); C.ld(O.g, C.edge_g(es));
-            }
-            for (uint64_t n = 0; n < nleaf; n += 2) {
-                double wE = 0., wO = 0.;
-                g_leapfrog(C, O, E, epsilon);
-                E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
-                NM_G_ACCOUNT(E, wE)
-                if (stop != STOP_NONE) break;
-                g_leapfrog(C, E, O, epsilon);
-                O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
-                NM_G_ACCOUNT(O, wO)
-                if (stop != STOP_NONE) break;
-                const uint64_t nn = n + 1;
-                const int t = (int)__builtin_ctzll(~nn);
-                uint32_t turn_bits = 0;
-                if (check) {
-                    if (g_turning_regs(E, O, fwd)) turn_bits |= 2u;
-                    for (int k = 2; k <= t && turn_bits == 0; ++k) {
-                        const uint64_t a_first = nn + 1 - (1ull << k);
-                        const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                        double az[2], av[2], lz[2], lv[2], bz[2], bv[2];
-                        C.ld(az, C.Ss(slot_F(fa))); C.ld(av, C.Ss(slot_F(fa) + 1));
-                        if (k == 2) {
-                            C.ld(lz, C.l1z); C.ld(lv, C.l1v);
-                            bz[0] = E.z[0]; bz[1] = E.z[1]; bv[0] = E.v[0]; bv[1] = E.v[1];
-                        } else {
-                            C.ld(lz, C.Ss(slot_L(MD, k - 1))); C.ld(lv, C.Ss(slot_L(MD, k - 1) + 1));
-                            C.ld(bz, C.Ss(slot_F(k - 1))); C.ld(bv, C.Ss(slot_F(k - 1) + 1));
-                        }
-                        double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (fwd) {
-                                turn_acc(az[j], av[j], O.z[j], O.v[j], s1, s2);
-                                turn_acc(lz[j], lv[j], O.z[j], O.v[j], s3, s4);
-                                turn_acc(az[j], av[j], bz[j], bv[j], s5, s6);
-                            } else {
-                                turn_acc(O.z[j], O.v[j], az[j], av[j], s1, s2);
-                                turn_acc(O.z[j], O.v[j], lz[j], lv[j], s3, s4);
-                                turn_acc(bz[j], bv[j], az[j], av[j], s5, s6);
-                            }
-                        }
-                        gsum2(s1, s2); gsum2(s3, s4); gsum2(s5, s6);
-                        if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
-                    }
-                }
-                {
-                    double total;
-                    const bool take = g_merge_weights(C, wE, wO, false, total, fatal);
-                    sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
-                    sub_log_size = total;
-                    if (fatal) { stop = STOP_FATAL; break; }
-                    if (turn_bits & 2u) { stop = STOP_TURNING; break; }
-                }
-                for (int k = 2; k <= t; ++k) {
-                    const PendEntry A = C.pend[k - 1];
-                    double total;
-                    const bool take = g_merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
-                    if (take) {
-                        used &= ~(1u << A.cand_slot);
-                    } else {
-                        if (sub_cand.slot >= 0) used &= ~(1u << sub_cand.slot);
-                        sub_cand = {A.cand_slot, A.cand_logp, A.cand_ke, A.cand_idx};
-                    }
-                    sub_log_size = total;
-                    if (fatal) { stop = STOP_FATAL; break; }
-                    if ((turn_bits >> k) & 1u) { stop = STOP_TURNING; break; }
-                }
-                if (stop != STOP_NONE) break;
-                if ((n & 3) == 0 && depth > 1) {
-                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
-                    C.st(E.z, C.Ss(fs));
-                    C.st(E.v, C.Ss(fs + 1));
-                }
-                if (n + 2 < nleaf) {
-                    if (t == 1) { C.st(O.z, C.l1z); C.st(O.v, C.l1v); }
-                    else { C.st(O.z, C.Ss(slot_L(MD, t))); C.st(O.v, C.Ss(slot_L(MD, t) + 1)); }
-                    if (sub_cand.slot == -2) sub_cand.slot = g_cand_to_pool(C, used, O.z);
-                    else if (sub_cand.slot == -3) sub_cand.slot = g_cand_to_pool(C, used, E.z);
-                    PendEntry e;
-                    e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
-                    e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
-                    C.pend[t] = e;
-                }
-            }
-        }
-#undef NM_G_ACCOUNT
-        if (stop == STOP_FATAL) { fatal = true; break; }
-        if (stop == STOP_DIVERGING) { used = used_before; break; }
-        if (stop == STOP_TURNING) {
-            used = used_before;
-            if (!in_extra) { in_extra = true; extra_left = s.extra_doublings; }
-            continue;
-        }
-        // top-level U-turn tests of the finished sub-tree (last leaf O) against the main tree (src/nuts.rs:143-161)
-        bool turning = false;
-        if (check) {
-            if (depth == 0) turning = g_turning_regs(E, O, fwd);
-            else {
-                double lz[2], lv[2], rz[2], rv[2], oz[2], ov[2];
-                C.ld(lz, C.edge_z(left_slot)); C.ld(lv, C.edge_v(left_slot));
-                C.ld(rz, C.edge_z(right_slot)); C.ld(rv, C.edge_v(right_slot));
-                if (depth == 1) { oz[0] = E.z[0]; oz[1] = E.z[1]; ov[0] = E.v[0]; ov[1] = E.v[1]; }
-                else { C.ld(oz, C.Ss(slot_F((int)depth))); C.ld(ov, C.Ss(slot_F((int)depth) + 1)); }
-                double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (fwd) {     // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
-                        turn_acc(lz[j], lv[j], O.z[j], O.v[j], s1, s2);
-                        turn_acc(rz[j], rv[j], O.z[j], O.v[j], s3, s4);
-                        turn_acc(lz[j], lv[j], oz[j], ov[j], s5, s6);
-                    } else {       // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
-                        turn_acc(O.z[j], O.v[j], rz[j], rv[j], s1, s2);
-                        turn_acc(oz[j], ov[j], rz[j], rv[j], s3, s4);
-                        turn_acc(O.z[j], O.v[j], lz[j], lv[j], s5, s6);
-                    }
-                }
-                gsum2(s1, s2); gsum2(s3, s4); gsum2(s5, s6);
-                turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
-            }
-        }
-        double total;
-        const bool take = g_merge_weights(C, log_size, sub_log_size, true, total, fatal);
-        if (fatal) break;
-        if (take) {
-            if (mc.slot >= 0) used &= ~(1u << mc.slot);
-            if (sub_cand.slot == -2) sub_cand.slot = g_cand_to_pool(C, used, O.z);
-            else if (sub_cand.slot == -3) sub_cand.slot = g_cand_to_pool(C, used, E.z);
-            mc = sub_cand;
-        } else if (sub_cand.slot >= 0) {
-            used &= ~(1u << sub_cand.slot);
-        }
-        const bool more = in_extra ? extra_left > 0 : (turning ? s.extra_doublings > 0 : depth + 1 < maxdepth);
-        if (more) {
-            int ns = fwd ? right_slot : left_slot;
-            const int other_side = fwd ? left_slot : right_slot;
-            if (ns == 0) ns = other_side == 1 ? 2 : 1;
-            C.st(O.z, C.edge_z(ns)); C.st(O.v, C.edge_v(ns)); C.st(O.g, C.edge_g(ns));
-            if (fwd) right_slot = ns; else left_slot = ns;
-            o_is_edge = true; o_edge_sign = sign;
-        }
-        if (fwd) right_idx = O.idx; else left_idx = O.idx;
-        depth += 1;
-        log_size = total;
-        if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
-    }
-    R.depth = depth;
-    R.chosen = mc;
-    if (fatal) return NM_CHAIN_LOGP_FATAL;
-    if (mc.slot >= 0) C.ld(zc, C.Ss(slot_C(MD, mc.slot)));
-    return NM_CHAIN_OK;
-}
-
-// ---- warm-up (group forms of the adaptation in nuts_kernels.hpp: the same operations on per-lane scalars) ----
-NM_DEV bool gall(bool ok) {
-    const uint64_t m = __ballot(ok);
-    return ((uint32_t)(m >> (8 * gg())) & 0xffu) == 0xffu;
-}
-// DualAverage::new (dual_avg.rs:44-53) or Adam::new (adam.rs:56-64)
-NM_DEV void g_stepsize_adapt_reset(ChainScalars& sc, const nm_settings& s, double initial_step) {
-    sc.log_step = dlog(initial_step);
-    if (s.step_size_method == NM_STEP_ADAM) { sc.adam_m = 0.; sc.adam_v = 0.; sc.adam_t = 0; return; }
-    sc.log_step_adapted = sc.log_step;
-    sc.hbar = 0.;
-    sc.mu = dlog(10. * initial_step);
-    sc.da_count = 1;
-}
-// update_stepsize (reference src/stepsize/adapt.rs:235-267)
-template <class GD>
-NM_DEV void g_update_stepsize(GCtx<GD>& C, bool use_best_guess) {
-    const nm_settings& s = C.P.s;
-    const double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
-                      : s.step_size_method == NM_STEP_ADAM ? dexp(C.sc.log_step)
-                      : (use_best_guess ? dexp(C.sc.log_step_adapted) : dexp(C.sc.log_step));
-    if (s.has_jitter) {
-        const double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
-        const double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
-        C.sc.step_size = step * j;
-    } else {
-        C.sc.step_size = step;
-    }
-}
-// DualAverage::advance (dual_avg.rs:55-64) / Adam::advance (adam.rs:70-98)
-template <class GD>
-NM_DEV void g_update_estimator(GCtx<GD>& C, bool late) {
-    const nm_settings& s = C.P.s;
-    if (s.step_size_method == NM_STEP_FIXED) return;
-    ChainScalars& sc = C.sc;
-    const double accept_stat = late ? sc.last_sym_mean_tree_accept : sc.last_mean_tree_accept;
-    if (s.step_size_method == NM_STEP_ADAM) {
-        const double gradient = accept_stat - s.target_accept;
-        sc.adam_t += 1;
-        sc.adam_m = s.adam_beta1 * sc.adam_m + (1.0 - s.adam_beta1) * gradient;
-        sc.adam_v = s.adam_beta2 * sc.adam_v + (1.0 - s.adam_beta2) * gradient * gradient;
-        const double m_hat = sc.adam_m / (1.0 - powi_rs(s.adam_beta1, (int32_t)sc.adam_t));
-        const double v_hat = sc.adam_v / (1.0 - powi_rs(s.adam_beta2, (int32_t)sc.adam_t));
-        sc.log_step += s.adam_learning_rate * m_hat / (__builtin_sqrt(v_hat) + s.adam_epsilon);
-        return;
-    }
-    const double w = 1. / ((double)sc.da_count + s.da_t0);
-    sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
-    sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
-    sc.log_step = fmin_rs(sc.log_step, C.P.ln_max_step);
-    const double mk = dexp(-s.da_k * dlog((double)sc.da_count));
-    sc.log_step_adapted = mk * sc.log_step + (1. - mk) * sc.log_step_adapted;
-    sc.da_count += 1;
-}
-// RunningVariance::add_sample (adapt/diagonal.rs:31-44, cpu_math.rs:605-631)
-NM_DEV void g_running_variance_add(double (&mean)[2], double (&var)[2], uint64_t new_count, const double (&value)[2]) {
-    if (new_count == 1) { mean[0] = value[0]; mean[1] = value[1]; return; }
-    const double diff_scale = 1.0 / (double)new_count;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double diff = value[k] - mean[k];
-        mean[k] = mean[k] + diff * diff_scale;
-        var[k] = var[k] + diff * diff;
-    }
-}
-template <class GD>
-NM_DEV void g_commit_mass_matrix(GCtx<GD>& C, const double (&sig)[2], const double (&isig)[2], const double (&mu)[2]) {
-    C.st(sig, C.Pp(P_SIG)); C.st(isig, C.Pp(P_ISIG)); C.st(mu, C.Pp(P_MU));
-    C.sig[0] = sig[0]; C.sig[1] = sig[1]; C.mu[0] = mu[0]; C.mu[1] = mu[1];
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const bool valid = 2 * gl() + k < C.dim;
-        acc = acc + (valid ? dlog(valid ? isig[k] : 1.0) : 0.0);
-    }
-    C.sc.mm_logdet = gsum(acc);
-    C.sc.mm_id += 1;
-}
-// Strategy::adapt -> update_diag_draw_grad / update_diag_draw (adapt/diagonal.rs:161-196, diagonal.rs:85-131)
-template <class GD>
-NM_DEV bool g_mass_matrix_adapt(GCtx<GD>& C, const double (&dm)[2], const double (&dv)[2], const double (&gm)[2], const double (&gv)[2]) {
-    if (C.sc.cnt_fg < 3) return false;
-    double sig[2] = {C.sig[0], C.sig[1]}, isig[2], mu[2];
-    C.ld(isig, C.Pp(P_ISIG));
-    if (C.P.s.use_grad_based_estimate) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool valid = 2 * gl() + k < C.dim;
-            double val = __builtin_sqrt(dv[k] / gv[k]);
-            double sd = sig[k], isd = isig[k];
-            if (!(!is_finite(val) | (val == 0.0))) {
-                val = clampd(val, 1e-20, 1e20);
-                sd = __builtin_sqrt(val);
-                isd = __builtin_sqrt(1.0 / val);
-            }
-            const double var = sd * sd;
-            double mean = var * gm[k];
-            mean = __builtin_fma(1.0, dm[k], mean);
-            sig[k] = valid ? sd : 0.0;
-            isig[k] = valid ? isd : 0.0;
-            mu[k] = valid ? mean : 0.0;
-        }
-    } else {
-        const double scale = 1.0 / (double)C.sc.cnt_fg;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool valid = 2 * gl() + k < C.dim;
-            const double d = dv[k] * scale;
-            double sd = sig[k], isd = isig[k];
-            if (!(!is_finite(d) | (d == 0.0))) {
-                const double val = clampd(d, 1e-20, 1e20);
-                sd = __builtin_sqrt(val);
-                isd = __builtin_sqrt(1.0 / val);
-            }
-            sig[k] = valid ? sd : 0.0;
-            isig[k] = valid ? isd : 0.0;
-            mu[k] = valid ? dm[k] : 0.0;
-        }
-    }
-    g_commit_mass_matrix(C, sig, isig, mu);
-    return true;
-}
-// stepsize::Strategy::init (src/stepsize/adapt.rs:91-199): the step-size search at x, after the first mass-matrix update
-template <class GD>
-NM_DEV uint64_t g_stepsize_init(GCtx<GD>& C, const double (&x)[2]) {
-    const nm_settings& s = C.P.s;
-    if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
-    GPt st;
-    {   // Hamiltonian::init_state (transformed_hamiltonian.rs:640-661, check_all :310-324)
-        double gx[2], isig[2];
-        st.logp = C.dens.eval(x, gx, C.dim);
-        C.ld(isig, C.Pp(P_ISIG));
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double t = __builtin_fma(-1.0, C.mu[k], x[k]);
-            st.z[k] = isig[k] * t;
-            st.g[k] = gx[k] * C.sig[k];
-            const bool valid = 2 * gl() + k < C.dim;
-            ok = ok && (!valid || (is_finite(st.z[k]) && is_finite(st.g[k]) && st.g[k] != 0.0 && is_finite(gx[k]) && is_finite(x[k])));
-        }
-        if (!gall(ok)) return NM_CHAIN_BAD_INIT;
-    }
-    const double logdet = C.sc.mm_logdet;
-    g_fill_normals(C.rng, C.samp, C.dim, C.zig);
-    double kacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        st.v[k] = 2 * gl() + k < C.dim ? 1.0 * C.samp[2 * gl() + k] : 0.0;
-        kacc = __builtin_fma(st.v[k], st.v[k], kacc);
-    }
-    const double ke0 = 0.5 * gsum(kacc);
-    const double e0 = ke0 - (st.logp + logdet);
-    GAccept col;
-    C.sc.step_size = s.initial_step;
-    int dir = 0;
-    for (int it = 0; it < 101; ++it) {
-        GPt o;
-        const int sign = it == 0 ? 1 : dir;
-        col.register_init(e0);
-        g_leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0);
-        const double energy = o.ke - (o.logp + logdet);
-        const double err = energy - e0;
-        if ((err > 1000.0) | !is_finite(err)) {
-            if (it > 0) C.sc.step_size = s.initial_step;
-            return NM_CHAIN_OK;
-        }
-        col.register_ok(energy);
-        const double accept = col.mean();
-        if (it == 0) { dir = accept > s.target_accept ? 1 : -1; continue; }
-        if (dir > 0) {
-            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { g_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
-            C.sc.step_size *= 2.;
-        } else {
-            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { g_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
-            C.sc.step_size /= 2.;
-        }
-    }
-    C.sc.step_size = s.initial_step;
-    return NM_CHAIN_OK;
-}
-// GlobalStrategy::adapt (src/adapt_strategy.rs:121-222); x, gx = the chosen draw
-template <bool TUNE, class GD>
-NM_DEV uint64_t g_adapt(GCtx<GD>& C, GAccept& col, bool is_good, const double (&x)[2], const double (&gx)[2]) {
-    const nm_settings& s = C.P.s;
-    ChainScalars& sc = C.sc;
-    const uint64_t draw = sc.draw_count;
-    sc.last_mean_tree_accept = col.mean();
-    sc.last_sym_mean_tree_accept = col.mean_sym();
-    sc.last_n_steps = col.count;
-    sc.last_max_energy_error = col.max_energy_error;
-    if (!TUNE || draw >= s.num_tune) {     // the sampling kernel (TUNE = false) is only launched once every chain is there
-        g_update_stepsize(C, true);
-        sc.tuning = 0;
-        return NM_CHAIN_OK;
-    }
-    if (draw < C.P.final_step_size_window) {
-        const bool is_early = draw < C.P.early_end;
-        if (!is_early && draw == C.P.early_end)
-            sc.current_window_size = sc.current_window_size > sc.cnt_bg ? sc.current_window_size : sc.cnt_bg;
-        const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
-        double fdm[2], fdv[2], fgm[2], fgv[2], bdm[2], bdv[2], bgm[2], bgv[2];
-        C.ld(fdm, C.Pp(E_DM)); C.ld(fdv, C.Pp(E_DV)); C.ld(fgm, C.Pp(E_GM)); C.ld(fgv, C.Pp(E_GV));
-        C.ld(bdm, C.Pp(B_DM)); C.ld(bdv, C.Pp(B_DV)); C.ld(bgm, C.Pp(B_GM)); C.ld(bgv, C.Pp(B_GV));
-        bool dirty = false;
-        if (is_good) {
-            sc.cnt_fg += 1;
-            sc.cnt_bg += 1;
-            g_running_variance_add(fdm, fdv, sc.cnt_fg, x);
-            g_running_variance_add(fgm, fgv, sc.cnt_fg, gx);
-            g_running_variance_add(bdm, bdv, sc.cnt_bg, x);
-            g_running_variance_add(bgm, bgv, sc.cnt_bg, gx);
-            dirty = true;
-        }
-        const bool could_switch = sc.cnt_bg >= switch_freq;
-        uint64_t next_window_size;
-        if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
-        else {
-            const double gv = (double)sc.current_window_size * s.mass_matrix_window_growth;
-            const double fl = __builtin_floor(gv);
-            const uint64_t grown = (uint64_t)((gv - fl >= 0.5) ? fl + 1.0 : fl);
-            next_window_size = sc.current_window_size + 1 > grown ? sc.current_window_size + 1 : grown;
-        }
-        const bool is_late = next_window_size + draw > C.P.final_step_size_window;
-        bool force_update = false;
-        if (could_switch && !is_late) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                fdm[k] = bdm[k]; fdv[k] = bdv[k]; fgm[k] = bgm[k]; fgv[k] = bgv[k];
-                bdm[k] = 0.0; bdv[k] = 0.0; bgm[k] = 0.0; bgv[k] = 0.0;
-            }
-            sc.cnt_fg = sc.cnt_bg;
-            sc.cnt_bg = 0;
-            force_update = true;
-            dirty = true;
-            if (!is_early) sc.current_window_size = next_window_size;
-        }
-        if (dirty) {
-            C.st(bdm, C.Pp(B_DM)); C.st(bdv, C.Pp(B_DV)); C.st(bgm, C.Pp(B_GM)); C.st(bgv, C.Pp(B_GV));
-            C.st(fdm, C.Pp(E_DM)); C.st(fdv, C.Pp(E_DV)); C.st(fgm, C.Pp(E_GM)); C.st(fgv, C.Pp(E_GV));
-        }
-        bool did_change = false;
-        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = g_mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
-        if (did_change) sc.last_update = draw;
-        g_update_estimator(C, is_late);
-        if (did_change & (sc.has_initial_mass_matrix != 0)) {
-            sc.has_initial_mass_matrix = 0;
-            return g_stepsize_init(C, x);
-        }
-        g_update_stepsize(C, false);
-        return NM_CHAIN_OK;
-    }
-    g_update_estimator(C, true);
-    g_update_stepsize(C, draw == s.num_tune - 1);
-    return NM_CHAIN_OK;
-}
-
-// NutsChain::draw (reference src/chain.rs:151-188) + the scalar statistics of expanded_draw (:190-232)
-template <bool TUNE, class GD>
-NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
-    const KParams& P = C.P;
-    ChainScalars& sc = C.sc;
-    GAccept col;
-    DrawResult R;
-    double x[2], gx[2], z[2], gz[2];
-    const uint64_t st = g_transition(C, col, R, z);
-    nm_draw_stats out;
-    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
-    if (st != NM_CHAIN_OK) {
-        sc.status = st;
-        if (P.out_stats && gl() == 0) {
-            nm_draw_stats zz = {};
-            zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = st;
-            P.out_stats[t_out * P.n_chains + chain] = zz;
-        }
-        return;
-    }
-    if (R.chosen.slot == -1 && !sc.px_stale) {
-        C.ld(x, C.Pp(P_X)); C.ld(gx, C.Pp(P_GX));
-        C.ld(z, C.Pp(P_Z)); C.ld(gz, C.Pp(P_GZ));
-    } else {
-        if (R.chosen.slot == -1) C.ld(z, C.Pp(P_Z));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double tt = z[k] * C.sig[k];
-            x[k] = __builtin_fma(1.0, C.mu[k], tt);
-        }
-        (void)C.dens.eval(x, gx, C.dim);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) gz[k] = gx[k] * C.sig[k];
-        const bool need_x = sc.tuning || t_out + 1 == P.n_draws;
-        if (need_x) { C.st(x, C.Pp(P_X)); C.st(gx, C.Pp(P_GX)); }
-        sc.px_stale = need_x ? 0 : 1;
-        C.st(z, C.Pp(P_Z)); C.st(gz, C.Pp(P_GZ));
-        sc.logp = R.chosen.logp;
-    }
-    const int64_t idx = R.chosen.idx;
-    if (P.out_positions) {
-        double* dst = P.out_positions + (size_t)(t_out * P.n_chains + chain) * P.dim;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { const int d = 2 * gl() + k; if (d < C.dim) dst[d] = x[k]; }
-    }
-    double fd = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) fd = fd + (z[k] + gz[k]) * (z[k] + gz[k]);
-    fd = gsum(fd);
-    const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
-    const int64_t trans_id = sc.transform_id;
-    sc.total_steps += col.count;
-    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);     // DrawGradCollector (adapt/diagonal.rs:73-83)
-    const uint64_t ast = g_adapt<TUNE>(C, col, is_good, x, gx);
-    if (ast != NM_CHAIN_OK) sc.status = ast;
-    out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
-    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
-    out.index_in_trajectory = idx; out.transformation_index = trans_id;
-    out.step_size = sc.step_size;
-    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size
-                      : P.s.step_size_method == NM_STEP_ADAM ? dexp(sc.log_step) : dexp(sc.log_step_adapted);
-    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
-    out.max_energy_error = sc.last_max_energy_error;
-    out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
-    out.fisher_distance = fd;
-    out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
-    out.chain_status = ast;
-    out.transformation_update_id = -1;
-    if (sc.mm_id != sc.stats_last_id) out.transformation_update_id = sc.mm_id;
-    sc.stats_last_id = sc.mm_id;
-    if (P.out_stats && gl() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
-    sc.draw_count += 1;
-}
-
-// TUNE = true: the whole adaptation is compiled in (any launch that starts inside the warm-up); TUNE = false: launches
-// after it, with the registers the adaptation would cost left to the tree
-template <class Dens, bool TUNE>
-__global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw_kernel(const KParams P) {
-    using GD = typename GroupDensity<Dens>::type;
-    __shared__ GroupShared sh;
-    dm_init_lds();
-    const int g = gg(), l = gl();
-    for (uint64_t base = (uint64_t)blockIdx.x * GPW; base < P.n_chains; base += (uint64_t)gridDim.x * GPW) {
-        const uint64_t chain = base + (uint64_t)g;
-        if (chain < P.n_chains) {
-            GCtx<GD> C(P, sh.sc[g]);
-            {   // chain scalars: HBM -> this group's LDS copy
-                const uint64_t* src = reinterpret_cast<const uint64_t*>(&P.sc[chain]);
-                uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc[g]);
-                constexpr int NW = (int)(sizeof(ChainScalars) / 8);
-                for (int i = l; i < NW; i += GS) dst[i] = src[i];
-                asm volatile("" ::: "memory");
-            }
-            C.dim = (int)P.dim;
-            C.md = (int)P.s.maxdepth;
-            C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad + 2 * l;
-            C.sv = P.svec + (size_t)blockIdx.x * P.nsslot * P.dpad + 16 * g + 2 * l;
-            C.l1z = sh.l1z[g] + 2 * l; C.l1v = sh.l1v[g] + 2 * l; C.samp = sh.samp[g];
-            C.pend = sh.pend[g];
-            C.zig = {P.zig_x, P.zig_f};
-            C.ld(C.sig, C.Pp(P_SIG)); C.ld(C.mu, C.Pp(P_MU));
-            C.rng.key = sh.sc[g].key;
-            C.rng.pos = C.sc.rng_pos; C.rng.base = C.sc.rng_pos + 16; C.rng.cache = sh.rng_cache[g];
-            C.dens.init(P.logp_params, C.dim);
-            if (C.sc.status == NM_CHAIN_OK) {
-                for (uint64_t t = 0; t < P.n_draws; ++t) {
-                    g_chain_draw<TUNE>(C, chain, t);
-                    if (C.sc.status != NM_CHAIN_OK) break;
-                }
-            }
-            C.sc.rng_pos = C.rng.pos;
-            asm volatile("" ::: "memory");
-            {
-                const uint64_t* src = reinterpret_cast<const uint64_t*>(&sh.sc[g]);
-                uint64_t* dst = reinterpret_cast<uint64_t*>(&P.sc[chain]);
-                constexpr int NW = (int)(sizeof(ChainScalars) / 8);
-                for (int i = l; i < NW; i += GS) dst[i] = src[i];
-            }
-        }
-    }
-}
-
+// lanes per chain for a dim (0: no group form)
+__host__ __device__ inline int group_size(uint64_t dim) { return dim <= 16 ? 8 : dim <= 32 ? 16 : dim <= 64 ? 32 : 0; }
 }  // namespace grp
 }  // namespace nm
+
+#define NM_GS 8
+#define NM_GNS grp8
+#include "nuts_group_impl.hpp"
+#undef NM_GS
+#undef NM_GNS
+#define NM_GS 16
+#define NM_GNS grp16
+#include "nuts_group_impl.hpp"
+#undef NM_GS
+#undef NM_GNS
+#define NM_GS 32
+#define NM_GNS grp32
+#include "nuts_group_impl.hpp"
+#undef NM_GS
+#undef NM_GNS

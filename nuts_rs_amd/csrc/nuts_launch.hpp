@@ -8,27 +8,35 @@
 
 namespace nm {
 enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
-                  K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY };  // the 8-lanes-per-chain kernels of nuts_group.hpp (dim <= 16): sampling / warm-up
+                  K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY };  // the small-chain kernels of nuts_group.hpp (dim <= 64): sampling / warm-up
 
-// the 8-lanes-per-chain kernel exists for the densities that have a group form (nuts_group.hpp)
+// the small-chain kernels exist for the densities that have a group form (nuts_group.hpp); the group size follows P.dim
+#define NM_LAUNCH_GROUP_NS(NS)                                                                                            \
+    if constexpr (!std::is_void<typename NS::GroupDensity<Dens>::type>::value) {                                          \
+        if (kind == K_GROUP_QUERY) {   /* both kernels share the block's tree scratch: the grid is sized for the roomier one */ \
+            int a = 0, b = 0;                                                                                             \
+            hipError_t st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, NS::nuts_group_draw_kernel<Dens, false>, 64, 0); \
+            if (st != hipSuccess) return st;                                                                              \
+            st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, NS::nuts_group_draw_kernel<Dens, true>, 64, 0);         \
+            *occ = a > b ? a : b;                                                                                         \
+            return st;                                                                                                    \
+        }                                                                                                                 \
+        if (kind == K_GROUP_TUNE) hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true>), dim3(grid_blocks), dim3(64), 0, stream, P); \
+        else hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false>), dim3(grid_blocks), dim3(64), 0, stream, P);    \
+        return hipGetLastError();                                                                                         \
+    } else {                                                                                                              \
+        return hipErrorInvalidValue;                                                                                      \
+    }
 template <class Dens>
 inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
-    if constexpr (!std::is_void<typename grp::GroupDensity<Dens>::type>::value) {
-        if (kind == K_GROUP_QUERY) {       // both kernels share the block's tree scratch: the grid is sized for the roomier one
-            int a = 0, b = 0;
-            hipError_t st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, grp::nuts_group_draw_kernel<Dens, false>, 64, 0);
-            if (st != hipSuccess) return st;
-            st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, grp::nuts_group_draw_kernel<Dens, true>, 64, 0);
-            *occ = a > b ? a : b;
-            return st;
-        }
-        if (kind == K_GROUP_TUNE) hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens, true>), dim3(grid_blocks), dim3(64), 0, stream, P);
-        else hipLaunchKernelGGL((grp::nuts_group_draw_kernel<Dens, false>), dim3(grid_blocks), dim3(64), 0, stream, P);
-        return hipGetLastError();
-    } else {
-        return hipErrorInvalidValue;
+    switch (grp::group_size(P.dim)) {
+    case 8: NM_LAUNCH_GROUP_NS(grp8)
+    case 16: NM_LAUNCH_GROUP_NS(grp16)
+    case 32: NM_LAUNCH_GROUP_NS(grp32)
     }
+    return hipErrorInvalidValue;
 }
+#undef NM_LAUNCH_GROUP_NS
 // grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
 // hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
 template <int DPL, int W, class Dens>

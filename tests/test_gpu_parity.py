@@ -385,7 +385,7 @@ def test_more_chains_than_resident_blocks(oracle):
 
 
 def test_lane_group_kernel_sweep(oracle):
-    """Chains with dim <= 16 can be drawn 8 per wavefront (nuts_group.hpp): randomised settings, ragged chain counts
+    """Chains with dim <= 16 / 32 / 64 can be drawn 8 / 4 / 2 per wavefront (nuts_group.hpp): randomised settings, ragged chain counts
     (partial wavefronts, more chains than resident groups), launches cut at and after the end of the warm-up — the same
     bits as the oracle, which knows nothing of the grouping."""
     rng = np.random.default_rng(77)
@@ -408,7 +408,7 @@ def test_lane_group_kernel_sweep(oracle):
                       mass_matrix_switch_freq=int(rng.choice([10, 30, 80])), early_mass_matrix_switch_freq=int(rng.choice([5, 10])),
                       mass_matrix_update_freq=int(rng.choice([1, 1, 3])), mass_matrix_window_growth=float(rng.choice([1.0, 1.5, 2.0]))))
         dens = rng.choice(["iid", "diag", "schools"], p=[0.4, 0.4, 0.2])
-        dim = 10 if dens == "schools" else int(rng.integers(1, 17))
+        dim = 10 if dens == "schools" else int(rng.integers(1, 17)) if rng.random() < 0.5 else int(rng.integers(17, 65))
         n_chains = int(rng.integers(1, 40))
         s = N.DiagNutsSettings(num_chains=n_chains, **kw)
         logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "schools": N.LogpSpec.eight_schools,

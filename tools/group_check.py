@@ -26,9 +26,11 @@ def run(settings, logp, n_chains, x0, n_tune, n_draws, lane_groups, split=(1,)):
 def main():
     rng = np.random.default_rng(3)
     cases = []
-    for dim in (1, 2, 3, 7, 10, 15, 16):
+    for dim in (1, 2, 3, 7, 10, 15, 16, 17, 24, 31, 32, 33, 47, 63, 64):
         cases.append(("iid", N.LogpSpec.iid_normal(dim, 0.5), dim, {}))
     cases.append(("diag", N.LogpSpec.diag_normal(np.exp(rng.normal(size=10))), 10, {}))
+    cases.append(("diag", N.LogpSpec.diag_normal(np.exp(rng.normal(size=29))), 29, {}))
+    cases.append(("diag", N.LogpSpec.diag_normal(np.exp(rng.normal(size=50))), 50, {}))
     cases.append(("schools", N.LogpSpec.eight_schools(), 10, {}))
     cases.append(("iid-extra", N.LogpSpec.iid_normal(10, 0.0), 10, dict(extra_doublings=2, mindepth=2)))
     cases.append(("iid-nojitter", N.LogpSpec.iid_normal(10, 0.0), 10, dict(_jitter=None)))
