@@ -221,7 +221,7 @@ typedef struct nm_engine_config {
     uint64_t dims_per_lane;        /* 0 = auto.  doubles per lane of every live vector: 2, 4, 8 or 16 */
     uint64_t waves_per_chain;      /* 0 = auto.  1, 2 or 4 wavefronts cooperate on one chain (dim <= 64*waves*dims_per_lane) */
     uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
-    uint64_t lane_groups;          /* chains with dim <= 16: draw them 8 per wavefront (8 lanes each) instead of one per wavefront, same results.
+    uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
                                     * 0 = auto (when n_chains >= 64), 1 = never, 2 = whenever the kernel applies */
     uint64_t reserved[2];
 } nm_engine_config;
@@ -289,7 +289,7 @@ uint64_t  nm_engine_num_chains(const nm_engine* e);
  * the oracle reproduces it with gpu_cfg(threads_per_chain). */
 uint64_t  nm_engine_threads_per_chain(const nm_engine* e);
 uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
-/* draw launches served by the 8-chains-per-wavefront kernel so far (nm_engine_config.lane_groups) */
+/* draw launches served by the several-chains-per-wavefront kernels so far (nm_engine_config.lane_groups) */
 uint64_t  nm_engine_group_launches(const nm_engine* e);
 /* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */
 void*     nm_engine_stream(nm_engine* e);

@@ -30,6 +30,8 @@ CONFIGS = {
     "k3": dict(name="K3 Neal's funnel dim 101", logp=lambda: N.LogpSpec.funnel(101), chains=8192, tune=400),
     "k5": dict(name="K5 normal with a full precision matrix dim 256 (per-chain GEMV)", logp=lambda: N.LogpSpec.mvn_precision(_k5_precision(256)),
                chains=4096, tune=400),
+    "s24": dict(name="small chains: diag normal dim 24 (16 lanes per chain)", logp=lambda: N.LogpSpec.diag_normal(np.exp(np.linspace(-1, 1, 24))), chains=32768, tune=400),
+    "s48": dict(name="small chains: diag normal dim 48 (32 lanes per chain)", logp=lambda: N.LogpSpec.diag_normal(np.exp(np.linspace(-1, 1, 48))), chains=32768, tune=400),
     "k4": dict(name="K4 8 schools non-centered dim 10 (one GPU's shard of 65536)", logp=N.LogpSpec.eight_schools,
                chains=8192, tune=400),
 }
