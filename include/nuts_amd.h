@@ -222,7 +222,7 @@ typedef struct nm_engine_config {
     uint64_t waves_per_chain;      /* 0 = auto.  1, 2 or 4 wavefronts cooperate on one chain (dim <= 64*waves*dims_per_lane) */
     uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
     uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
-                                    * 0 = auto (when n_chains >= 64), 1 = never, 2 = whenever the kernel applies */
+                                    * 0 = auto (when there are more chains than resident wavefronts, ~2048), 1 = never, 2 = whenever the kernel applies */
     uint64_t reserved[2];
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);

@@ -332,13 +332,14 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch));
         E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
+        const uint64_t wave_slots = resident;                      // chains the wave-per-chain kernel runs at once
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
-        // small chains: 8 lanes per chain, 8 chains per wave (nuts_group.hpp)
+        // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const bool group_density = logp->kind == NM_LOGP_IID_NORMAL || logp->kind == NM_LOGP_DIAG_NORMAL || logp->kind == NM_LOGP_EIGHT_SCHOOLS;
         const int gs = grp::group_size(logp->dim);
         if (cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
-            s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains >= 64 || cfg.lane_groups == 2)) {
+            s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
             E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, nullptr));

@@ -430,16 +430,19 @@ def test_lane_group_kernel_sweep(oracle):
             raise AssertionError(f"case {i} ({dens}, dim {dim}, {n_chains} chains, grid {grid}, {kw}): {e}") from None
 
 
-def test_lane_group_kernel_is_the_default_for_small_chains(oracle):
-    """Automatic choice (n_chains >= 64): same draws as with the grouping switched off, and the final state the host
-    reads back (positions, gradients, step sizes) is the same too."""
-    s = N.DiagNutsSettings(num_chains=100, seed=5, num_tune=60)
+def test_lane_group_kernel_is_the_default_for_many_small_chains(oracle):
+    """Automatic choice (more chains than resident wavefronts): same draws as with the grouping switched off, and the
+    final state the host reads back (positions, gradients, step sizes, mass matrix) is the same too."""
+    n = 6000
+    s = N.DiagNutsSettings(num_chains=n, seed=5, num_tune=60)
     logp = N.LogpSpec.eight_schools()
-    x0 = oracle.init_positions_uniform(s.seed, 0, 100, 10)
-    a = run_engine(s, logp, 100, x0, 110, lane_groups=0, splits=(60,))
-    b = run_engine(s, logp, 100, x0, 110, lane_groups=1, splits=(60,))
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, 10)
+    a = run_engine(s, logp, n, x0, 90, lane_groups=0, splits=(60,))
+    b = run_engine(s, logp, n, x0, 90, lane_groups=1, splits=(60,))
     assert_bit_exact(a[0], a[1], b[0], b[1])
     assert a[2]["group_launches"] == 2 and b[2]["group_launches"] == 0
     for k in ("x", "gx", "step_sizes", "stds", "mean"):
         assert (a[2][k].view(np.uint64) == b[2][k].view(np.uint64)).all(), k
     assert a[2]["counters"]["total_leapfrogs"] == b[2]["counters"]["total_leapfrogs"]
+    few = run_engine(s, logp, 100, x0[:100], 10)
+    assert few[2]["group_launches"] == 0        # few chains: one wavefront per chain finishes sooner
