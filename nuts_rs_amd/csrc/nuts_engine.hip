@@ -336,7 +336,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
-        const bool group_density = logp->kind == NM_LOGP_IID_NORMAL || logp->kind == NM_LOGP_DIAG_NORMAL || logp->kind == NM_LOGP_EIGHT_SCHOOLS;
+        const bool group_density = logp->kind != NM_LOGP_MODULE;      // every built-in density has a group form
         const int gs = grp::group_size(logp->dim);
         if (cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains

@@ -39,6 +39,7 @@ NM_DEV uint64_t gbcast_u64(uint64_t x, int j) {
 struct GroupShared {
     uint32_t rng_cache[GPW][16 * GS];         // GS ChaCha blocks per chain
     double samp[GPW][2 * GS];                     // stream-ordered normals of the momentum refresh
+    double xs[GPW][2 * GS];                   // the position, visible to the group (densities that need all of x)
     double l1z[GPW][2 * GS], l1v[GPW][2 * GS];        // L[1] end point
     PendEntry pend[GPW][GMAXDEPTH + 1];
     ChainScalars sc[GPW];
@@ -47,6 +48,7 @@ struct GroupShared {
 // ---- densities (group forms of IidNormal / DiagNormal / EightSchools: same operations, group-relative lanes) ----
 struct GIidNormal {
     double mu;
+    NM_DEV void set_lds(double*) {}
     NM_DEV void init(const double* params, int) { mu = params[0]; }
     NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
         double acc = 0.0;
@@ -62,6 +64,7 @@ struct GIidNormal {
     }
 };
 struct GDiagNormal {
+    NM_DEV void set_lds(double*) {}
     const double* prec;
     double norm;
     NM_DEV void init(const double* params, int dim) {
@@ -90,6 +93,7 @@ struct GDiagNormal {
     }
 };
 struct GEightSchools {
+    NM_DEV void set_lds(double*) {}
     const double* par;
     NM_DEV void init(const double* params, int) { par = params; }
     NM_DEV double eval(const double (&x)[2], double (&gx)[2], int) const {
@@ -132,9 +136,69 @@ struct GEightSchools {
         return gsum(acc);
     }
 };
+struct GFunnel {
+    NM_DEV void set_lds(double*) {}
+    NM_DEV void init(const double*, int) {}
+    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
+        const double v = gbcast(x[0], 0);
+        const double kk = (double)(dim - 1);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * gl() + k;
+            const bool in = d >= 1 && d < dim;
+            acc = acc + (in ? x[k] * x[k] : 0.0);
+        }
+        const double ss = gsum(acc);
+        const double ev = dexp(-v);
+        const double g0 = -v / 9.0 - 0.5 * kk + 0.5 * ev * ss;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * gl() + k;
+            gx[k] = d == 0 ? g0 : (d < dim ? -ev * x[k] : 0.0);
+        }
+        return -v * v / 18.0 - 0.5 * kk * v - 0.5 * ev * ss;
+    }
+};
+struct GMvnPrec {            // y_d = sum_j P[j][d] x_j, j ascending, one fma per term; x_j published through the group's LDS row
+    const double* P;
+    double* xs;
+    NM_DEV void set_lds(double* lds) { xs = lds; }
+    NM_DEV void init(const double* params, int) { P = params; }
+    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * gl() + k;
+            xs[d] = d < dim ? x[k] : 0.0;
+        }
+        asm volatile("" ::: "memory");
+        double y[2] = {0.0, 0.0};
+        for (int j = 0; j < dim; ++j) {
+            const double xj = xs[j];
+            const double* row = P + (size_t)j * (size_t)dim;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * gl() + k;
+                const double p = d < dim ? row[d] : 0.0;
+                y[k] = __builtin_fma(p, xj, y[k]);
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool valid = 2 * gl() + k < dim;
+            gx[k] = valid ? -y[k] : 0.0;
+            acc = acc + (valid ? x[k] * y[k] : 0.0);
+        }
+        return -0.5 * gsum(acc);
+    }
+};
 template <class Dens> struct GroupDensity { using type = void; };
 template <> struct GroupDensity<IidNormal> { using type = GIidNormal; };
 template <> struct GroupDensity<DiagNormal> { using type = GDiagNormal; };
+template <> struct GroupDensity<Funnel> { using type = GFunnel; };
+template <> struct GroupDensity<MvnPrec> { using type = GMvnPrec; };
 template <> struct GroupDensity<EightSchools> { using type = std::conditional<GS == 8, GEightSchools, void>::type; };   // dim 10
 
 // ---- the chain's generator, one copy per group (same stream as DevRng) ----
@@ -960,6 +1024,7 @@ __global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw
             C.ld(C.sig, C.Pp(P_SIG)); C.ld(C.mu, C.Pp(P_MU));
             C.rng.key = sh.sc[g].key;
             C.rng.pos = C.sc.rng_pos; C.rng.base = C.sc.rng_pos + 16; C.rng.cache = sh.rng_cache[g];
+            C.dens.set_lds(sh.xs[g]);
             C.dens.init(P.logp_params, C.dim);
             if (C.sc.status == NM_CHAIN_OK) {
                 for (uint64_t t = 0; t < P.n_draws; ++t) {

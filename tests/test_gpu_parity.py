@@ -407,11 +407,19 @@ def test_lane_group_kernel_sweep(oracle):
                       early_window=float(rng.choice([0.1, 0.3, 0.5])), step_size_window=float(rng.choice([0.1, 0.15, 0.3])),
                       mass_matrix_switch_freq=int(rng.choice([10, 30, 80])), early_mass_matrix_switch_freq=int(rng.choice([5, 10])),
                       mass_matrix_update_freq=int(rng.choice([1, 1, 3])), mass_matrix_window_growth=float(rng.choice([1.0, 1.5, 2.0]))))
-        dens = rng.choice(["iid", "diag", "schools"], p=[0.4, 0.4, 0.2])
+        dens = rng.choice(["iid", "diag", "schools", "funnel", "mvn"], p=[0.25, 0.3, 0.15, 0.15, 0.15])
         dim = 10 if dens == "schools" else int(rng.integers(1, 17)) if rng.random() < 0.5 else int(rng.integers(17, 65))
+        if dens == "funnel":
+            dim = max(dim, 2)
         n_chains = int(rng.integers(1, 40))
         s = N.DiagNutsSettings(num_chains=n_chains, **kw)
+
+        def mvn():
+            a_ = np.random.default_rng(i).normal(size=(dim, dim))
+            p_ = a_ @ a_.T / dim + np.eye(dim)
+            return N.LogpSpec.mvn_precision((p_ + p_.T) / 2)
         logp = {"iid": lambda: N.LogpSpec.iid_normal(dim, 3.0), "schools": N.LogpSpec.eight_schools,
+                "funnel": lambda: N.LogpSpec.funnel(dim), "mvn": mvn,
                 "diag": lambda: N.LogpSpec.diag_normal(np.exp(np.random.default_rng(i).uniform(-3, 3, dim)))}[dens]()
         x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
         n_draws = s.num_tune + 40
