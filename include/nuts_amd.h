@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 3
+#define NM_ABI_VERSION 4
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -146,6 +146,11 @@ typedef struct nm_logp_spec {
  * kind = NM_LOGP_MODULE, module_path = "my_density.so".  `python -m nuts_rs_amd.build` has a helper
  * (nuts_rs_amd.build.build_density_module).  The module exports nm_module_launch / nm_module_info; the engine checks
  * that it was built against the same kernel-parameter layout.
+ * Group form (optional, dim <= 64): many small chains are drawn several per wavefront (nm_engine_config.lane_groups).
+ * A module takes part if it also defines `template <class L> struct MyDensityGroup` with `set_lds(ptr)`,
+ * `init(params, dim)` and `double eval(const double (&x)[2], double (&grad)[2], int dim) const`, where this lane holds
+ * elements 2 L::lane(), 2 L::lane() + 1 and L::sum / L::bcast combine the chain's lanes, and is built with
+ * -DNM_MODULE_GROUP_DENSITY=MyDensityGroup -DNM_MODULE_GS=<8|16|32 for dim <= 16|32|64> (tests/user_density/ has one).
  * ------------------------------------------------------------------------------------------- */
 /* The tiling the engine uses for `dim` (requested_* = 0: automatic): doubles per lane and waves per chain. */
 nm_status nm_pick_tiling(uint64_t dim, uint64_t requested_dims_per_lane, uint64_t requested_waves_per_chain,

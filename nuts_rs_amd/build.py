@@ -66,12 +66,16 @@ def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):
     raise ValueError(f"no tiling for dim {dim}")
 
 
-def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=()):
+def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None):
     """Compile a user density (a functor `struct_name` defined in `header`, see include/nuts_amd.h "User densities")
     with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s)."""
     dpl, w = pick_tiling(dim, dims_per_lane, waves_per_chain)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     header = os.path.abspath(header)
+    if group_struct:          # the density's group form: several chains per wavefront for dim <= 64
+        if dim > 64:
+            raise ValueError("group forms exist for dim <= 64")
+        extra_flags = list(extra_flags) + [f"-DNM_MODULE_GROUP_DENSITY={group_struct}", f"-DNM_MODULE_GS={8 if dim <= 16 else 16 if dim <= 32 else 32}"]
     cmd = [hipcc] + FLAGS + list(extra_flags) + [
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
         f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),

@@ -140,7 +140,7 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 // ---------------------------------------------------------------------------------------------
 
 typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ);
-typedef void (*module_info_fn)(uint64_t out[4]);
+typedef void (*module_info_fn)(uint64_t out[5]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
                          module_launch_fn module = nullptr) {
@@ -244,6 +244,7 @@ struct nm_engine {
     size_t staging_bytes[10] = {};
     void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
     module_launch_fn module_launch = nullptr;
+    int module_group_lanes = 0;             // lanes per chain of the module's group form (0: it has none)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -317,8 +318,9 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         module_info_fn info = (module_info_fn)dlsym(e->module_handle, "nm_module_info");
         e->module_launch = (module_launch_fn)dlsym(e->module_handle, "nm_module_launch");
         if (!info || !e->module_launch) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "%s is not a density module (nm_module_info / nm_module_launch missing)", logp->module_path); }
-        uint64_t mi[4] = {0, 0, 0, 0};
+        uint64_t mi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         info(mi);
+        e->module_group_lanes = (int)mi[4];
         if (mi[0] != sizeof(KParams) || mi[1] != NM_ABI_VERSION) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module built against another engine (kernel parameters %llu bytes / ABI %llu, engine %zu / %d)", (unsigned long long)mi[0], (unsigned long long)mi[1], sizeof(KParams), NM_ABI_VERSION); }
         if ((int)mi[2] != dpl || (int)mi[3] != wv) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module was built for tiling (%llu doubles per lane, %llu waves) but dim %llu uses (%d, %d): rebuild it with nm_pick_tiling's answer", (unsigned long long)mi[2], (unsigned long long)mi[3], (unsigned long long)logp->dim, dpl, wv); }
     }
@@ -336,13 +338,13 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
-        const bool group_density = logp->kind != NM_LOGP_MODULE;      // every built-in density has a group form
         const int gs = grp::group_size(logp->dim);
+        const bool group_density = logp->kind != NM_LOGP_MODULE || (gs && e->module_group_lanes == gs);   // every built-in density has a group form
         if (cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
-            E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, nullptr));
+            E_TRY(launch(logp->kind, dpl, wv, K_GROUP_QUERY, dummy, 0, nullptr, &gocc, e->module_launch));
             uint64_t gres = (uint64_t)(gocc > 0 ? gocc : 1) * (uint64_t)(cus > 0 ? cus : 1);
             if (cfg.grid_blocks) gres = cfg.grid_blocks;
             const uint64_t need = (n_chains + (64 / gs) - 1) / (64 / gs);
@@ -465,7 +467,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
                             !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
     if (e->group_grid && only_basic) {
         // a launch that starts inside the warm-up takes the kernel with the adaptation compiled in
-        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, nullptr));
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, e->module_launch));
         e->group_launches += 1;
     } else
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));

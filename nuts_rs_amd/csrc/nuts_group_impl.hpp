@@ -36,6 +36,15 @@ NM_DEV uint64_t gbcast_u64(uint64_t x, int j) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// what the group form of a USER density (include/nuts_amd.h "User densities") works with: its lane holds elements
+// 2 lane(), 2 lane() + 1 of the chain's vectors
+struct Lanes {
+    static constexpr int kLanes = GS;
+    NM_DEV static int lane() { return gl(); }
+    NM_DEV static double sum(double x) { return gsum(x); }                 // over the chain's lanes, the engine's order
+    NM_DEV static double bcast(double x, int j) { return gbcast(x, j); }   // the value lane j of this chain holds
+};
+
 struct GroupShared {
     uint32_t rng_cache[GPW][16 * GS];         // GS ChaCha blocks per chain
     double samp[GPW][2 * GS];                     // stream-ordered normals of the momentum refresh

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/nuts_amd.h but not exported"
     assert set(names) == set(_lib.ABI_SYMBOLS)
-    assert L.nm_abi_version() == 3
+    assert L.nm_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -23,21 +23,23 @@ def module_path(dim=DIM):
     return os.path.join(MODDIR, f"my_diag_normal_dpl{dpl}_w{w}.so")
 
 
-def ensure_module(dim=DIM):
-    out = module_path(dim)
-    srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp")]
+def ensure_module(dim=DIM, group=False):
+    out = module_path(dim) if not group else os.path.join(MODDIR, f"my_diag_normal_group_dim{dim}.so")
+    srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp",
+                                                          "nuts_group.hpp", "nuts_group_impl.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         os.makedirs(MODDIR, exist_ok=True)
-        B.build_density_module(HEADER, "MyDiagNormal", dim, out)
+        B.build_density_module(HEADER, "MyDiagNormal", dim, out, group_struct="MyDiagNormalGroup" if group else None)
     return out
 
 
 def test_module_builds_and_exports():
     path = ensure_module()
     m = C.CDLL(path)
-    info = (C.c_uint64 * 4)()
+    info = (C.c_uint64 * 8)()
     m.nm_module_info(info)
     assert info[1] == N.load_library().nm_abi_version() and (info[2], info[3]) == B.pick_tiling(DIM) == (2, 1)
+    assert info[4] == 0                                             # built without a group form
     assert hasattr(m, "nm_module_launch")
     L = N.load_library()
     d, w = C.c_uint64(), C.c_uint64()
@@ -69,3 +71,37 @@ def test_user_density_module_matches_builtin_and_oracle(oracle):
     with pytest.raises(N.NutsAmdError) as e:
         N.ChainBatch(s, N.LogpSpec.module(DIM, os.path.join(HERE, "no_such_module.so"), prec), 5)
     assert e.value.status == 1 and "cannot load" in str(e.value)
+
+
+GROUP_DIM = 12
+
+
+def test_group_form_module_builds():
+    m = C.CDLL(ensure_module(GROUP_DIM, group=True))
+    info = (C.c_uint64 * 8)()
+    m.nm_module_info(info)
+    assert (info[2], info[3], info[4]) == (2, 1, 8)                 # 8 lanes per chain for dim <= 16
+
+
+@pytest.mark.gpu
+def test_user_density_group_form_matches_oracle(oracle):
+    """A user density with a group form: its chains are drawn 8 per wavefront, with the oracle's bits."""
+    path = ensure_module(GROUP_DIM, group=True)
+    prec = np.exp(np.random.default_rng(4).uniform(-2, 2, GROUP_DIM))
+    n = 37
+    s = N.DiagNutsSettings(num_chains=n, seed=78, num_tune=70)
+    x0 = oracle.init_positions_uniform(78, 0, n, GROUP_DIM)
+    b = N.ChainBatch(s, N.LogpSpec.module(GROUP_DIM, path, prec), n, lane_groups=2)
+    b.set_position(x0)
+    pos, st = b.draw_many(120)
+    assert b.group_launches() == 1
+    b.close()
+    pos_o, st_o, _, failed = run_oracle(oracle, s, N.LogpSpec.diag_normal(prec), n, x0, 120)
+    assert failed == 0
+    assert_bit_exact(pos, st, pos_o, st_o)
+    # a module without a group form keeps one wavefront per chain, whatever lane_groups says
+    b = N.ChainBatch(s, N.LogpSpec.module(DIM, ensure_module(), np.ones(DIM)), n, lane_groups=2)
+    b.set_position(oracle.init_positions_uniform(78, 0, n, DIM))
+    b.draw_many(5)
+    assert b.group_launches() == 0
+    b.close()

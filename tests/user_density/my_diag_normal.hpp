@@ -37,3 +37,35 @@ struct MyDiagNormal {
         return -0.5 * R.sum(acc) + norm;
     }
 };
+
+// The same density in GROUP form (optional): for many small chains the engine draws several chains per wavefront, each
+// on L::kLanes lanes; this lane holds elements 2 L::lane(), 2 L::lane() + 1.  Same operations, so the same results.
+template <class L>
+struct MyDiagNormalGroup {
+    const double* prec;
+    double norm;
+    NM_DEV void set_lds(double*) {}
+    NM_DEV void init(const double* params, int dim) {
+        prec = params;
+        double acc = 0.0;
+        for (int j = 0; j < 2; ++j) {
+            const int d = 2 * L::lane() + j;
+            acc = acc + (d < dim ? nm::dlog(params[d < dim ? d : 0]) : 0.0);
+        }
+        const double log_det_p = L::sum(acc);
+        norm = -0.5 * ((double)dim * nm::dlog(6.283185307179586) - log_det_p);
+    }
+    NM_DEV double eval(const double (&x)[2], double (&gx)[2], int dim) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * L::lane() + k;
+            const bool valid = d < dim;
+            const double p = valid ? prec[d] : 0.0;
+            const double px = p * x[k];
+            gx[k] = valid ? -px : 0.0;
+            acc = acc + (valid ? x[k] * px : 0.0);
+        }
+        return -0.5 * L::sum(acc) + norm;
+    }
+};
