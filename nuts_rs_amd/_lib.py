@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NUTS_AMD_LIB", os.path.join(_HERE, "libnuts_amd.so"))   # env override: tuning builds
 
 NM_OK = 0
+NM_ERR_LOGP_FAILURE = 6
 STATUS_NAMES = {0: "NM_OK", 1: "NM_ERR_INVALID_ARG", 2: "NM_ERR_NO_DEVICE", 3: "NM_ERR_HIP", 4: "NM_ERR_UNSUPPORTED",
                 5: "NM_ERR_BAD_INIT", 6: "NM_ERR_LOGP_FAILURE", 7: "NM_ERR_STATE"}
 

@@ -239,12 +239,16 @@ class ChainBatch:
                          float(r["step_size"]), int(r["n_steps"])) for r in st[0]]
         return pos[0], prog
 
-    def draw_many(self, n_draws, positions=True, stats=True):
-        """n_draws draws of every chain; returns host arrays ([n_draws, n_chains, dim], stats [n_draws, n_chains])."""
+    def draw_many(self, n_draws, positions=True, stats=True, raise_on_error=True):
+        """n_draws draws of every chain; returns host arrays ([n_draws, n_chains, dim], stats [n_draws, n_chains]).
+        Chains that stopped with an error (or never started: BadInitGrad) raise NM_ERR_LOGP_FAILURE after the healthy
+        chains' results are in the arrays; raise_on_error=False returns them anyway (rows of failed chains are unwritten)."""
         pos = np.empty((n_draws, self.n_chains, self.logp.dim)) if positions else None
         st = np.zeros((n_draws, self.n_chains), dtype=STATS_DTYPE) if stats else None
-        check(_lib.load().nm_engine_draw_to_host(self._h, n_draws, pos.ctypes.data if positions else None,
-                                                 st.ctypes.data if stats else None))
+        rc = _lib.load().nm_engine_draw_to_host(self._h, n_draws, pos.ctypes.data if positions else None,
+                                                st.ctypes.data if stats else None)
+        if rc != _lib.NM_ERR_LOGP_FAILURE or raise_on_error:
+            check(rc)
         return pos, st
 
     def stored_vectors(self):

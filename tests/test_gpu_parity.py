@@ -454,3 +454,27 @@ def test_lane_group_kernel_is_the_default_for_many_small_chains(oracle):
     assert a[2]["counters"]["total_leapfrogs"] == b[2]["counters"]["total_leapfrogs"]
     few = run_engine(s, logp, 100, x0[:100], 10)
     assert few[2]["group_launches"] == 0        # few chains: one wavefront per chain finishes sooner
+
+
+def test_lane_group_kernel_skips_failed_chains(oracle):
+    """A chain whose set_position failed (BadInitGrad) shares a wavefront with seven healthy ones: they draw what they
+    draw with one wavefront per chain; the failed chain stays untouched."""
+    n, dim = 19, 8
+    s = N.DiagNutsSettings(num_chains=n, seed=34, num_tune=40)
+    logp = N.LogpSpec.iid_normal(dim, 3.0)
+    x0 = oracle.init_positions_uniform(34, 0, n, dim)
+    x0[1] = 3.0
+    x0[9] = 3.0
+    good = np.array([c not in (1, 9) for c in range(n)])
+    out = {}
+    for lg in (1, 2):
+        b = N.ChainBatch(s, logp, n, lane_groups=lg)
+        assert list(np.nonzero(b.set_position(x0, raise_on_error=False))[0]) == [1, 9]
+        with pytest.raises(N.NutsAmdError):
+            b.draw_many(1)                            # a failed chain is an error, as Chain::draw's Result is
+        pos, st = b.draw_many(70, raise_on_error=False)
+        out[lg] = (pos[:, good], st[:, good], b.group_launches(), b.positions()[~good])
+        b.close()
+    assert out[1][2] == 0 and out[2][2] == 2
+    assert_bit_exact(out[2][0], out[2][1], out[1][0], out[1][1])
+    assert (out[2][3] == out[1][3]).all() and (out[2][1]["chain_status"] == 0).all()
