@@ -462,10 +462,8 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    // small chains, positions / scalar statistics only: the 8-chains-per-wavefront kernel computes the same draws
-    const bool only_basic = !out->d_gradient && !out->d_transformed_position && !out->d_transformed_gradient && !out->d_mass_matrix_inv &&
-                            !out->d_transformation_mu && !out->d_divergence_start && !out->d_divergence_start_gradient && !out->d_divergence_end;
-    if (e->group_grid && only_basic) {
+    // small chains, many of them: the several-chains-per-wavefront kernels compute the same draws and statistics
+    if (e->group_grid) {
         // a launch that starts inside the warm-up takes the kernel with the adaptation compiled in
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, e->module_launch));
         e->group_launches += 1;

@@ -11,8 +11,8 @@
 //   * the same exp / ln, the same ChaCha stream and ziggurat, the same tree (ported from nuts_transition), the same
 //     adaptation, the same memory layout (pvec slots per chain; a block's tree scratch holds its chains side by side).
 // The doubling loop is naturally lockstep (every group is at depth d in iteration d); groups whose tree ended wait for
-// the wave's longest tree.  Scope: warm-up and sampling draws, positions + scalar statistics, the elementwise densities
-// and 8 schools, maxdepth <= 10; the engine uses the wave kernel otherwise (and for set_position).
+// the wave's longest tree.  Scope: warm-up and sampling draws with all their statistics, every built-in density (and user
+// modules that bring a group form), maxdepth <= 10; the engine uses the wave kernel otherwise (and for set_position).
 // The implementation (nuts_group_impl.hpp) is compiled once per group size into namespaces grp8 / grp16 / grp32.
 #pragma once
 #include <type_traits>

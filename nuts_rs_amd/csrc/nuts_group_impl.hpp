@@ -470,6 +470,7 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
     }
     R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false;
     R.divergence_energy_error = 0.; R.div_start_idx = 0;
+    const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
     bool fatal = false;
     bool in_extra = false;
     uint64_t extra_left = 0;
@@ -497,7 +498,7 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
         const bool reuse_edge = o_is_edge && o_edge_sign == sign;
         o_is_edge = false;
 
-#define NM_G_ACCOUNT(PT, WOUT)                                                                            \
+#define NM_G_ACCOUNT(START, PT, WOUT)                                                                      \
         {                                                                                                 \
             const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
             const double err_ = energy_ - e0;                                                             \
@@ -505,6 +506,9 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
                 R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
+                if (want_div) {          /* DivergenceInfo locations: the F[0] scratch pair is dead from here on */ \
+                    C.st((START).z, C.Ss(slot_F(0))); C.st((PT).z, C.Ss(slot_F(0) + 1));                  \
+                }                                                                                         \
                 stop = STOP_DIVERGING;                                                                    \
             } else {                                                                                      \
                 col.register_ok(energy_);                                                                 \
@@ -515,7 +519,7 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
         if (depth == 0) {
             g_leapfrog(C, E, O, epsilon);
             O.idx = edge_idx + (int64_t)sign;
-            NM_G_ACCOUNT(O, sub_log_size)
+            NM_G_ACCOUNT(E, O, sub_log_size)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
             if (!reuse_edge) {
@@ -526,11 +530,11 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
                 double wE = 0., wO = 0.;
                 g_leapfrog(C, O, E, epsilon);
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
-                NM_G_ACCOUNT(E, wE)
+                NM_G_ACCOUNT(O, E, wE)
                 if (stop != STOP_NONE) break;
                 g_leapfrog(C, E, O, epsilon);
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
-                NM_G_ACCOUNT(O, wO)
+                NM_G_ACCOUNT(E, O, wO)
                 if (stop != STOP_NONE) break;
                 const uint64_t nn = n + 1;
                 const int t = (int)__builtin_ctzll(~nn);
@@ -930,6 +934,34 @@ NM_DEV uint64_t g_adapt(GCtx<GD>& C, GAccept& col, bool is_good, const double (&
     return NM_CHAIN_OK;
 }
 
+template <class GD>
+NM_DEV void g_write_row(GCtx<GD>& C, double* base, size_t row, const double (&t)[2]) {
+    if (!base) return;
+    double* dst = base + row;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int d = 2 * gl() + k; if (d < C.dim) dst[d] = t[k]; }
+}
+// DivergenceInfo.{start_location, start_gradient, end_location} (transformed_hamiltonian.rs:590-604), as emit_divergence_vectors
+template <class GD>
+NM_DEV void g_emit_divergence_vectors(GCtx<GD>& C, int64_t start_idx, size_t row) {
+    const KParams& P = C.P;
+    double x[2], gx[2], zt[2];
+    if (start_idx == 0) {
+        C.ld(x, C.Pp(P_X)); C.ld(gx, C.Pp(P_GX));
+    } else {
+        C.ld(zt, C.Ss(slot_F(0)));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) x[k] = __builtin_fma(1.0, C.mu[k], zt[k] * C.sig[k]);
+        (void)C.dens.eval(x, gx, C.dim);
+    }
+    g_write_row(C, P.out_div_start, row, x);
+    g_write_row(C, P.out_div_start_grad, row, gx);
+    C.ld(zt, C.Ss(slot_F(0) + 1));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) x[k] = __builtin_fma(1.0, C.mu[k], zt[k] * C.sig[k]);
+    g_write_row(C, P.out_div_end, row, x);
+}
+
 // NutsChain::draw (reference src/chain.rs:151-188) + the scalar statistics of expanded_draw (:190-232)
 template <bool TUNE, class GD>
 NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
@@ -950,6 +982,9 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
         }
         return;
     }
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
+        g_emit_divergence_vectors(C, R.div_start_idx, row);          // before P_X / P_GX take the new draw
     if (R.chosen.slot == -1 && !sc.px_stale) {
         C.ld(x, C.Pp(P_X)); C.ld(gx, C.Pp(P_GX));
         C.ld(z, C.Pp(P_Z)); C.ld(gz, C.Pp(P_GZ));
@@ -963,18 +998,17 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
         (void)C.dens.eval(x, gx, C.dim);
 #pragma unroll
         for (int k = 0; k < 2; ++k) gz[k] = gx[k] * C.sig[k];
-        const bool need_x = sc.tuning || t_out + 1 == P.n_draws;
+        const bool need_x = sc.tuning || t_out + 1 == P.n_draws || P.out_div_start || P.out_div_start_grad;
         if (need_x) { C.st(x, C.Pp(P_X)); C.st(gx, C.Pp(P_GX)); }
         sc.px_stale = need_x ? 0 : 1;
         C.st(z, C.Pp(P_Z)); C.st(gz, C.Pp(P_GZ));
         sc.logp = R.chosen.logp;
     }
     const int64_t idx = R.chosen.idx;
-    if (P.out_positions) {
-        double* dst = P.out_positions + (size_t)(t_out * P.n_chains + chain) * P.dim;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { const int d = 2 * gl() + k; if (d < C.dim) dst[d] = x[k]; }
-    }
+    g_write_row(C, P.out_positions, row, x);
+    g_write_row(C, P.out_gradient, row, gx);                     // PointStats (transformed_hamiltonian.rs:122-157)
+    g_write_row(C, P.out_tpos, row, z);
+    g_write_row(C, P.out_tgrad, row, gz);
     double fd = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) fd = fd + (z[k] + gz[k]) * (z[k] + gz[k]);
@@ -998,7 +1032,11 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
     out.chain_status = ast;
     out.transformation_update_id = -1;
-    if (sc.mm_id != sc.stats_last_id) out.transformation_update_id = sc.mm_id;
+    if (sc.mm_id != sc.stats_last_id) {                         // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70)
+        out.transformation_update_id = sc.mm_id;
+        g_write_row(C, P.out_mm_inv, row, C.sig);
+        g_write_row(C, P.out_mm_mu, row, C.mu);
+    }
     sc.stats_last_id = sc.mm_id;
     if (P.out_stats && gl() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;

@@ -253,6 +253,11 @@ VECTOR_CASES = [
     ("low_threshold_iid", dict(seed=32, num_tune=40, max_energy_error=0.25), "iid", 70, 6, 70, (0, 0)),
     ("schools", dict(seed=33, num_tune=120), "schools", 10, 8, 200, (0, 0)),
     ("iid_w2", dict(seed=34, num_tune=40, max_energy_error=0.5), "iid", 600, 3, 55, (8, 2)),
+    # several chains per wavefront (nuts_group.hpp): 8 / 4 / 2 chains, the last wavefront partly filled
+    ("grouped_funnel_dim11", dict(seed=35, num_tune=80), "funnel", 11, 21, 160, "group"),
+    ("grouped_schools", dict(seed=36, num_tune=120), "schools", 10, 13, 200, "group"),
+    ("grouped_low_threshold_dim30", dict(seed=37, num_tune=40, max_energy_error=0.25), "iid", 30, 9, 70, "group"),
+    ("grouped_funnel_dim50", dict(seed=38, num_tune=80), "funnel", 50, 5, 160, "group"),
 ]
 
 
@@ -260,18 +265,21 @@ VECTOR_CASES = [
 def test_expanded_draw_vector_statistics_bit_exact(oracle, case):
     """`expanded_draw` (src/chain.rs:190-204): gradient / transformed point / mass-matrix events / divergence
     locations, against the oracle's copies of the same reference fields."""
-    _, kw, dens, dim, n_chains, n_draws, (dpl, wpc) = case
+    _, kw, dens, dim, n_chains, n_draws, tiling = case
+    grouped = tiling == "group"
+    dpl, wpc = (0, 0) if grouped else tiling
     s = N.DiagNutsSettings(num_chains=n_chains, store_gradient=True, store_unconstrained=True, store_transformed=True,
                            store_divergences=True, **kw)
     s.adapt_options.mass_matrix_options.store_mass_matrix = True
     logp = {"funnel": lambda: N.LogpSpec.funnel(dim), "iid": lambda: N.LogpSpec.iid_normal(dim, 3.0),
             "schools": N.LogpSpec.eight_schools}[dens]()
     x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
-    b = N.ChainBatch(s, logp, n_chains, dims_per_lane=dpl, waves_per_chain=wpc)
+    b = N.ChainBatch(s, logp, n_chains, dims_per_lane=dpl, waves_per_chain=wpc, lane_groups=2 if grouped else 1)
     assert sorted(b.stored_vectors()) == sorted(N.VECTOR_STATS)
     b.set_position(x0)
     pos_g, st_g, vec_g = b.expanded_draw_many(n_draws)
     tpc = b.threads_per_chain()
+    assert b.group_launches() == (1 if grouped else 0)
     b.close()
     vec_o = {}
     pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc),
