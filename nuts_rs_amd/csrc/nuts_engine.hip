@@ -251,7 +251,7 @@ struct nm_engine {
     uint64_t kernel_launches = 0;
     uint64_t steps_base = 0, draws_total = 0;
     uint64_t group_launches = 0;
-    uint64_t draws_launched = 0;            // draws every chain has been asked for since creation (never reset)
+    uint64_t draws_launched = 0;            // draw index of the healthy chain that is furthest behind (set_positions + launches)
     bool pending_timing = false;
 };
 
@@ -434,12 +434,16 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
-    uint64_t bad = 0, fatal = 0;
+    uint64_t bad = 0, fatal = 0, min_draws = ~0ull;
     for (uint64_t c = 0; c < e->n_chains; ++c) {
         if (h_chain_status) h_chain_status[c] = sc[c].status;
         if (sc[c].status == NM_CHAIN_BAD_INIT) bad++;
         else if (sc[c].status != NM_CHAIN_OK) fatal++;
+        else if (sc[c].draw_count < min_draws) min_draws = sc[c].draw_count;
     }
+    // the draw index of the chain that is furthest behind decides whether a launch still needs the warm-up kernel (a chain
+    // whose first set_position failed may start later than the others)
+    e->draws_launched = min_draws == ~0ull ? 0 : min_draws;
     e->positioned = true;
     if (fatal) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s): logp failure during set_position", (unsigned long long)fatal);
     if (bad) return fail(NM_ERR_BAD_INIT, "%llu chain(s): Could not initialize state because of bad initial gradient", (unsigned long long)bad);

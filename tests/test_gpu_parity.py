@@ -486,3 +486,26 @@ def test_lane_group_kernel_skips_failed_chains(oracle):
     assert out[1][2] == 0 and out[2][2] == 2
     assert_bit_exact(out[2][0], out[2][1], out[1][0], out[1][1])
     assert (out[2][3] == out[1][3]).all() and (out[2][1]["chain_status"] == 0).all()
+
+
+def test_lane_group_kernel_late_starter(oracle):
+    """A chain whose first set_position failed starts its warm-up when the others are already sampling: the launch must
+    still take the kernel with the adaptation in it (the engine keys that on the chain that is furthest behind)."""
+    n, dim = 12, 6
+    s = N.DiagNutsSettings(num_chains=n, seed=35, num_tune=30)
+    logp = N.LogpSpec.iid_normal(dim, 3.0)
+    x0 = oracle.init_positions_uniform(35, 0, n, dim)
+    bad = x0.copy()
+    bad[4] = 3.0                                             # zero gradient: BadInitGrad
+    out = {}
+    for lg in (1, 2):
+        b = N.ChainBatch(s, logp, n, lane_groups=lg)
+        assert list(np.nonzero(b.set_position(bad, raise_on_error=False))[0]) == [4]
+        b.draw_many(45, raise_on_error=False)                # the other 11 chains finish their warm-up
+        cur = b.positions()
+        cur[4] = x0[4]
+        assert (b.set_position(cur, raise_on_error=False) == 0).all()
+        out[lg] = b.draw_many(50)
+        b.close()
+    assert_bit_exact(out[2][0], out[2][1], out[1][0], out[1][1])
+    assert (out[2][1]["tuning"][:30, 4] == 1).all() and (out[2][1]["tuning"][:, 0] == 0).all()
