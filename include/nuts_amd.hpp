@@ -148,7 +148,16 @@ public:
         cfg.device = device; cfg.chain_id_offset = chain_id_offset;
         check(nm_engine_create(&s, &l, n_chains, &cfg, &h_));
     }
+    // the same with every engine-side knob (tiling, grid, lane_groups, ...): start from nm_engine_config_default
+    ChainBatch(const DiagNutsSettings& settings, const LogpSpec& logp, uint64_t n_chains, const nm_engine_config& cfg)
+        : settings_(settings), n_(n_chains), dim_(logp.dim), offset_(cfg.chain_id_offset) {
+        nm_settings s = settings.to_c();
+        nm_logp_spec l = logp.to_c();
+        check(nm_engine_create(&s, &l, n_chains, &cfg, &h_));
+    }
     ~ChainBatch() { if (h_) nm_engine_destroy(h_); }
+    // draw launches served by the several-chains-per-wavefront kernels (many chains with dim <= 64)
+    uint64_t group_launches() const { return nm_engine_group_launches(h_); }
     ChainBatch(const ChainBatch&) = delete;
     ChainBatch& operator=(const ChainBatch&) = delete;
 
