@@ -238,6 +238,7 @@ def test_k4_eight_schools_posterior():
     assert (b.set_position(b.init_positions_uniform()) == 0).all()
     b.draw_device(300)
     pos, st = b.draw_many(40)
+    assert b.group_launches() == 2          # more chains than resident wavefronts: drawn 8 per wavefront (nuts_group.hpp)
     b.close()
     assert (st["chain_status"] == 0).all()
     mu, tau = pos[..., 0], np.exp(pos[..., 1])
@@ -509,3 +510,23 @@ def test_lane_group_kernel_late_starter(oracle):
         b.close()
     assert_bit_exact(out[2][0], out[2][1], out[1][0], out[1][1])
     assert (out[2][1]["tuning"][:30, 4] == 1).all() and (out[2][1]["tuning"][:, 0] == 0).all()
+
+
+def test_k4_full_size_one_gpu():
+    """BASELINE configs[3] at its full size on ONE GPU (65536 chains x dim 10, 8 chains per wavefront): every chain
+    healthy, the pooled posterior where it belongs, chains statistically exchangeable (no chain-position artefacts of
+    the grouping: the 8 lanes-groups of a wavefront see the same distribution)."""
+    C_ = 65536
+    s = N.DiagNutsSettings(num_chains=C_, seed=5, num_tune=200, num_draws=20)
+    b = N.ChainBatch(s, N.LogpSpec.eight_schools(), C_)
+    assert (b.set_position(b.init_positions_uniform()) == 0).all()
+    b.draw_device(200)
+    pos, st = b.draw_many(20)
+    assert b.group_launches() == 2
+    b.close()
+    assert (st["chain_status"] == 0).all() and (st["tuning"] == 0).all()
+    mu = pos[..., 0]
+    assert abs(mu.mean() - 4.4) < 0.15 and abs(mu.std() - 3.3) < 0.15
+    by_group = mu.reshape(20, C_ // 8, 8).mean(axis=(0, 1))          # chains by their position inside the wavefront
+    assert np.ptp(by_group) < 0.25
+    assert 0.7 < st["mean_tree_accept"].mean() < 0.9 and st["diverging"].mean() < 0.02
