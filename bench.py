@@ -5,19 +5,35 @@
             steady state; draws/sec/chain (M2) is reported beside it.
   workload: K2 — iid N(3,1), dim 1024, 4096 chains PER GPU, maxdepth 10, per-chain diagonal mass matrix,
             DiagNutsSettings defaults with num_tune 400; x0 ~ U(-1,1) from each chain's generator, seed 20260928.
-  step    : one NUTS draw of every chain (one pass of the hot path over the batch of 4096 chains).
+  step    : one NUTS draw of every chain (one pass of the hot path over the batch of 4096 chains), WITH the draw and
+            its statistics recorded: every timed launch writes `Chain::draw`'s position ([steps][chains][dim] f64) and
+            the per-draw statistics ([steps][chains] nm_draw_stats) into device buffers (reference src/chain.rs:151-188
+            returns the position of every draw).
             Setup (untimed, reported as `adaptation`): engine creation, set_position, the 400 tuning draws.
-            Then W untimed post-warm-up steps, then EXACTLY K timed steps between barrier + device sync.
-  N GPUs  : one process per GPU (torch.distributed, RCCL backend); chains shard with no data-path collective
-            (global chain id = rank * 4096 + local id; results are invariant to the partition) => "weak" scaling;
-            value = all ranks' steps*dims / max-over-ranks time.
+            Then W untimed post-warm-up steps, then R repeats of EXACTLY K timed steps, each between
+            barrier + device sync; `value` is the MEDIAN repeat (all repeats are listed in `repeats`).
+  N GPUs  : one process per GPU (torch.distributed, RCCL backend); `python bench.py --gpus N` starts the N ranks itself
+            (torch.distributed.run) when it is not already running under a launcher.  Chains shard with no data-path
+            collective (global chain id = rank * 4096 + local id; results are invariant to the partition) => "weak"
+            scaling; value = all ranks' steps*dims / max-over-ranks time.
+  roofline: HBM.  `achieved` = bytes the dominant kernel (nuts_draw_kernel) actually moved through the memory-side
+            counters (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate --pmc passes of this same workload, taken live by
+            this script on rank 0 at N = 1, corrected with the factors calibrated on known-size streams,
+            profiles/*hbm_calibration.json) / its launch time (HIP events on the engine's stream, un-profiled run);
+            `frac` = achieved / 8 TB/s <= 1.  The 64 B/(step x dim) algorithmic model of SURVEY §8(d) is reported
+            beside it (`algorithmic`): it is NOT a bound for this design, whose live state is register / LDS resident.
 The state is resident in HBM before the timed region (positions are uploaded in set_position; draws stay on the
 device), so `value` contains no PCIe traffic.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,8 +42,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md)
-HBM_COPY_GBS = 6290.0          # measured float4 copy on MI355X per the same guide
+HBM_COPY_GBS = 6290.0          # measured float4 copy on MI355X per the same guide (this box's own probe is reported too)
 ALGO_BYTES_PER_STEP_DIM = 64   # read z,v,g_z,sigma,mu + write z',v',g_z' in f64, per (step x dim)
+KERNEL = "nuts_draw_kernel"
+SQ_COUNTERS = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+               "SQ_INSTS_VALU", "SQ_INSTS_SALU"]
 
 
 def parse():
@@ -35,62 +54,175 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--repeats", type=int, default=5, help="timed repeats of K steps each; value = the median")
     p.add_argument("--chains", type=int, default=4096, help="chains per GPU")
     p.add_argument("--dim", type=int, default=1024)
     p.add_argument("--num-tune", type=int, default=400)
     p.add_argument("--seed", type=int, default=20260928)
     p.add_argument("--dims-per-lane", type=int, default=0)
+    p.add_argument("--no-record", action="store_true", help="do not record draws / statistics in the timed launches (comparison only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-chains", type=int, default=0, help="chains of the bounded CPU sample (0 = 2 per host core)")
+    p.add_argument("--pmc", default="live", choices=["live", "profile", "off"],
+                   help="HBM traffic of the timed launch: live rocprofv3 --pmc passes | latest committed profile, scaled | none")
+    p.add_argument("--pmc-timeout", type=float, default=150.0)
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
+    p.add_argument("--master-port", type=int, default=29511)
     return p.parse_args()
 
 
-def pmc_traffic(args):
-    """HBM bytes per timed launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    this same command, tools/pmc_run.sh; gfx950 correction: FETCH_SIZE x2 for 16 B/lane streams, per
-    MI355X_MICROARCH.md).  Counters cannot be collected from inside an un-profiled run, so the latest committed
-    summary under profiles/ is reported when it was taken on the same workload; otherwise null."""
-    import glob
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic from the memory-side counters
+# ------------------------------------------------------------------------------------------------------------------
+def calibration():
+    """FETCH_SIZE / WRITE_SIZE -> bytes factors measured on known-size 16 B/lane streams (tools/hbm_probe.py under
+    rocprofv3 --pmc; MI355X_MICROARCH.md §HBM: FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950).  Falls
+    back to the guide's documented x2 / x1 when no calibration file is committed."""
+    best = {"fetch_factor": 2.0, "write_factor": 1.0, "source": "MI355X_MICROARCH.md §HBM (uncalibrated default)"}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_calibration.json"))):
+        try:
+            d = json.load(open(f))
+            best = {"fetch_factor": float(d["fetch_factor"]), "write_factor": float(d["write_factor"]),
+                    "source": os.path.relpath(f, ROOT), "copy_GBps": d.get("copy_GBps"), "triad_GBps": d.get("triad_GBps")}
+        except Exception:
+            continue
+    return best
+
+
+def read_counters(db, kernel=KERNEL):
+    """{counter: value of the LAST dispatch of `kernel`} from a rocprofv3 rocpd database."""
+    c = sqlite3.connect(db)
+    res = {}
+    for name, cname, val in c.execute("select kernel_name, counter_name, value from counters_collection order by start"):
+        if kernel in name:
+            res[cname] = val      # later dispatches overwrite: the last one is the timed launch
+    return res
+
+
+def pmc_live(args):
+    """Re-run this workload (tune, warm-up, ONE recorded K-step launch) under rocprofv3 --pmc, one pass per counter set
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; tracing options are never combined with --pmc)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    deadline = time.time() + args.pmc_timeout
+    tmp = tempfile.mkdtemp(prefix="nm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--gpus", "1", "--steps", str(args.steps),
+             "--warmup", str(args.warmup), "--chains", str(args.chains), "--dim", str(args.dim),
+             "--num-tune", str(args.num_tune), "--seed", str(args.seed), "--dims-per-lane", str(args.dims_per_lane)]
+    if args.no_record:
+        child.append("--no-record")
+    for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_COUNTERS)):
+        left = deadline - time.time()
+        if left < 10:
+            out.setdefault("skipped", []).append(tag)
+            continue
+        cmd = [exe, "--pmc"] + counters + ["-d", tmp, "-o", tag, "--"] + child
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=left)
+        except subprocess.TimeoutExpired:
+            out.setdefault("skipped", []).append(tag + " (timeout)")
+            continue
+        dbs = glob.glob(os.path.join(tmp, "**", tag + "_results.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            out.setdefault("skipped", []).append(f"{tag} (rc {r.returncode})")
+            continue
+        try:
+            out.update(read_counters(dbs[0]))
+            for line in r.stdout.decode(errors="replace").splitlines():
+                if line.startswith("{") and '"pmc_child"' in line:
+                    out.setdefault("child", {})[tag] = json.loads(line)
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("skipped", []).append(f"{tag} ({e})")
+    shutil.rmtree(tmp, ignore_errors=True)
+    if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+        return None, f"counter passes incomplete: {out.get('skipped')}"
+    return out, None
+
+
+def pmc_profile(steps_dims):
+    """Fallback: the latest committed profile's bytes per (leapfrog-step x dim), scaled to this run's steps x dims."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k2.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload", {"chains": 4096, "dim": 1024, "steps": 200}) == {"chains": args.chains, "dim": args.dim, "steps": args.steps}:
+        if d.get("hbm_bytes_per_step_dim"):
             best = (f, d)
     if not best:
         return None, None
     f, d = best
-    return d.get("hbm_bytes_per_launch"), os.path.relpath(f, ROOT)
+    return d["hbm_bytes_per_step_dim"] * steps_dims, os.path.relpath(f, ROOT)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args, cores):
     """The CPU restatement of nuts-rs (oracle/, reference arithmetic: libm + SIMD-order sums) on this box's host
-    cores: one chain per task over `cores` threads (the reference's Rayon structure, src/sampler.rs:1116), same
-    density / settings / seeds, a bounded sample of the same workload.  Labelled "port": it is NOT nuts-rs itself
-    (no Rust toolchain here or on the GPU box)."""
+    cores, WALL CLOCK: one chain per task over `cores` threads (the reference's Rayon structure, src/sampler.rs:1116),
+    same density / settings / seeds, a bounded sample of the same workload.  Labelled "port": it is NOT nuts-rs itself
+    (no Rust toolchain in this image; `cargo` is probed and reported)."""
     from oracle import oracle as O
     n = args.cpu_chains or 2 * cores
     draws = 25
     s = O.default_settings(seed=args.seed, num_tune=args.num_tune, num_chains=n)
     x0 = O.init_positions_uniform(args.seed, 0, n, args.dim)
-    t0 = time.time()
-    r = O.run_timed(s, O.LOGP_IID_NORMAL, args.dim, [3.0], O.ref_cfg(), n, x0, args.num_tune, draws, n_threads=cores)
-    wall = time.time() - t0
-    rate = r["steps"] * args.dim / (r["cpu_seconds"] / cores) if r["cpu_seconds"] > 0 else 0.0
-    return {
-        "value": rate, "unit": "leapfrog-steps*dims/s", "cores": cores, "kind": "port",
+    r = O.run_wall(s, O.LOGP_IID_NORMAL, args.dim, [3.0], O.ref_cfg(), n, x0, args.num_tune, draws, n_threads=cores)
+    rate = r["steps"] * args.dim / r["wall_seconds"] if r["wall_seconds"] > 0 else 0.0
+    out = {
+        "value": rate, "unit": "leapfrog-steps*dims/s", "cores": cores, "kind": "port", "timing": "wall clock",
         "sample": f"CPU restatement of nuts-rs (oracle/, not nuts-rs): {n} chains x dim {args.dim}, same settings/seed, "
-                  f"{args.num_tune} warm-up draws untimed then {draws} timed draws per chain, one chain per task on "
-                  f"{cores} threads; {r['steps']} steps in {r['cpu_seconds']:.2f} cpu-s ({wall:.1f} s wall incl. warm-up)",
-        "warmup_value": r["warm_steps"] * args.dim / (r["warm_cpu_seconds"] / cores) if r["warm_cpu_seconds"] > 0 else 0.0,
+                  f"{args.num_tune} warm-up draws per chain (phase 1, {r['warm_wall_seconds']:.2f} s wall) then {draws} "
+                  f"timed draws per chain, one chain per task on {cores} threads; {r['steps']} steps in "
+                  f"{r['wall_seconds']:.3f} s wall",
+        "warmup_value": r["warm_steps"] * args.dim / r["warm_wall_seconds"] if r["warm_wall_seconds"] > 0 else 0.0,
+        "reference_toolchain": {"cargo": shutil.which("cargo"), "rustc": shutil.which("rustc"),
+                                "note": "BASELINE.md §4.1: the reference itself is timed only where cargo exists"},
     }
+    # criterion replica of the reference's own bench (benches/sample.rs:76-98, :190-198): 1 chain, 1000 draws all inside
+    # the warm-up (num_tune 1000), maxdepth 3, N(3,1), init 3.5 — wall ms on one core, dims 10 and 1000
+    try:
+        rep = {}
+        for d in (10, 1000):
+            s1 = O.default_settings(seed=42, num_tune=1000, num_draws=1000, maxdepth=3, num_chains=1)
+            best = None
+            for _ in range(3):
+                rr = O.run_wall(s1, O.LOGP_IID_NORMAL, d, [3.0], O.ref_cfg(), 1, np.full((1, d), 3.5), 1000, 0, n_threads=1)
+                best = rr["warm_wall_seconds"] if best is None else min(best, rr["warm_wall_seconds"])
+            rep[f"sample_1000_{d}"] = {"ms": best * 1e3}
+        out["criterion_replica"] = dict(rep, note="benches/sample.rs:190-198 on the CPU restatement, 1 thread, best of 3; "
+                                                  "the chain key is this repo's Sampler seeding of seed 42, not StdRng's")
+    except Exception as e:  # noqa: BLE001
+        out["criterion_replica"] = {"failed": str(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.dist_backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible (one rank per GPU over RCCL); "
+                         f"use --dist-backend gloo to let ranks share a GPU on a test rig")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     import torch
     import nuts_rs_amd as N
 
@@ -99,6 +231,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}")
     ndev = torch.cuda.device_count()
     if args.dist_backend == "nccl" and local_rank >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
@@ -109,7 +243,7 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         if args.dist_backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -123,12 +257,19 @@ def main():
 
     C_, D = args.chains, args.dim
     settings = N.DiagNutsSettings(num_chains=C_ * world, seed=args.seed, num_tune=args.num_tune,
-                                  num_draws=args.steps + args.warmup)
+                                  num_draws=args.steps * max(1, args.repeats) + args.warmup)
     batch = N.ChainBatch(settings, N.LogpSpec.iid_normal(D, 3.0), C_, chain_id_offset=rank * C_,
                          device=device_index, dims_per_lane=args.dims_per_lane)
     x0 = batch.init_positions_uniform()
     status = batch.set_position(x0)
     assert (status == 0).all()
+    # the draws and their statistics are recorded in these device buffers by every timed launch
+    record = not args.no_record
+    d_pos = d_st = None
+    if record:
+        d_pos = torch.empty((args.steps, C_, D), dtype=torch.float64, device=f"cuda:{device_index}")
+        d_st = torch.zeros((args.steps, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device=f"cuda:{device_index}")
+    p_pos, p_st = (d_pos.data_ptr(), d_st.data_ptr()) if record else (0, 0)
     # ---- adaptation phase (untimed setup; reported)
     barrier()
     t0 = time.perf_counter()
@@ -139,37 +280,87 @@ def main():
     # ---- W untimed post-warm-up steps
     if args.warmup:
         batch.draw_device(args.warmup)
-    batch.reset_counters()
-    # ---- K timed steps
-    barrier()
-    t0 = time.perf_counter()
-    batch.draw_device(args.steps, sync=False)
-    batch.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    c = batch.counters()
-    steps_local = c["total_leapfrogs"]
-
+    # ---- R repeats of K timed steps
+    R = 1 if args.pmc_child else max(1, args.repeats)
+    reps = []
+    for _ in range(R):
+        batch.reset_counters()
+        barrier()
+        t0 = time.perf_counter()
+        batch.draw_device(args.steps, p_pos, p_st, sync=False)
+        batch.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        c = batch.counters()
+        steps_local = c["total_leapfrogs"]
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sv = torch.tensor([float(steps_local)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(sv, op=dist.ReduceOp.SUM)
+            reps.append((float(t.item()), float(sv.item()), steps_local, c["kernel_ms"]))
+        else:
+            reps.append((elapsed, float(steps_local), steps_local, c["kernel_ms"]))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_max = float(t.item())
-        sv = torch.tensor([float(steps_local), float(c_tune["total_leapfrogs"]), t_tune], dtype=torch.float64, device=red_dev)
+        sv = torch.tensor([float(c_tune["total_leapfrogs"]), t_tune], dtype=torch.float64, device=red_dev)
         sv_max = sv.clone()
         dist.all_reduce(sv, op=dist.ReduceOp.SUM)
         dist.all_reduce(sv_max, op=dist.ReduceOp.MAX)
-        steps_total, tune_steps_total, t_tune_max = float(sv[0]), float(sv[1]), float(sv_max[2])
+        tune_steps_total, t_tune_max = float(sv[0]), float(sv_max[1])
     else:
-        elapsed_max, steps_total, tune_steps_total, t_tune_max = elapsed, float(steps_local), float(c_tune["total_leapfrogs"]), t_tune
+        tune_steps_total, t_tune_max = float(c_tune["total_leapfrogs"]), t_tune
 
+    if args.pmc_child:
+        el, st_tot, st_loc, kms = reps[0]
+        print(json.dumps({"pmc_child": True, "steps": st_loc, "kernel_ms": kms, "recorded": record}))
+        batch.close()
+        return
+
+    recorded_ok = None
+    if record and rank == 0:     # the last repeat's buffers hold real draws: finite positions, the right draw indices
+        st_host = np.frombuffer(d_st[-1].cpu().numpy().tobytes(), dtype=N.STATS_DTYPE)
+        first_draw = args.num_tune + args.warmup + (R - 1) * args.steps
+        recorded_ok = bool(torch.isfinite(d_pos[-1]).all().item()) and bool((st_host["draw"] == first_draw + args.steps - 1).all()) \
+            and bool((st_host["n_steps"] > 0).all())
     if rank == 0:
-        value = steps_total * D / elapsed_max
-        # roofline of the dominant kernel (nuts_draw_kernel), rank 0's launch, timed with HIP events on the
-        # engine's own stream inside libnuts_amd (nm_engine_get_counters)
-        kern_s = c["kernel_ms"] * 1e-3
+        rates = [s_tot * D / el for el, s_tot, _, _ in reps]
+        order = np.argsort(rates)
+        mid = int(order[len(order) // 2])                       # the median repeat IS the reported measurement
+        elapsed_max, steps_total, steps_local, kern_ms = reps[mid]
+        value = rates[mid]
+        kern_s = kern_ms * 1e-3                                 # HIP events on the engine's own stream (nm_engine_get_counters)
         algo_bytes = steps_local * D * ALGO_BYTES_PER_STEP_DIM
-        achieved = algo_bytes / kern_s / 1e9
-        traffic, traffic_src = pmc_traffic(args)
+        cal = calibration()
+        traffic = traffic_src = None
+        pmc_detail = {}
+        if world == 1 and args.pmc == "live":
+            got, why = pmc_live(args)
+            if got:
+                child_steps = (got.get("child", {}).get("fetch") or {}).get("steps") or steps_local
+                fetch_b = got["FETCH_SIZE"] * 1024.0 * cal["fetch_factor"]
+                write_b = got["WRITE_SIZE"] * 1024.0 * cal["write_factor"]
+                per_step_dim = (fetch_b + write_b) / (child_steps * D)
+                traffic = per_step_dim * steps_local * D     # the profiled launch's bytes per step x dim, at this launch's steps
+                traffic_src = "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on this GPU"
+                pmc_detail = {"fetch_bytes": fetch_b, "write_bytes": write_b, "hbm_bytes_per_step_dim": per_step_dim,
+                              "profiled_launch_steps": child_steps, "calibration": cal}
+                if "SQ_WAVE_CYCLES" in got and got["SQ_WAVE_CYCLES"]:
+                    wc = got["SQ_WAVE_CYCLES"]
+                    pmc_detail["issue"] = {
+                        "note": "second bound: a wavefront's dependent chain (one wave per SIMD at 512 registers)",
+                        "wait_any_frac": got.get("SQ_WAIT_ANY", 0.0) / wc,
+                        "wait_inst_frac": got.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                        "active_inst_frac": got.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                        "valu_active_frac": got.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                        "valu_insts_per_leapfrog_wave": got.get("SQ_INSTS_VALU", 0.0) / max(1, child_steps),
+                        "salu_insts_per_leapfrog_wave": got.get("SQ_INSTS_SALU", 0.0) / max(1, child_steps)}
+                if got.get("skipped"):
+                    pmc_detail["skipped_passes"] = got["skipped"]
+            else:
+                pmc_detail = {"live_failed": why}
+        if traffic is None and args.pmc != "off":
+            traffic, traffic_src = pmc_profile(steps_local * D)
+        achieved = (traffic / kern_s / 1e9) if traffic else None
         out = {
             "metric": "leapfrog-steps*dims/sec at 4096 chains x dim 1024 (post-warm-up NUTS draws)",
             "value": value, "unit": "leapfrog-steps*dims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,16 +369,26 @@ def main():
             "config": {"workload": f"K2: iid N(3,1) dim {D} x {C_} chains per GPU, maxdepth 10, per-chain diag mass matrix, "
                                    f"DiagNutsSettings defaults, num_tune {args.num_tune} (untimed), seed {args.seed}",
                        "chains_per_gpu": C_, "dim": D, "num_tune": args.num_tune, "parallelism": f"chains sharded x{world}, no collective",
-                       "rng": "ChaCha8 stream + ziggurat normals (reference semantics)"},
+                       "rng": "ChaCha8 stream + ziggurat normals (reference semantics)",
+                       "draws_recorded": record, "recorded_buffers_verified": recorded_ok},
+            "repeats": {"n": R, "reported": "median", "values": rates, "min": min(rates), "max": max(rates),
+                        "ms_per_step": [el / args.steps * 1e3 for el, _, _, _ in reps]},
             "draws_per_sec_per_chain": args.steps / elapsed_max,
             "leapfrogs_per_draw": steps_total / (args.steps * C_ * world),
             "adaptation": {"value": tune_steps_total * D / t_tune_max, "unit": "leapfrog-steps*dims/s",
                            "draws": args.num_tune, "seconds": t_tune_max},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "nuts_draw_kernel", "kernel_ms_per_launch": c["kernel_ms"] / max(1, c["kernel_launches"]),
-                         "launches": c["kernel_launches"], "algorithmic_bytes_per_launch": algo_bytes / max(1, c["kernel_launches"]),
-                         "frac_of_measured_copy": achieved / HBM_COPY_GBS},
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": KERNEL, "kernel_ms_per_launch": kern_ms, "launches": 1,
+                         "frac_of_measured_copy": (achieved / (cal.get("copy_GBps") or HBM_COPY_GBS)) if achieved else None,
+                         "measured_copy_GBps": cal.get("copy_GBps"), "measured_triad_GBps": cal.get("triad_GBps"),
+                         "algorithmic": {"bytes_per_step_dim": ALGO_BYTES_PER_STEP_DIM, "bytes_per_launch": algo_bytes,
+                                         "rate_GBps": algo_bytes / kern_s / 1e9,
+                                         "moved_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                                         "note": "SURVEY §8(d)'s streaming model; not a bound here: live points, sigma, mu "
+                                                 "stay in registers / LDS, HBM carries the tree's end points instead"},
+                         "pmc": pmc_detail},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

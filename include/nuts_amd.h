@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 4
+#define NM_ABI_VERSION 5
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -335,6 +335,21 @@ nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const uint8_t* h_
 
 /* Chain RNG key derivation (host helper; reference src/sampler.rs:1105-1106, :761). */
 nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]);
+
+/* ---------------------------------------------------------------------------------------------
+ * HBM streaming probes: copy / triad / read / write with the engine's access shape
+ * (16 B per lane, 1 KiB per wave instruction) over arrays of `bytes_per_array` bytes each, `iters` timed launches
+ * after one warm-up launch (HIP events on the probe's own stream).  They give the roofline its measured
+ * denominator on the box at hand, and they are the known-size kernels the rocprofv3 FETCH_SIZE / WRITE_SIZE
+ * counters are calibrated on (tools/hbm_probe.py, profiles/r02*_hbm_calibration.json).
+ * ------------------------------------------------------------------------------------------- */
+#define NM_PROBE_COPY 0      /* c[i] = a[i]                 reads 1 array, writes 1 */
+#define NM_PROBE_TRIAD 1     /* c[i] = fma(s, b[i], a[i])   reads 2 arrays, writes 1 */
+#define NM_PROBE_READ 2      /* sum of a                    reads 1 array */
+#define NM_PROBE_WRITE 3     /* c[i] = const                writes 1 array */
+#define NM_PROBE_COPY_NT 4   /* copy with non-temporal stores (the cache policy of the engine's candidate / per-draw stores) */
+nm_status nm_probe_bandwidth(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
+                             uint64_t* bytes_read_per_iter, uint64_t* bytes_written_per_iter);
 
 const char* nm_last_error(void);
 uint64_t    nm_abi_version(void);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
-    "nm_pick_tiling",
+    "nm_pick_tiling", "nm_probe_bandwidth",
 ]
 
 
@@ -140,6 +140,7 @@ def load():
     L.nm_standard_normal_batch.argtypes = [u64, u64, vp, vp, vp, vp]
     L.nm_chain_rng_key.argtypes = [u64, u64, vp]
     L.nm_pick_tiling.argtypes = [u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_last_error.restype = C.c_char_p
     L.nm_abi_version.restype = u64
     for name in ABI_SYMBOLS:

@@ -34,6 +34,20 @@ static nm_status fail(nm_status st, const char* fmt, ...) {
     } while (0)
 
 extern "C" const char* nm_last_error(void) { return g_last_error.c_str(); }
+static nm_status ensure_device(int64_t device);
+// HBM streaming probes (probe_bw.hip)
+extern "C" int nm_probe_bandwidth_impl(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
+                                       uint64_t* bytes_read, uint64_t* bytes_written, const char** err);
+extern "C" nm_status nm_probe_bandwidth(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
+                                        uint64_t* bytes_read, uint64_t* bytes_written) {
+    if (kind > NM_PROBE_COPY_NT) return fail(NM_ERR_INVALID_ARG, "unknown probe kind %llu", (unsigned long long)kind);
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    const char* err = nullptr;
+    const int rc = nm_probe_bandwidth_impl(kind, bytes_per_array, iters, ms_per_iter, bytes_read, bytes_written, &err);
+    if (rc != 0) return fail(rc == 1 ? NM_ERR_INVALID_ARG : NM_ERR_HIP, "bandwidth probe: %s", err ? err : "?");
+    return NM_OK;
+}
 extern "C" uint64_t nm_abi_version(void) { return NM_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,114 @@
+// probe_bw.hip — HBM streaming probes with the engine's own access shape (16 B per lane, 1 KiB per wave instruction,
+// buffer-descriptor addressing): the measured denominator of the roofline and the known-size
+// kernels the rocprofv3 FETCH_SIZE / WRITE_SIZE counters are calibrated on (MI355X_MICROARCH.md §HBM: FETCH_SIZE reads
+// 1/2 of a wide coalesced stream on gfx950, WRITE_SIZE is uncalibrated).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/nuts_amd.h"
+
+namespace {
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr int AUX_NT = 2;
+
+// persistent grid-stride over 16-byte elements; every wave instruction moves 1 KiB, consecutive waves consecutive KiB
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_kernel(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                   double2* __restrict__ c, uint64_t n16, double s, double* sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {            // four independent 16 B accesses in flight per lane
+        if (KIND == NM_PROBE_COPY || KIND == NM_PROBE_COPY_NT) {
+            const double2 q0 = a[i], q1 = a[i + stride], q2 = a[i + 2 * stride], q3 = a[i + 3 * stride];
+            if (KIND == NM_PROBE_COPY) { c[i] = q0; c[i + stride] = q1; c[i + 2 * stride] = q2; c[i + 3 * stride] = q3; }
+            else {
+                __builtin_nontemporal_store(q0.x, &c[i].x); __builtin_nontemporal_store(q0.y, &c[i].y);
+                __builtin_nontemporal_store(q1.x, &c[i + stride].x); __builtin_nontemporal_store(q1.y, &c[i + stride].y);
+                __builtin_nontemporal_store(q2.x, &c[i + 2 * stride].x); __builtin_nontemporal_store(q2.y, &c[i + 2 * stride].y);
+                __builtin_nontemporal_store(q3.x, &c[i + 3 * stride].x); __builtin_nontemporal_store(q3.y, &c[i + 3 * stride].y);
+            }
+        } else if (KIND == NM_PROBE_TRIAD) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 x = a[i + u * stride], y = b[i + u * stride];
+                c[i + u * stride] = make_double2(__builtin_fma(s, y.x, x.x), __builtin_fma(s, y.y, x.y));
+            }
+        } else if (KIND == NM_PROBE_READ) {
+            const double2 q0 = a[i], q1 = a[i + stride], q2 = a[i + 2 * stride], q3 = a[i + 3 * stride];
+            acc += (q0.x + q0.y) + (q1.x + q1.y) + (q2.x + q2.y) + (q3.x + q3.y);
+        } else {   // NM_PROBE_WRITE
+            const double2 q = make_double2(s, (double)i);
+            c[i] = q; c[i + stride] = q; c[i + 2 * stride] = q; c[i + 3 * stride] = q;
+        }
+    }
+    for (; i < n16; i += stride) {
+        if (KIND == NM_PROBE_READ) acc += a[i].x + a[i].y;
+        else if (KIND == NM_PROBE_TRIAD) { const double2 x = a[i], y = b[i]; c[i] = make_double2(__builtin_fma(s, y.x, x.x), __builtin_fma(s, y.y, x.y)); }
+        else if (KIND == NM_PROBE_WRITE) c[i] = make_double2(s, (double)i);
+        else c[i] = a[i];
+    }
+    if (KIND == NM_PROBE_READ && acc == 12345.678) *sink = acc;   // keeps the loads alive
+}
+
+hipError_t launch_probe(uint64_t kind, unsigned grid, hipStream_t st, const double2* a, const double2* b, double2* c,
+                        uint64_t n16, double* sink) {
+    switch (kind) {
+    case NM_PROBE_COPY: hipLaunchKernelGGL(probe_kernel<NM_PROBE_COPY>, dim3(grid), dim3(256), 0, st, a, b, c, n16, 0.5, sink); break;
+    case NM_PROBE_COPY_NT: hipLaunchKernelGGL(probe_kernel<NM_PROBE_COPY_NT>, dim3(grid), dim3(256), 0, st, a, b, c, n16, 0.5, sink); break;
+    case NM_PROBE_TRIAD: hipLaunchKernelGGL(probe_kernel<NM_PROBE_TRIAD>, dim3(grid), dim3(256), 0, st, a, b, c, n16, 0.5, sink); break;
+    case NM_PROBE_READ: hipLaunchKernelGGL(probe_kernel<NM_PROBE_READ>, dim3(grid), dim3(256), 0, st, a, b, c, n16, 0.5, sink); break;
+    case NM_PROBE_WRITE: hipLaunchKernelGGL(probe_kernel<NM_PROBE_WRITE>, dim3(grid), dim3(256), 0, st, a, b, c, n16, 0.5, sink); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+// declared in include/nuts_amd.h
+extern "C" int nm_probe_bandwidth_impl(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
+                                       uint64_t* bytes_read, uint64_t* bytes_written, const char** err) {
+    *err = nullptr;
+    const uint64_t n16 = bytes_per_array / 16;
+    if (n16 == 0 || iters == 0) { *err = "empty probe"; return 1; }
+    double2 *a = nullptr, *b = nullptr, *c = nullptr;
+    double* sink = nullptr;
+    hipError_t e = hipSuccess;
+    auto fin = [&](hipError_t er) {
+        if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); if (sink) (void)hipFree(sink);
+        if (er != hipSuccess) { *err = hipGetErrorString(er); return 3; }
+        return 0;
+    };
+    const bool needs_a = kind != NM_PROBE_WRITE, needs_b = kind == NM_PROBE_TRIAD, needs_c = kind != NM_PROBE_READ;
+    if (needs_a && (e = hipMalloc(&a, n16 * 16)) != hipSuccess) return fin(e);
+    if (needs_b && (e = hipMalloc(&b, n16 * 16)) != hipSuccess) return fin(e);
+    if (needs_c && (e = hipMalloc(&c, n16 * 16)) != hipSuccess) return fin(e);
+    if ((e = hipMalloc(&sink, 8)) != hipSuccess) return fin(e);
+    if (a && (e = hipMemset(a, 0x11, n16 * 16)) != hipSuccess) return fin(e);
+    if (b && (e = hipMemset(b, 0x22, n16 * 16)) != hipSuccess) return fin(e);
+    if (c && (e = hipMemset(c, 0, n16 * 16)) != hipSuccess) return fin(e);
+    int cus = 256;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)cus * 8u;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fin(e);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    e = launch_probe(kind, grid, st, a, b, c, n16, sink);                       // warm-up launch
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+        (void)hipEventRecord(e0, st);
+        for (uint64_t i = 0; i < iters && e == hipSuccess; ++i) e = launch_probe(kind, grid, st, a, b, c, n16, sink);
+        (void)hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (ms_per_iter) *ms_per_iter = (double)ms / (double)iters;
+    }
+    if (bytes_read) *bytes_read = (needs_a ? n16 * 16 : 0) + (needs_b ? n16 * 16 : 0);
+    if (bytes_written) *bytes_written = needs_c ? n16 * 16 : 0;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+    return fin(e);
+}

@@ -175,6 +175,55 @@ int nmo_run_timed(const Settings* s, int64_t kind, uint64_t dim, const double* p
     return failed.load();
 }
 
+// Wall-clock variant (bench.py's cpu_baseline): phase 1 = every chain's set_position + n_warm draws on n_threads host
+// threads (one chain per task, the reference's Rayon structure), join; phase 2 = n_draws draws of every chain, again
+// one chain per task.  Reports the wall seconds and leapfrog steps of each phase.
+int nmo_run_wall(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+                 const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_warm,
+                 uint64_t n_draws, uint64_t n_threads, double* out_warm_wall, uint64_t* out_warm_steps,
+                 double* out_wall, uint64_t* out_steps) {
+    std::vector<std::unique_ptr<Chain>> chains(n_chains);
+    std::atomic<int> failed{0};
+    auto phase = [&](bool warm, double* wall, uint64_t* steps_out) {
+        std::atomic<uint64_t> next{0}, steps{0};
+        auto work = [&]() {
+            for (;;) {
+                uint64_t c = next.fetch_add(1);
+                if (c >= n_chains) break;
+                DrawStats st;
+                uint64_t local = 0;
+                if (warm) {
+                    uint8_t key[32];
+                    nmo_chain_key(s->seed, chain_offset + c, key);
+                    Density d = make_density(kind, dim, params, n_params);
+                    chains[c].reset(new Chain(*s, d, *cfg, chain_offset + c, key));
+                    if (chains[c]->set_position(x0 + c * dim) != ST_OK) { failed++; chains[c].reset(); continue; }
+                }
+                if (!chains[c]) continue;
+                const uint64_t n = warm ? n_warm : n_draws;
+                for (uint64_t t = 0; t < n; ++t) {
+                    if (chains[c]->draw(nullptr, &st) != ST_OK) { failed++; chains[c].reset(); break; }
+                    local += st.n_steps;
+                }
+                steps += local;
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (n_threads <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (uint64_t i = 0; i < n_threads; ++i) th.emplace_back(work);
+            for (auto& t : th) t.join();
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        if (wall) *wall = std::chrono::duration<double>(t1 - t0).count();
+        if (steps_out) *steps_out = steps.load();
+    };
+    phase(true, out_warm_wall, out_warm_steps);
+    phase(false, out_wall, out_steps);
+    return failed.load();
+}
+
 // Adam::new(initial_step) then advance(accept[i], target): log_step after every advance
 void nmo_adam_sequence(const MathCfg* cfg, double initial_step, const double* accept, uint64_t n, double target,
                        double beta1, double beta2, double epsilon, double learning_rate, double* out_log_step) {

@@ -115,6 +115,8 @@ def lib():
                                 C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_uint64, C.c_uint64,
                                 C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_uint64)]
+    L.nmo_run_wall.restype = C.c_int
+    L.nmo_run_wall.argtypes = L.nmo_run_timed.argtypes
     L.nmo_logaddexp.restype = C.c_double
     L.nmo_logaddexp.argtypes = [C.POINTER(MathCfg), C.c_double, C.c_double]
     L.nmo_scalar_fn.restype = C.c_double
@@ -254,4 +256,18 @@ def run_timed(settings, kind, dim, params, cfg, n_chains, x0, n_warm, n_draws, c
                                  chain_offset, x0, n_warm, n_draws, n_threads, C.byref(ws), C.byref(wsteps),
                                  C.byref(secs), C.byref(steps))
     return dict(failed=failed, warm_cpu_seconds=ws.value, warm_steps=wsteps.value, cpu_seconds=secs.value,
+                steps=steps.value)
+
+
+def run_wall(settings, kind, dim, params, cfg, n_chains, x0, n_warm, n_draws, chain_offset=0, n_threads=1):
+    """CPU-baseline leg, wall clock: phase 1 (set_position + n_warm draws of every chain) and phase 2 (n_draws draws of
+    every chain), each with one chain per task on n_threads host threads; returns the wall seconds and steps of both."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    ws, secs = C.c_double(), C.c_double()
+    wsteps, steps = C.c_uint64(), C.c_uint64()
+    failed = lib().nmo_run_wall(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains,
+                                chain_offset, x0, n_warm, n_draws, n_threads, C.byref(ws), C.byref(wsteps),
+                                C.byref(secs), C.byref(steps))
+    return dict(failed=failed, warm_wall_seconds=ws.value, warm_steps=wsteps.value, wall_seconds=secs.value,
                 steps=steps.value)

@@ -27,6 +27,7 @@ def ensure_module(dim=DIM, group=False):
     out = module_path(dim) if not group else os.path.join(MODDIR, f"my_diag_normal_group_dim{dim}.so")
     srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp",
                                                           "nuts_group.hpp", "nuts_group_impl.hpp")]
+    srcs.append(os.path.join(HERE, "..", "include", "nuts_amd.h"))       # the ABI version is part of the module
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         os.makedirs(MODDIR, exist_ok=True)
         B.build_density_module(HEADER, "MyDiagNormal", dim, out, group_struct="MyDiagNormalGroup" if group else None)

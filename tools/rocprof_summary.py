@@ -31,12 +31,23 @@ def counters(db, sub):
     return res
 
 
-def pmc(d, out, sub="nuts_draw_kernel"):
+def bench_line(logdir, tag):
+    """the JSON line bench.py printed in the pass `tag` (its stdout log), or None"""
+    try:
+        for line in open(os.path.join(logdir, tag + "_stdout.log")):
+            if line.startswith("{") and '"metric"' in line:
+                return json.loads(line)
+    except OSError:
+        pass
+    return None
+
+
+def pmc(d, out, sub="nuts_draw_kernel", logdir=None):
     """The LAST dispatch of the kernel is bench.py's timed launch (tune, warm-up, timed)."""
     c = sqlite3.connect(os.path.join(d, "trace_results.db"))
     durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + sub + "%",))]
     res = {"kernel": sub, "dispatches": len(durs), "timed_launch_duration_ns": durs[-1] if durs else None}
-    for f in ("fetch", "write", "tcc"):
+    for f in ("fetch", "write", "tcc", "sq"):
         p = os.path.join(d, f + "_results.db")
         if os.path.exists(p):
             for k, v in counters(p, sub).items():
@@ -49,6 +60,19 @@ def pmc(d, out, sub="nuts_draw_kernel"):
         res["hbm_bytes_per_launch"] = res["fetch_bytes_corrected"] + res["write_bytes"]
         if res["timed_launch_duration_ns"]:
             res["hbm_GBps_over_kernel"] = res["hbm_bytes_per_launch"] / res["timed_launch_duration_ns"]
+    # per (leapfrog-step x dim), so that a run with another step count can scale it (bench.py --pmc profile)
+    line = bench_line(logdir, "fetch") if logdir else None
+    if line and "hbm_bytes_per_launch" in res:
+        steps_dims = line["leapfrogs_per_draw"] * line["steps"] * line["config"]["chains_per_gpu"] * line["config"]["dim"]
+        res["workload"] = {"chains": line["config"]["chains_per_gpu"], "dim": line["config"]["dim"], "steps": line["steps"],
+                           "draws_recorded": line["config"].get("draws_recorded")}
+        res["leapfrog_steps_x_dims_of_launch"] = steps_dims
+        res["hbm_bytes_per_step_dim"] = res["hbm_bytes_per_launch"] / steps_dims
+        res["hbm_bytes_per_chain_draw"] = res["hbm_bytes_per_launch"] / (line["steps"] * line["config"]["chains_per_gpu"])
+    if res.get("SQ_WAVE_CYCLES"):
+        wc = res["SQ_WAVE_CYCLES"]
+        res["issue"] = {k: res.get(c, 0.0) / wc for k, c in (("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_frac", "SQ_WAIT_INST_ANY"),
+                                                          ("active_inst_frac", "SQ_ACTIVE_INST_ANY"), ("valu_active_frac", "SQ_ACTIVE_INST_VALU"))}
     if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res:
         res["l2_hit_rate"] = res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])
     json.dump(res, open(out, "w"), indent=1)
@@ -59,4 +83,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
+        pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:6]))
