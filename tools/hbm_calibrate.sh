@@ -8,5 +8,5 @@ python tools/hbm_probe.py run > $OUT/probe_rates.json 2> $OUT/probe_rates.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch -- python tools/hbm_probe.py run --iters 3 > $OUT/fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write -- python tools/hbm_probe.py run --iters 3 > $OUT/write_stdout.log 2>&1
 F=$(find $OUT -name fetch_results.db | head -1); D=$(dirname "$F")
-python tools/hbm_probe.py calibrate "$D" $OUT/hbm_calibration.json > $OUT/calibrate.log 2>&1
+python tools/hbm_probe.py calibrate "$D" $OUT/hbm_calibration.json --rates $OUT/probe_rates.json > $OUT/calibrate.log 2>&1
 cat $OUT/probe_rates.json; cat $OUT/calibrate.log | tail -30

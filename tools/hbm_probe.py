@@ -43,7 +43,7 @@ def last_per_kind(db, counter):
     return res
 
 
-def calibrate(d, out, mib=1024):
+def calibrate(d, out, mib=1024, rates=None):
     n = float(mib << 20)
     fetch = last_per_kind(os.path.join(d, "fetch_results.db"), "FETCH_SIZE")
     write = last_per_kind(os.path.join(d, "write_results.db"), "WRITE_SIZE")
@@ -56,6 +56,10 @@ def calibrate(d, out, mib=1024):
     # the engine's traffic is 16 B/lane loads, plain and nt stores: calibrate on copy (+ nt copy for the stores)
     res["fetch_factor"] = ff.get(0) or 2.0
     res["write_factor"] = (wf.get(0, 1.0) + wf.get(4, wf.get(0, 1.0))) / 2.0
+    if rates and os.path.exists(rates):          # the un-profiled probe rates of the same box
+        r = json.loads(open(rates).read().strip().splitlines()[-1])
+        for k in KINDS:
+            res[k + "_GBps"] = r[k]["GBps"]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
@@ -64,6 +68,6 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     opt = lambda k, d: int(a[a.index(k) + 1]) if k in a else d
     if a and a[0] == "calibrate":
-        calibrate(a[1], a[2], opt("--mib", 1024))
+        calibrate(a[1], a[2], opt("--mib", 1024), a[a.index("--rates") + 1] if "--rates" in a else None)
     else:
         run(opt("--mib", 1024), opt("--iters", 20))
