@@ -171,7 +171,7 @@ def cpu_baseline(args, cores):
     (no Rust toolchain in this image; `cargo` is probed and reported)."""
     from oracle import oracle as O
     n = args.cpu_chains or 2 * cores
-    draws = 25
+    draws = 100
     s = O.default_settings(seed=args.seed, num_tune=args.num_tune, num_chains=n)
     x0 = O.init_positions_uniform(args.seed, 0, n, args.dim)
     r = O.run_wall(s, O.LOGP_IID_NORMAL, args.dim, [3.0], O.ref_cfg(), n, x0, args.num_tune, draws, n_threads=cores)

@@ -41,6 +41,10 @@ struct Settings {
     double fixed_step_size;
     double da_k, da_t0, da_gamma, da_max_step_size;
     double adam_beta1, adam_beta2, adam_epsilon, adam_learning_rate;
+    // which MassMatrixAdaptStrategy: 0 = DiagAdaptStrategy, 1 = LowRankMassMatrixStrategy (reference src/sampler.rs:651, :245)
+    uint64_t adaptation;
+    double lr_gamma, lr_eigval_cutoff;          // LowRankSettings (src/transform/low_rank.rs:188-203)
+    uint64_t freeze_transform;                  // engine knob (not a reference setting): the transformation is given, never adapted
 };
 
 struct DrawStats {   // same field order as nm_draw_stats
@@ -50,6 +54,7 @@ struct DrawStats {   // same field order as nm_draw_stats
     double logp, energy, energy_error, fisher_distance, divergence_energy_error;
     uint64_t chain_status;
     int64_t transformation_update_id;   // DiagMassMatrixStats.transformation_update_id, -1 = None
+    uint64_t num_eigenvalues;           // MatrixStats.num_eigenvalues (low_rank.rs:205-216) on update draws, else 0
 };
 
 // Optional vector-valued statistics of one draw (rows of length dim; nullptr = not wanted).  The reference's
@@ -64,6 +69,7 @@ struct DrawVectors {
     double* divergence_start = nullptr;         // where diverging
     double* divergence_start_gradient = nullptr;
     double* divergence_end = nullptr;
+    double* mass_matrix_eigvals = nullptr;      // MatrixStats.mass_matrix_eigvals: lambda^(1/2), NaN-padded to dim (low_rank.rs:232-243)
 };
 
 enum { LOGP_IID_NORMAL = 0, LOGP_DIAG_NORMAL = 1, LOGP_FUNNEL = 2, LOGP_EIGHT_SCHOOLS = 3, LOGP_MVN_PREC = 4,
@@ -239,6 +245,13 @@ struct DiagMassMatrix {
         logdet = m.sum_ln(inv_stds.data(), n);
         id += 1;
     }
+    // set_transform :155-161
+    void set_transform(const Ctx& m, const Vec& stds_, const Vec& mean_) {
+        stds = stds_; mean = mean_;
+        for (size_t i = 0; i < stds.size(); ++i) inv_stds[i] = 1.0 / stds[i];   // array_recip cpu_math.rs:328-330
+        logdet = m.sum_ln(inv_stds.data(), stds.size());
+        id += 1;
+    }
     // :233-265
     void compute_transformed_position(const Vec& x, Vec& z) const {
         axpy_out(mean.data(), x.data(), -1.0, z.data(), x.size());
@@ -252,6 +265,88 @@ struct DiagMassMatrix {
         multiply(gx.data(), stds.data(), gz.data(), gx.size());
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// LowRankMassMatrix (reference src/transform/low_rank.rs:95-186, :325-404; apply_lowrank_transform*
+// src/math/cpu_math.rs:332-425).  F(y) = sigma . (I + U (diag(lambda)^1/2 - I) U') (y + mu_lr) + mean.
+// The base class is the `diag` member; the base's id / logdet double as the OUTER id / logdet (both ids start at -1 and
+// move together: update_from_grad and update bump diag.id and self.id in the same call, low_rank.rs:139-186).
+// Summation order of the two skinny matrix products: faer's matmul has no reproducible order (the reference's own
+// tests use 1e-12); here U'v is one ordered dot product per eigenvector (Ctx::vector_dot: the reference's SIMD order or
+// the engine's lane order) and v + U s is accumulated eigenvector by eigenvector with one fma per term.
+// ---------------------------------------------------------------------------------------------
+struct MassMatrix : DiagMassMatrix {
+    bool has_inner = false;
+    size_t rank = 0;
+    Vec vecs;              // [rank][n]: eigenvector k contiguous (column k of the reference's U)
+    Vec vals_sqrt, vals_sqrt_inv, mu_lr;
+    double logdet_contribution = 0;
+    explicit MassMatrix(size_t n) : DiagMassMatrix(n), mu_lr(n, 0.0) {}
+
+    // update_from_grad low_rank.rs:139-153
+    void update_from_grad(const Ctx& m, const Vec& pos, const Vec& grad, double fill, double lo, double hi) {
+        has_inner = false; rank = 0;
+        update_diag_grad(m, pos, grad, fill, lo, hi);          // logdet = diag.logdet, id += 1
+    }
+    // update low_rank.rs:155-186 with InnerMatrix::new :55-92.  vecs_rows: [n_eig][n].  Returns false when it bails out.
+    bool update(const Ctx& m, const Vec& stds_, const Vec& mean_, const Vec& vals, const Vec& vecs_rows, const Vec& mu_low_rank) {
+        const size_t n = mean.size();
+        if (!all_finite(stds_.data(), n) || !all_finite(mean_.data(), n)) return false;
+        if (!all_finite(vals.data(), vals.size()) || !all_finite(vecs_rows.data(), vecs_rows.size())) return false;
+        set_transform(m, stds_, mean_);
+        double ld = -0.0;                                       // f64::sum of the mapped iterator: sequential
+        for (double v : vals) ld += -0.5 * m.ln(v);
+        logdet_contribution = ld;
+        rank = vals.size();
+        vecs = vecs_rows;
+        vals_sqrt.resize(rank); vals_sqrt_inv.resize(rank);
+        for (size_t k = 0; k < rank; ++k) { vals_sqrt[k] = std::sqrt(vals[k]); vals_sqrt_inv[k] = 1.0 / vals_sqrt[k]; }
+        mu_lr = mu_low_rank;
+        logdet = logdet_contribution + logdet;                  // inner.logdet() + diag.logdet()
+        has_inner = true;
+        return true;
+    }
+    // apply_lowrank_transform_inplace cpu_math.rs:383-425:  v += U ((vals - 1) . (U' v))
+    void apply_inplace(const Ctx& m, const Vec& vals, Vec& v) const {
+        if (rank == 0) return;
+        const size_t n = v.size();
+        Vec sc(rank);
+        for (size_t k = 0; k < rank; ++k) sc[k] = m.vector_dot(&vecs[k * n], v.data(), n);
+        for (size_t k = 0; k < rank; ++k) sc[k] *= vals[k] - 1.0;
+        for (size_t k = 0; k < rank; ++k)
+            for (size_t i = 0; i < n; ++i) v[i] = std::fma(vecs[k * n + i], sc[k], v[i]);
+    }
+    // low_rank.rs:325-398
+    void compute_transformed_position(const Ctx& m, const Vec& x, Vec& z) const {
+        axpy_out(mean.data(), x.data(), -1.0, z.data(), x.size());
+        for (size_t i = 0; i < x.size(); ++i) z[i] = z[i] * inv_stds[i];
+        if (has_inner) {
+            axpy(mu_lr.data(), z.data(), -1.0, z.size());
+            apply_inplace(m, vals_sqrt_inv, z);
+        }
+    }
+    void compute_untransformed_position(const Ctx& m, const Vec& z, Vec& x) const {
+        if (!has_inner) multiply(z.data(), stds.data(), x.data(), z.size());
+        else {
+            x = z;                                              // apply_lowrank_transform: dest = rhs, then += U scratch
+            apply_inplace(m, vals_sqrt, x);
+            axpy(mu_lr.data(), x.data(), 1.0, x.size());
+            for (size_t i = 0; i < x.size(); ++i) x[i] = x[i] * stds[i];
+        }
+        axpy(mean.data(), x.data(), 1.0, z.size());
+    }
+    void compute_transformed_gradient(const Ctx& m, const Vec& gx, Vec& gz) const {
+        multiply(gx.data(), stds.data(), gz.data(), gx.size());
+        if (has_inner) apply_inplace(m, vals_sqrt, gz);
+    }
+};
+
+// What LowRankMassMatrixStrategy::compute_update needs (reference src/transform/adapt/low_rank.rs:73-142): thin SVDs, a
+// pivoted QR and three symmetric eigendecompositions.  The oracle delegates them to a callback (numpy / LAPACK in
+// oracle/lowrank.py, following the reference step by step).  draws / grads: [ndraws][ndim].  Returns 0 = Some(...), 1 = None.
+typedef int (*lowrank_estimator_fn)(void* ctx, uint64_t ndim, uint64_t ndraws, const double* draws, const double* grads,
+                                    double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
+                                    double* vals /*[min(ndim, 2 ndraws)]*/, double* vecs /*[.][ndim]*/, double* mu_low_rank);
 
 // AcceptanceRateCollector (reference src/stepsize/dual_avg.rs:83-166)
 struct AcceptanceRateCollector {
@@ -310,7 +405,7 @@ struct LeapfrogResult { LeapfrogKind kind; State state; DivergenceInfo info; };
 struct Hamiltonian {
     const Ctx* m;
     const Density* dens;
-    DiagMassMatrix mm;
+    MassMatrix mm;
     double step_size = 0;
     size_t n;
     Hamiltonian(const Ctx* m_, const Density* d) : m(m_), dens(d), mm(d->dim), n(d->dim) {}
@@ -327,7 +422,7 @@ struct Hamiltonian {
         axpy_out(s.gz.data(), s.v.data(), epsilon / 2., o.v.data(), n);          // first_velocity_halfstep :178-184
         axpy_out(o.v.data(), s.z.data(), epsilon, o.z.data(), n);                // position_step :220-225
         // init_from_transformed_position (diagonal.rs:196-209)
-        mm.compute_untransformed_position(o.z, o.x);
+        mm.compute_untransformed_position(*m, o.z, o.x);
         double logp = 0;
         int st = dens->logp(*m, o.x.data(), o.gx.data(), &logp);
         if (st != 0) {
@@ -337,7 +432,7 @@ struct Hamiltonian {
             if (acc) acc->register_leapfrog(*m, out.get(), true);
             return {LF_DIVERGENCE, nullptr, info};
         }
-        mm.compute_transformed_gradient(o.gx, o.gz);
+        mm.compute_transformed_gradient(*m, o.gx, o.gz);
         o.logp = logp;
         o.logdet = mm.logdet;
         o.transform_id = mm.id;
@@ -381,8 +476,8 @@ struct Hamiltonian {
         double logp = 0;
         int rc = dens->logp(*m, p.x.data(), p.gx.data(), &logp);               // init_from_untransformed_position
         if (rc != 0) return ST_LOGP_FATAL;
-        mm.compute_transformed_position(p.x, p.z);
-        mm.compute_transformed_gradient(p.gx, p.gz);
+        mm.compute_transformed_position(*m, p.x, p.z);
+        mm.compute_transformed_gradient(*m, p.gx, p.gz);
         p.logp = logp; p.logdet = mm.logdet; p.transform_id = mm.id;
         if (!check_all(p)) return ST_BAD_INIT;
         *out = st;
@@ -408,8 +503,8 @@ struct Hamiltonian {
     void initialize_trajectory(Point& p, ChaCha8Rng& rng) {
         for (size_t i = 0; i < n; ++i) p.v[i] = 1.0 * standard_normal(rng, *m);  // array_gaussian cpu_math.rs:561-577
         if (mm.id != p.transform_id) {                                           // inv_transform_normalize diagonal.rs:210-221
-            mm.compute_transformed_position(p.x, p.z);
-            mm.compute_transformed_gradient(p.gx, p.gz);
+            mm.compute_transformed_position(*m, p.x, p.z);
+            mm.compute_transformed_gradient(*m, p.gx, p.gz);
             p.logdet = mm.logdet;
             p.transform_id = mm.id;
         }

@@ -37,7 +37,7 @@ def last_per_kind(db, counter):
     c = sqlite3.connect(db)
     res = {}
     for name, cname, val in c.execute("select kernel_name, counter_name, value from counters_collection order by start"):
-        m = re.search(r"probe_kernel<\(?(?:int\))?(\d)>", name)
+        m = re.search(r"probe_flat_kernel<\(?(?:int\))?(\d), *\(?(?:int\))?8>", name)     # the widest flat variant
         if m and cname == counter:
             res[int(m.group(1))] = val
     return res
