@@ -12,6 +12,7 @@
 //   NutsChain                  src/chain.rs:137-188
 #pragma once
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <string>
 #include <vector>
@@ -724,6 +725,11 @@ struct Chain {
     bool tuning = true, has_initial_mass_matrix = true;
     // diag Strategy (adapt/diagonal.rs:108-115)
     RunningVariance var_draw, var_grad, var_draw_bg, var_grad_bg;
+    // LowRankMassMatrixStrategy (adapt/low_rank.rs:14-21): the window of draws / gradients and where its background starts
+    std::deque<Vec> lr_draws, lr_grads;
+    size_t lr_background_split = 0;
+    lowrank_estimator_fn lr_estimator = nullptr;
+    void* lr_estimator_ctx = nullptr;
     // stepsize::Strategy (stepsize/adapt.rs:52-65)
     DualAverage da;
     Adam adam;
@@ -753,6 +759,29 @@ struct Chain {
     }
     Chain(const Chain&) = delete;
 
+    bool is_low_rank() const { return s.adaptation == 1; }
+    // MassMatrixAdaptStrategy::{current_count, background_count} (adapt/diagonal.rs:150-159, adapt/low_rank.rs:339-345)
+    uint64_t mm_current_count() const { return is_low_rank() ? lr_draws.size() : var_draw.count; }
+    uint64_t mm_background_count() const { return is_low_rank() ? lr_draws.size() - lr_background_split : var_draw_bg.count; }
+    // LowRankMassMatrixStrategy::adapt -> update (adapt/low_rank.rs:53-71, :347-353): true whenever count >= 3, whatever
+    // the estimator or LowRankMassMatrix::update make of the window
+    bool lowrank_adapt() {
+        if (lr_draws.size() < 3) return false;
+        const size_t nd = lr_draws.size();
+        Vec D(nd * n), G(nd * n);
+        for (size_t i = 0; i < nd; ++i)
+            for (size_t j = 0; j < n; ++j) { D[i * n + j] = lr_draws[i][j]; G[i * n + j] = lr_grads[i][j]; }
+        const size_t maxr = std::min(n, 2 * nd);
+        Vec stds(n), mean(n), vals(maxr), vecs(maxr * n), mu(n);
+        uint64_t n_eig = 0;
+        if (!lr_estimator) return true;
+        int rc = lr_estimator(lr_estimator_ctx, n, nd, D.data(), G.data(), s.lr_gamma, s.lr_eigval_cutoff, stds.data(),
+                              mean.data(), &n_eig, vals.data(), vecs.data(), mu.data());
+        if (rc != 0) return true;                                // compute_update returned None: no update, still `true`
+        vals.resize(n_eig); vecs.resize(n_eig * n);
+        (void)h.mm.update(m, stds, mean, vals, vecs, mu);
+        return true;
+    }
     bool is_fixed() const { return s.step_size_method == 2; }
     bool is_adam() const { return s.step_size_method == 1; }
     void adapt_reset(double step) { if (is_adam()) adam.reset(m, step); else da.reset(m, step); }
@@ -813,10 +842,16 @@ struct Chain {
         State st;
         int rc = h.init_state_untransformed(position, &st);
         if (rc != ST_OK) return rc;
-        // DiagAdaptStrategy::init adapt/diagonal.rs:209-231
-        var_draw.add_sample(st->x); var_draw_bg.add_sample(st->x);
-        var_grad.add_sample(st->gx); var_grad_bg.add_sample(st->gx);
-        h.mm.update_diag_grad(m, st->x, st->gx, 1.0, 1e-20, 1e20);
+        if (is_low_rank()) {
+            // LowRankMassMatrixStrategy::init adapt/low_rank.rs:299-317: add_draw(point), update_from_grad
+            lr_draws.push_back(st->x); lr_grads.push_back(st->gx);
+            h.mm.update_from_grad(m, st->x, st->gx, 1.0, 1e-20, 1e20);
+        } else {
+            // DiagAdaptStrategy::init adapt/diagonal.rs:209-231
+            var_draw.add_sample(st->x); var_draw_bg.add_sample(st->x);
+            var_grad.add_sample(st->gx); var_grad_bg.add_sample(st->gx);
+            h.mm.update_diag_grad(m, st->x, st->gx, 1.0, 1e-20, 1e20);
+        }
         rc = stepsize_init(position);
         if (rc != ST_OK) return rc;
         rc = h.init_state(position, &state);
@@ -832,14 +867,19 @@ struct Chain {
         if (draw >= num_tune) { update_stepsize(true); tuning = false; return ST_OK; }
         if (draw < final_step_size_window) {
             bool is_early = draw < early_end;
+            const bool frozen = s.freeze_transform != 0;                          // engine knob: no mass-matrix estimator at all
             if (!is_early && draw == early_end)
-                current_window_size = std::max(current_window_size, var_draw_bg.count);
+                current_window_size = std::max(current_window_size, frozen ? (uint64_t)0 : mm_background_count());
             uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : current_window_size;
-            if (coll.dg.is_good) {                                                // update_estimators adapt/diagonal.rs:134-141
-                var_draw.add_sample(coll.dg.draw); var_grad.add_sample(coll.dg.grad);
-                var_draw_bg.add_sample(coll.dg.draw); var_grad_bg.add_sample(coll.dg.grad);
+            if (coll.dg.is_good && !frozen) {
+                if (is_low_rank()) {                                              // update_estimators adapt/low_rank.rs:323-333
+                    lr_draws.push_back(coll.dg.draw); lr_grads.push_back(coll.dg.grad);
+                } else {                                                          // update_estimators adapt/diagonal.rs:134-141
+                    var_draw.add_sample(coll.dg.draw); var_grad.add_sample(coll.dg.grad);
+                    var_draw_bg.add_sample(coll.dg.draw); var_grad_bg.add_sample(coll.dg.grad);
+                }
             }
-            bool could_switch = var_draw_bg.count >= switch_freq;
+            bool could_switch = !frozen && mm_background_count() >= switch_freq;
             uint64_t next_window_size;
             if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
             else {
@@ -849,13 +889,21 @@ struct Chain {
             bool is_late = next_window_size + draw > final_step_size_window;
             bool force_update = false;
             if (could_switch && !is_late) {
-                var_draw = var_draw_bg; var_draw_bg = RunningVariance(n);         // switch adapt/diagonal.rs:143-148
-                var_grad = var_grad_bg; var_grad_bg = RunningVariance(n);
+                if (is_low_rank()) {                                              // switch adapt/low_rank.rs:335-342
+                    for (size_t i = 0; i < lr_background_split; ++i) { lr_draws.pop_front(); lr_grads.pop_front(); }
+                    lr_background_split = lr_draws.size();
+                } else {
+                    var_draw = var_draw_bg; var_draw_bg = RunningVariance(n);     // switch adapt/diagonal.rs:143-148
+                    var_grad = var_grad_bg; var_grad_bg = RunningVariance(n);
+                }
                 force_update = true;
                 if (!is_early) current_window_size = next_window_size;
             }
             bool did_change = false;
-            if (force_update | (draw - last_update >= s.mass_matrix_update_freq)) {
+            if (frozen) {
+            } else if (is_low_rank()) {
+                if (force_update | (draw - last_update >= s.mass_matrix_update_freq)) did_change = lowrank_adapt();
+            } else if (force_update | (draw - last_update >= s.mass_matrix_update_freq)) {
                 if (var_draw.count >= 3) {                                        // Strategy::adapt adapt/diagonal.rs:161-196
                     if (s.use_grad_based_estimate)
                         h.mm.update_diag_draw_grad(m, var_draw.mean, var_grad.mean, var_draw.variance, var_grad.variance,
@@ -906,13 +954,18 @@ struct Chain {
             // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70) against the id seen at the previous
             // extraction (chain.rs:195-200; starts at -1, sampler.rs:795)
             o.transformation_update_id = h.mm.id != stats_last_id ? h.mm.id : -1;
+            o.num_eigenvalues = (h.mm.id != stats_last_id && h.mm.has_inner) ? h.mm.rank : 0;   // MatrixStats low_rank.rs:222-229
         }
         if (vec) {
             auto put = [&](double* dst, const Vec& v) { if (dst) for (size_t i = 0; i < n; ++i) dst[i] = v[i]; };
             put(vec->gradient, chosen->gx);
             put(vec->transformed_position, chosen->z);
             put(vec->transformed_gradient, chosen->gz);
-            if (h.mm.id != stats_last_id) { put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean); }
+            if (h.mm.id != stats_last_id) {
+                put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean);
+                if (vec->mass_matrix_eigvals && h.mm.has_inner)                    // low_rank.rs:232-243: lambda^(1/2), NaN beyond the rank
+                    for (size_t i = 0; i < n; ++i) vec->mass_matrix_eigvals[i] = i < h.mm.rank ? h.mm.vals_sqrt[i] : NAN;
+            }
             if (info.divergence.present) {
                 put(vec->divergence_start, info.divergence.start_location);
                 put(vec->divergence_start_gradient, info.divergence.start_gradient);

@@ -26,6 +26,12 @@ void nmo_settings_default(Settings* s) {
     s->step_size_method = 0; s->fixed_step_size = 0.0;
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;   // adam.rs:25-33
+    s->adaptation = 0; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;          // low_rank.rs:195-203
+}
+// LowRankNutsSettings::default() (reference src/sampler.rs:636-642): num_tune 800, mass_matrix_update_freq 20
+void nmo_settings_default_low_rank(Settings* s) {
+    nmo_settings_default(s);
+    s->num_tune = 800; s->mass_matrix_update_freq = 20; s->adaptation = 1;
 }
 uint64_t nmo_settings_size(void) { return sizeof(Settings); }
 uint64_t nmo_draw_stats_size(void) { return sizeof(DrawStats); }
@@ -65,6 +71,18 @@ void* nmo_chain_create_callback(const Settings* s, uint64_t dim, host_logp_fn cb
     return new Chain(*s, d, *cfg, chain_id, key);
 }
 void nmo_chain_destroy(void* c) { delete (Chain*)c; }
+// LowRankMassMatrixStrategy's dense linear algebra (thin SVD / pivoted QR / eigh) is delegated to this callback
+void nmo_chain_set_estimator(void* c, lowrank_estimator_fn fn, void* ctx) { ((Chain*)c)->lr_estimator = fn; ((Chain*)c)->lr_estimator_ctx = ctx; }
+// LowRankMassMatrix::update(stds, mean, vals, vecs, mean_low_rank) on the chain's transformation (vecs: [n_eig][dim]);
+// returns 1 if it was applied, 0 if update() bailed out on non-finite input
+int nmo_chain_set_transform(void* cv, const double* stds, const double* mean, uint64_t n_eig, const double* vals,
+                            const double* vecs, const double* mu_lr) {
+    Chain* c = (Chain*)cv;
+    const size_t n = c->n;
+    return c->h.mm.update(c->m, Vec(stds, stds + n), Vec(mean, mean + n), Vec(vals, vals + n_eig), Vec(vecs, vecs + n_eig * n),
+                          Vec(mu_lr, mu_lr + n)) ? 1 : 0;
+}
+int nmo_chain_draw_ex(void* c, double* out_position, DrawStats* stats, const DrawVectors* vec) { return ((Chain*)c)->draw(out_position, stats, vec); }
 int nmo_chain_set_position(void* c, const double* x0) { return ((Chain*)c)->set_position(x0); }
 int nmo_chain_draw(void* c, double* out_position, DrawStats* stats) { return ((Chain*)c)->draw(out_position, stats); }
 void nmo_chain_get_state(void* cv, double* x, double* gx, double* stds, double* mean, double* step_size,
@@ -83,10 +101,31 @@ void nmo_chain_get_state(void* cv, double* x, double* gx, double* stds, double* 
 // Many chains, one task per chain over `n_threads` host threads (the structure of the reference's Rayon
 // Sampler, src/sampler.rs:1116, :1287-1326).  x0 [n][dim]; out_positions [n_draws][n][dim] or NULL;
 // out_stats [n_draws][n] or NULL.  Returns the number of chains that failed.
+// A transformation given from outside (nm_engine_set_transform on the engine): applied to every chain right after
+// set_position with LowRankMassMatrix::update semantics.  per_chain = 0: one (stds, mean, vals, vecs, mu_lr) for all
+// chains; 1: arrays are [n_chains][...].
+struct RunExtras {
+    const double *stds, *mean, *vals, *vecs, *mu_lr;
+    uint64_t n_eig, per_chain;
+    lowrank_estimator_fn estimator;
+    void* estimator_ctx;
+};
+static RunExtras g_no_extras = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+int nmo_run_ex(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+               const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_draws,
+               double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads,
+               const DrawVectors* out_vec, const RunExtras* ex);
 int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
             const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_draws,
             double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads,
             const DrawVectors* out_vec /* bases of [n_draws][n][dim] arrays, or NULL */) {
+    return nmo_run_ex(s, kind, dim, params, n_params, cfg, n_chains, chain_offset, x0, n_draws, out_positions, out_stats,
+                      out_total_steps, n_threads, out_vec, &g_no_extras);
+}
+int nmo_run_ex(const Settings* s, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+               const MathCfg* cfg, uint64_t n_chains, uint64_t chain_offset, const double* x0, uint64_t n_draws,
+               double* out_positions, DrawStats* out_stats, uint64_t* out_total_steps, uint64_t n_threads,
+               const DrawVectors* out_vec, const RunExtras* ex) {
     std::atomic<uint64_t> next{0}, steps{0};
     std::atomic<int> failed{0};
     auto work = [&]() {
@@ -97,7 +136,13 @@ int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params,
             nmo_chain_key(s->seed, chain_offset + c, key);
             Density d = make_density(kind, dim, params, n_params);
             Chain ch(*s, d, *cfg, chain_offset + c, key);
+            ch.lr_estimator = ex->estimator; ch.lr_estimator_ctx = ex->estimator_ctx;
             if (ch.set_position(x0 + c * dim) != ST_OK) { failed++; continue; }
+            if (ex->stds) {
+                const uint64_t k = ex->per_chain ? c : 0, r = ex->n_eig;
+                (void)nmo_chain_set_transform(&ch, ex->stds + k * dim, ex->mean + k * dim, r, ex->vals + k * r,
+                                              ex->vecs + k * r * dim, ex->mu_lr + k * dim);
+            }
             uint64_t local = 0;
             for (uint64_t t = 0; t < n_draws; ++t) {
                 DrawStats st;
@@ -107,7 +152,7 @@ int nmo_run(const Settings* s, int64_t kind, uint64_t dim, const double* params,
                     auto at = [&](double* b) { return b ? b + off : nullptr; };
                     row = {at(out_vec->gradient), at(out_vec->transformed_position), at(out_vec->transformed_gradient),
                            at(out_vec->mass_matrix_inv), at(out_vec->transformation_mu), at(out_vec->divergence_start),
-                           at(out_vec->divergence_start_gradient), at(out_vec->divergence_end)};
+                           at(out_vec->divergence_start_gradient), at(out_vec->divergence_end), at(out_vec->mass_matrix_eigvals)};
                 }
                 int rc = ch.draw(out_positions ? out_positions + (t * n_chains + c) * dim : nullptr, &st,
                                  out_vec ? &row : nullptr);
@@ -326,6 +371,36 @@ int nmo_diag_kat(const MathCfg* cfg, uint64_t dim, const double* precision_diag,
         z[i] = Z[i]; gz[i] = GZ[i]; x_rt[i] = XR[i];
         stds[i] = mm.stds[i]; inv_stds[i] = mm.inv_stds[i]; mean[i] = mm.mean[i];
     }
+    return rc;
+}
+
+// LowRankMassMatrix known-answer harness (reference tests src/transform/mod.rs:391-674, src/transform/low_rank.rs:415-533):
+// update(stds, mean, vals, vecs, mu_lr) then init_from_untransformed_position(x) and the init_from_transformed_position
+// round trip; `which` >= 0 instead applies one map to `x`: 0 compute_transformed_position, 1 compute_untransformed_position,
+// 2 compute_transformed_gradient (result in z).
+int nmo_lowrank_kat(const MathCfg* cfg, uint64_t dim, const double* precision_diag, const double* stds, const double* mean,
+                    uint64_t n_eig, const double* vals, const double* vecs, const double* mu_lr, int64_t which,
+                    const double* x, double* z, double* gz, double* logp, double* logdet, double* x_rt, double* logp_rt,
+                    double* logdet_rt) {
+    Ctx m{*cfg};
+    Density d = make_density(LOGP_DIAG_NORMAL, dim, precision_diag, dim);
+    MassMatrix mm(dim);
+    if (!mm.update(m, Vec(stds, stds + dim), Vec(mean, mean + dim), Vec(vals, vals + n_eig), Vec(vecs, vecs + n_eig * dim),
+                   Vec(mu_lr, mu_lr + dim))) return 3;
+    Vec X(x, x + dim), GX(dim), Z(dim), GZ(dim);
+    if (which == 0) { mm.compute_transformed_position(m, X, Z); for (uint64_t i = 0; i < dim; ++i) z[i] = Z[i]; return 0; }
+    if (which == 1) { mm.compute_untransformed_position(m, X, Z); for (uint64_t i = 0; i < dim; ++i) z[i] = Z[i]; return 0; }
+    if (which == 2) { mm.compute_transformed_gradient(m, X, Z); for (uint64_t i = 0; i < dim; ++i) z[i] = Z[i]; return 0; }
+    int rc = d.logp(m, X.data(), GX.data(), logp);
+    mm.compute_transformed_position(m, X, Z);
+    mm.compute_transformed_gradient(m, GX, GZ);
+    *logdet = mm.logdet;
+    Vec XR(dim), GXR(dim), GZR(dim);
+    mm.compute_untransformed_position(m, Z, XR);
+    rc |= d.logp(m, XR.data(), GXR.data(), logp_rt);
+    mm.compute_transformed_gradient(m, GXR, GZR);
+    *logdet_rt = mm.logdet;
+    for (uint64_t i = 0; i < dim; ++i) { z[i] = Z[i]; gz[i] = GZ[i]; x_rt[i] = XR[i]; }
     return rc;
 }
 

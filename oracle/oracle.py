@@ -40,8 +40,12 @@ class Settings(C.Structure):
         ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
         ("adam_learning_rate", C.c_double),
+        ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
+        ("freeze_transform", C.c_uint64),
     ]
 
+
+ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
 
 STATS_DTYPE = np.dtype([
     ("draw", "<u8"), ("chain", "<u8"), ("depth", "<u8"), ("maxdepth_reached", "<u8"), ("diverging", "<u8"),
@@ -49,11 +53,11 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
-    ("transformation_update_id", "<i8"),
+    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"),
 ])
 
 VECTOR_STATS = ("gradient", "transformed_position", "transformed_gradient", "mass_matrix_inv", "transformation_mu",
-                "divergence_start", "divergence_start_gradient", "divergence_end")
+                "divergence_start", "divergence_start_gradient", "divergence_end", "mass_matrix_eigvals")
 
 
 class DrawVectors(C.Structure):
@@ -63,6 +67,18 @@ class DrawVectors(C.Structure):
 class MathCfg(C.Structure):
     _fields_ = [("detmath", C.c_int64), ("reduce_mode", C.c_int64), ("simd_lanes", C.c_int64),
                 ("gpu_threads", C.c_int64)]
+
+
+# LowRankMassMatrixStrategy's dense linear algebra as a callback (oracle/lowrank.py implements it with LAPACK)
+ESTIMATOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+class RunExtras(C.Structure):
+    _fields_ = [("stds", C.c_void_p), ("mean", C.c_void_p), ("vals", C.c_void_p), ("vecs", C.c_void_p),
+                ("mu_lr", C.c_void_p), ("n_eig", C.c_uint64), ("per_chain", C.c_uint64),
+                ("estimator", ESTIMATOR_FN), ("estimator_ctx", C.c_void_p)]
 
 
 REDUCE_REF_SIMD, REDUCE_GPU = 0, 1
@@ -107,6 +123,16 @@ def lib():
     L.nmo_run.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64, C.POINTER(MathCfg),
                           C.c_uint64, C.c_uint64, _dp, C.c_uint64, C.c_void_p, C.c_void_p,
                           C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p]
+    L.nmo_run_ex.restype = C.c_int
+    L.nmo_run_ex.argtypes = L.nmo_run.argtypes + [C.POINTER(RunExtras)]
+    L.nmo_settings_default_low_rank.argtypes = [C.POINTER(Settings)]
+    L.nmo_chain_set_estimator.argtypes = [C.c_void_p, ESTIMATOR_FN, C.c_void_p]
+    L.nmo_chain_set_transform.restype = C.c_int
+    L.nmo_chain_set_transform.argtypes = [C.c_void_p, _dp, _dp, C.c_uint64, _dp, _dp, _dp]
+    L.nmo_lowrank_kat.restype = C.c_int
+    L.nmo_lowrank_kat.argtypes = [C.POINTER(MathCfg), C.c_uint64, _dp, _dp, _dp, C.c_uint64, _dp, _dp, _dp, C.c_int64,
+                                  _dp, _dp, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double), _dp,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.nmo_adam_sequence.restype = None
     L.nmo_adam_sequence.argtypes = [C.POINTER(MathCfg), C.c_double, C.POINTER(C.c_double), C.c_uint64, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
@@ -151,9 +177,10 @@ def lib():
     return L
 
 
-def default_settings(**overrides):
+def default_settings(low_rank=False, **overrides):
+    """DiagNutsSettings::default() or, with low_rank=True, LowRankNutsSettings::default() (src/sampler.rs:630-642)."""
     s = Settings()
-    lib().nmo_settings_default(C.byref(s))
+    (lib().nmo_settings_default_low_rank if low_rank else lib().nmo_settings_default)(C.byref(s))
     for k, v in overrides.items():
         if not hasattr(s, k):
             raise AttributeError(k)
@@ -212,6 +239,22 @@ class Chain:
         return dict(x=x, gx=gx, stds=sd, mean=mu, step_size=eps.value, rng_pos=pos.value)
 
 
+def lowrank_kat(cfg, precision_diag, stds, mean, vals, vecs, mu_lr, x, which=-1):
+    """LowRankMassMatrix::update(...) then init_from_untransformed_position(x) + round trip (which = -1), or one of
+    compute_transformed_position / compute_untransformed_position / compute_transformed_gradient (which = 0 / 1 / 2)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    dim = len(stds)
+    vals = f(vals)
+    vecs = f(vecs).reshape(len(vals), dim) if len(vals) else np.zeros((0, dim))
+    z, gz, x_rt = np.empty(dim), np.empty(dim), np.empty(dim)
+    logp, logdet, logp_rt, logdet_rt = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    rc = lib().nmo_lowrank_kat(C.byref(cfg), dim, f(precision_diag), f(stds), f(mean), len(vals),
+                               vals if len(vals) else np.zeros(1), vecs if len(vals) else np.zeros(1), f(mu_lr), which, f(x),
+                               z, gz, C.byref(logp), C.byref(logdet), x_rt, C.byref(logp_rt), C.byref(logdet_rt))
+    return dict(rc=rc, z=z, gz=gz, x_rt=x_rt, logp=logp.value, logdet=logdet.value, logp_rt=logp_rt.value,
+                logdet_rt=logdet_rt.value)
+
+
 def adam_sequence(initial_step, accept, target, beta1, beta2, epsilon, learning_rate, cfg=None):
     acc = np.ascontiguousarray(accept, dtype=np.float64)
     out = np.empty(len(acc))
@@ -222,8 +265,20 @@ def adam_sequence(initial_step, accept, target, beta1, beta2, epsilon, learning_
     return out
 
 
+def _transform_arrays(transform, n_chains, dim):
+    """(stds, mean, vals, vecs, mu_lr) -> contiguous arrays + (n_eig, per_chain).  vecs is [n_eig][dim] (one eigenvector
+    per row), or [n_chains][n_eig][dim] with every other entry carrying a leading chain axis too."""
+    stds, mean, vals, vecs, mu = (np.ascontiguousarray(a, dtype=np.float64) for a in transform)
+    per_chain = int(stds.ndim == 2)
+    n_eig = vals.shape[-1] if vals.size else 0
+    want = ((n_chains, dim) if per_chain else (dim,))
+    assert stds.shape == want and mean.shape == want and mu.shape == want
+    assert vecs.size == (n_chains if per_chain else 1) * n_eig * dim
+    return (stds, mean, vals, vecs, mu), n_eig, per_chain
+
+
 def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0, n_threads=1,
-        want_positions=True, want_stats=True, vectors=None):
+        want_positions=True, want_stats=True, vectors=None, transform=None, estimator=None):
     """Many chains on host threads (reference Sampler structure).  Returns positions [draws][chains][dim], stats, steps.
 
     vectors: optional dict that receives the vector-valued statistics, [draws][chains][dim] each (NaN-filled; event
@@ -239,10 +294,18 @@ def run(settings, kind, dim, params, cfg, n_chains, x0, n_draws, chain_offset=0,
         for k in VECTOR_STATS:
             vectors[k] = np.full((n_draws, n_chains, dim), np.nan)
             setattr(dv, k, vectors[k].ctypes.data)
-    failed = lib().nmo_run(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains, chain_offset,
-                           x0, n_draws, pos.ctypes.data if pos is not None else None,
-                           st.ctypes.data if st is not None else None, C.byref(steps), n_threads,
-                           C.byref(dv) if dv is not None else None)
+    ex = RunExtras()
+    keep = None
+    if transform is not None:
+        keep, ex.n_eig, ex.per_chain = _transform_arrays(transform, n_chains, dim)
+        ex.stds, ex.mean, ex.vals, ex.vecs, ex.mu_lr = (a.ctypes.data for a in keep)
+    if estimator is not None:
+        ex.estimator = estimator
+        n_threads = 1               # a Python callback: one thread
+    failed = lib().nmo_run_ex(C.byref(settings), kind, dim, params, len(params), C.byref(cfg), n_chains, chain_offset,
+                              x0, n_draws, pos.ctypes.data if pos is not None else None,
+                              st.ctypes.data if st is not None else None, C.byref(steps), n_threads,
+                              C.byref(dv) if dv is not None else None, C.byref(ex))
     return pos, st, steps.value, failed
 
 

@@ -397,3 +397,110 @@ def test_reference_crate_draws(oracle):
         c = ch["chain"]
         assert (st["n_steps"][:, c] == np.array(ch["num_steps"])).all(), "tree sizes differ: the random stream is not the crate's"
         assert np.allclose(pos[:, c], np.array(ch["draws"]), rtol=1e-9, atol=1e-12)
+
+
+# ---- low-rank transformation (reference src/transform/low_rank.rs, adapt/low_rank.rs) ----------------------------------
+def _std_normal_logp(z):
+    return -0.5 * (len(z) * math.log(2 * math.pi) + float(np.sum(np.asarray(z) ** 2)))
+
+
+@pytest.mark.parametrize("mode", ["ref", "gpu"])
+def test_lowrank_mass_matrix_reference_kats(oracle, mode):
+    """The reference's own LowRankMassMatrix tests (src/transform/mod.rs:391-674), tolerance 1e-12 as there."""
+    cfg = oracle.ref_cfg() if mode == "ref" else oracle.gpu_cfg()
+    for name in ("lowrank_transform_position_and_gradient", "lowrank_round_trip", "lowrank_with_rank1_correction",
+                 "lowrank_nonzero_mean"):
+        k = KATS[name]
+        tol = k["tol"]
+        if "sigma2" in k:
+            sigma2 = np.array(k["sigma2"])
+            prec, stds = 1.0 / sigma2, np.sqrt(sigma2)
+        else:
+            prec, stds = np.array(k["precision_diag"]), np.array(k["stds"])
+        mean = np.array(k["mean"], dtype=float)
+        x = mean + stds if k.get("x_is_mean_plus_sigma") else np.array(k["x"])
+        r = oracle.lowrank_kat(cfg, prec, stds, mean, k["vals"], k["vecs"], k["mu_lr"], x)
+        assert r["rc"] == 0
+        if "expect_z" in k:
+            assert np.abs(r["z"] - k["expect_z"]).max() <= tol, name
+        if "expect_gz" in k:
+            assert np.abs(r["gz"] - k["expect_gz"]).max() <= tol, name
+        assert np.abs(r["x_rt"] - x).max() <= tol, name                       # init_from_transformed_position recovers x
+        assert abs(r["logp"] - r["logp_rt"]) < tol and abs(r["logdet"] - r["logdet_rt"]) < tol
+        expected_logdet = float(np.sum(-np.log(stds))) + float(np.sum(-0.5 * np.log(np.array(k["vals"], dtype=float))))
+        assert abs(r["logdet"] - expected_logdet) < tol, name
+        if k.get("adapted_logp_is_standard_normal"):
+            assert abs((r["logp"] - r["logdet"]) - _std_normal_logp(r["z"])) < tol, name
+
+
+@pytest.mark.parametrize("mode", ["ref", "gpu"])
+def test_lowrank_module_round_trips(oracle, mode):
+    """src/transform/low_rank.rs:415-533: compute_transformed_position and compute_untransformed_position are inverses."""
+    cfg = oracle.ref_cfg() if mode == "ref" else oracle.gpu_cfg()
+    K = KATS["lowrank_module_round_trips"]
+    for c in K["cases"]:
+        a = (np.ones(3), c["stds"], c["mean"], c["vals"], c["vecs"], c["mu_lr"])
+        first, second = (0, 1) if c["start"] == "x" else (1, 0)
+        mid = oracle.lowrank_kat(cfg, *a, c["point"], which=first)["z"]
+        back = oracle.lowrank_kat(cfg, *a, mid, which=second)["z"]
+        assert np.abs(back - c["point"]).max() <= K["tol"], c["name"]
+
+
+def test_lowrank_estimator_reference_kats(oracle):
+    """src/transform/adapt/low_rank.rs:354-407 (test_spd_mean, test_estimate_mass_matrix) on the oracle's estimator."""
+    from oracle import lowrank as LR
+    K = KATS["lowrank_estimator"]
+    k = K["spd_mean"]
+    out = LR.spd_mean(np.diag(k["x_diag"]), np.diag(k["y_diag"]))
+    assert np.allclose(out, np.diag(k["expected_diag"]), rtol=k["rel_tol"], atol=k["abs_tol"])
+    k = K["estimate_mass_matrix"]
+    draws = np.random.default_rng(1).normal(size=tuple(k["shape"]))
+    vals, vecs = LR.estimate_mass_matrix(draws, -draws, k["gamma"])
+    assert (vals > 0).all() and np.isfinite(vecs).all()
+    assert np.allclose(vals, 1.0, rtol=k["rel_tol"], atol=k["abs_tol"])
+    # the whole update on an exactly low-rank correlated Gaussian: x = L e, score = -Sigma^-1 x  =>  F whitens it
+    rng = np.random.default_rng(5)
+    dim, n = 12, 60
+    u = np.linalg.qr(rng.normal(size=(dim, 2)))[0]
+    sigma = np.eye(dim) + u @ np.diag([30.0, 8.0]) @ u.T
+    x = np.linalg.cholesky(sigma) @ rng.normal(size=(dim, n))
+    g = -np.linalg.solve(sigma, x)
+    stds, mean, vals, vecs, mu = LR.compute_update(x, g, 1e-5, 2.0)
+    assert len(vals) >= 2 and vals.max() > 4 and np.isfinite(vecs).all()
+    a = np.eye(dim) + vecs @ np.diag(np.sqrt(vals) - 1.0) @ vecs.T            # F's linear part without sigma
+    cov_adapted = np.linalg.inv(np.diag(stds) @ a) @ sigma @ np.linalg.inv(np.diag(stds) @ a).T
+    assert np.linalg.cond(cov_adapted) < 0.2 * np.linalg.cond(np.diag(1 / stds) @ sigma @ np.diag(1 / stds))
+
+
+def test_default_settings_low_rank(oracle):
+    k = KATS["default_settings_low_rank"]
+    s = oracle.default_settings(low_rank=True)
+    for name, v in k.items():
+        if name != "source":
+            assert getattr(s, name) == v, name
+    assert s.adaptation == oracle.ADAPT_LOW_RANK
+
+
+def test_lowrank_adaptation_behaviour(oracle):
+    """LowRankNutsSettings on a correlated normal: the adapted transformation must shorten the trajectories compared with
+    the diagonal adaptation (the reason the reference has it), and a fixed exact transformation must whiten the target."""
+    from oracle import lowrank as LR
+    dim = 16
+    rng = np.random.default_rng(11)
+    u = np.linalg.qr(rng.normal(size=(dim, 2)))[0]
+    sigma = np.eye(dim) + u @ np.diag([200.0, 50.0]) @ u.T
+    prec = np.linalg.inv(sigma)
+    prec = (prec + prec.T) / 2
+    x0 = oracle.init_positions_uniform(3, 0, 2, dim)
+    steps = {}
+    for low_rank in (False, True):
+        s = oracle.default_settings(low_rank=low_rank, seed=3, num_tune=300, num_chains=2)
+        est = LR.estimator_callback() if low_rank else None
+        pos, st, _, failed = oracle.run(s, oracle.LOGP_MVN_PREC, dim, prec.reshape(-1), oracle.ref_cfg(), 2, x0, 400,
+                                        estimator=est)
+        assert failed == 0
+        steps[low_rank] = st["n_steps"][300:].mean()
+        if low_rank:
+            assert (st["num_eigenvalues"][st["transformation_update_id"] >= 0][-1:] >= 1).all()
+            assert np.abs(np.cov(pos[300:].reshape(-1, dim).T) - sigma).max() < 0.6 * np.abs(sigma).max()
+    assert steps[True] < 0.8 * steps[False], steps
