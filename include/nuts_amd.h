@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 5
+#define NM_ABI_VERSION 6
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -98,7 +98,20 @@ typedef struct nm_settings {
     double   adam_beta2;                     /* 0.999 */
     double   adam_epsilon;                   /* 1e-8 */
     double   adam_learning_rate;             /* 0.05 */
+    /* which MassMatrixAdaptStrategy drives the transformation: `DiagNutsSettings` or `LowRankNutsSettings`
+     * (reference src/sampler.rs:243-245, :651: GlobalStrategy<M, DiagAdaptStrategy<M>> / <M, LowRankMassMatrixStrategy>) */
+    uint64_t adaptation;                     /* NM_ADAPT_DIAG */
+    /* adapt_options.mass_matrix_options: LowRankSettings (src/transform/low_rank.rs:188-203); store_mass_matrix above is shared */
+    double   lr_gamma;                       /* 1e-5 */
+    double   lr_eigval_cutoff;               /* 2.0 */
+    /* engine knob, not a reference setting: the transformation is the one given by nm_engine_set_transform and the
+     * mass-matrix estimator steps of GlobalStrategy::adapt (update_estimators / switch / adapt) are skipped; the
+     * step-size schedule runs as usual */
+    uint64_t freeze_transform;               /* 0 */
 } nm_settings;
+
+#define NM_ADAPT_DIAG 0
+#define NM_ADAPT_LOW_RANK 1   /* reference src/transform/low_rank.rs, src/transform/adapt/low_rank.rs */
 
 #define NM_STEP_DUAL_AVERAGE 0
 #define NM_STEP_ADAM 1      /* reference src/stepsize/adam.rs:42-112 */
@@ -106,6 +119,8 @@ typedef struct nm_settings {
 
 /* Fill `s` with `DiagNutsSettings::default()` (reference src/sampler.rs:630-634). */
 void nm_settings_default(nm_settings* s);
+/* Fill `s` with `LowRankNutsSettings::default()` (reference src/sampler.rs:636-642: num_tune 800, mass_matrix_update_freq 20). */
+void nm_settings_default_low_rank(nm_settings* s);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-density registry.  The reference takes an arbitrary `CpuLogpFunc::logp(&[f64], &mut [f64])
@@ -186,6 +201,8 @@ typedef struct nm_draw_stats {
     int64_t  transformation_update_id; /* DiagMassMatrixStats.transformation_update_id (src/transform/diagonal.rs:32-71):
                                       the mass-matrix version if it differs from the one seen at the previous draw's
                                       statistics (first draw: compared with -1, src/sampler.rs:795), else -1 (= None) */
+    uint64_t num_eigenvalues;      /* MatrixStats.num_eigenvalues (src/transform/low_rank.rs:205-229) on the draws where
+                                      transformation_update_id >= 0 (0 while the transformation has no low-rank part), else 0 */
 } nm_draw_stats;
 /* Notes on reference naming.  `NutsStats.draw` (src/chain.rs:215-232) is read AFTER `draw_count += 1`
  * (src/chain.rs:184, :195) and therefore equals nm_draw_stats.draw + 1; `divergence_draw` likewise.
@@ -214,7 +231,10 @@ typedef struct nm_draw_outputs {
     double*        d_divergence_start;        /* DivergenceInfo.start_location (position the divergent leapfrog started from) */
     double*        d_divergence_start_gradient;
     double*        d_divergence_end;          /* DivergenceInfo.end_location */
-    uint64_t       reserved[6];
+    double*        d_mass_matrix_eigvals;     /* MatrixStats.mass_matrix_eigvals (low_rank.rs:232-243): lambda^(1/2) of the low-rank
+                                                 part, NaN beyond num_eigenvalues; event row (NM_ADAPT_LOW_RANK only;
+                                                 d_mass_matrix_inv then carries MatrixStats.mass_matrix_stds) */
+    uint64_t       reserved[5];
 } nm_draw_outputs;
 
 typedef struct nm_engine nm_engine;
@@ -228,7 +248,9 @@ typedef struct nm_engine_config {
     uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
     uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
                                     * 0 = auto (when there are more chains than resident wavefronts, ~2048), 1 = never, 2 = whenever the kernel applies */
-    uint64_t reserved[2];
+    uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
+                                    * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return */
+    uint64_t reserved[1];
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 
@@ -275,6 +297,42 @@ nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_posit
  * rows that were not written read as NaN. */
 nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* h_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * The low-rank transformation (NM_ADAPT_LOW_RANK; reference `LowRankMassMatrix`, src/transform/low_rank.rs:95-186):
+ *     F(y) = sigma . (I + U (diag(lambda)^1/2 - I) U') (y + mu_lr) + mean
+ * applied inside the fused leapfrog (x' = F(z'), g_z' = J_F' g_x'; src/transform/low_rank.rs:325-398,
+ * src/math/cpu_math.rs:332-425).  Its adaptation (`LowRankMassMatrixStrategy`, src/transform/adapt/low_rank.rs) keeps
+ * the window of draws / gradients on the device; the dense linear algebra of `compute_update` (thin SVDs, pivoted
+ * QR, three symmetric eigendecompositions — faer in the reference) runs on the host between kernel launches: a chain
+ * whose schedule asks for a new matrix pauses, the host estimates it from the chain's window and uploads it, the
+ * next launch resumes the chain at the same point of GlobalStrategy::adapt.  nm_engine_draw* do all of that.
+ * ------------------------------------------------------------------------------------------- */
+/* The estimator: draws / grads are [n_draws][dim] (oldest first); outputs: stds[dim], mean[dim], *n_eig <= min(dim, 2 n_draws),
+ * vals[*n_eig], vecs[*n_eig][dim] (one eigenvector per row), mu_low_rank[dim].  Returns 0 (Some) or 1 (None: no update).
+ * Called from several host threads at once (one chain each).  The default is the built-in C++ restatement of
+ * compute_update (nuts_rs_amd/csrc/lowrank_host.cpp). */
+typedef int (*nm_lowrank_estimator_fn)(void* ctx, uint64_t dim, uint64_t n_draws, const double* draws, const double* grads,
+                                       double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
+                                       double* vals, double* vecs, double* mu_low_rank);
+nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_estimator_fn fn, void* ctx, uint64_t n_threads /* 0 = all cores */);
+/* The built-in estimator itself (host only, no device needed): for tests and for callers that adapt elsewhere. */
+int nm_lowrank_compute_update(void* unused, uint64_t dim, uint64_t n_draws, const double* draws, const double* grads,
+                              double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
+                              double* vals, double* vecs, double* mu_low_rank);
+
+/* `LowRankMassMatrix::update(stds, mean, vals, vecs, mean_low_rank)` (src/transform/low_rank.rs:155-186) for every chain,
+ * from the host: the transformation version moves on and the current points are re-whitened lazily at their next
+ * trajectory (src/dynamics/transformed_hamiltonian.rs:706-720).  per_chain = 0: one transformation for all chains
+ * (h_stds[dim], h_mean[dim], h_vals[n_eig], h_vecs[n_eig][dim], h_mu_low_rank[dim]); 1: every array has a leading
+ * [n_chains] axis.  Chains whose input is not finite keep their transformation (the reference returns early).
+ * Needs settings.adaptation == NM_ADAPT_LOW_RANK; with settings.freeze_transform the schedule never replaces it. */
+nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, uint64_t n_eig, const double* h_stds, const double* h_mean,
+                                  const double* h_vals, const double* h_vecs, const double* h_mu_low_rank);
+/* Current low-rank part per chain: h_n_eig[n_chains]; optional h_vals [n_chains][max_rank] (lambda^(1/2)),
+ * h_vecs [n_chains][max_rank][dim], h_mu_low_rank [n_chains][dim]. */
+nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_sqrt, double* h_vecs, double* h_mu_low_rank);
+uint64_t  nm_engine_lowrank_max_rank(const nm_engine* e);
+
 /* Current per-chain quantities, host copies ([n_chains][dim] unless noted). */
 nm_status nm_engine_get_positions(nm_engine* e, double* h_x);
 nm_status nm_engine_get_gradients(nm_engine* e, double* h_gx);
@@ -315,6 +373,14 @@ nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uint64_t dims_
                             double* d_x_out, double* d_gx_out,
                             double* d_logp_out, double* d_kinetic_out, double* d_energy_error_out,
                             void* stream);
+
+/* The three maps of the low-rank transformation for n independent chains (unit parity of low_rank.rs:325-398):
+ * which 0 compute_transformed_position (x -> z), 1 compute_untransformed_position (z -> x), 2 compute_transformed_gradient
+ * (g_x -> g_z).  d_stds, d_mean, d_mu_low_rank, d_in, d_out: [n][dim]; d_vals [n][n_eig] (the RAW eigenvalues lambda),
+ * d_vecs [n][n_eig][dim]. */
+nm_status nm_lowrank_transform_batch(uint64_t which, uint64_t n, uint64_t dim, uint64_t n_eig, uint64_t dims_per_lane,
+                                     const double* d_stds, const double* d_mean, const double* d_vals, const double* d_vecs,
+                                     const double* d_mu_low_rank, const double* d_in, double* d_out, void* stream);
 
 /* U-turn criterion `is_turning` (reference transformed_hamiltonian.rs:617-638 via scalar_prods3,
  * src/math/util.rs:221-347) for n pairs: out_t[2*i] = (z_end - z_start).v_start, out_t[2*i+1] = (..).v_end. */

@@ -25,7 +25,9 @@ ABI_SYMBOLS = [
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
-    "nm_pick_tiling", "nm_probe_bandwidth",
+    "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_engine_set_lowrank_estimator",
+    "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
+    "nm_lowrank_transform_batch",
 ]
 
 
@@ -47,6 +49,8 @@ class NmSettings(C.Structure):
         ("da_k", C.c_double), ("da_t0", C.c_double), ("da_gamma", C.c_double), ("da_max_step_size", C.c_double),
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
         ("adam_learning_rate", C.c_double),
+        ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
+        ("freeze_transform", C.c_uint64),
     ]
 
 
@@ -58,7 +62,7 @@ class NmLogpSpec(C.Structure):
 class NmEngineConfig(C.Structure):
     _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
                 ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("lane_groups", C.c_uint64),
-                ("reserved", C.c_uint64 * 2)]
+                ("lowrank_max_rank", C.c_uint64), ("reserved", C.c_uint64 * 1)]
 
 
 STATS_DTYPE = np.dtype([
@@ -67,17 +71,23 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
-    ("transformation_update_id", "<i8"),
+    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"),
 ])
 
 # nm_draw_outputs: the draws, the scalar statistics and the vector-valued statistics (reference stat names)
 VECTOR_STATS = ("gradient", "transformed_position", "transformed_gradient", "mass_matrix_inv", "transformation_mu",
-                "divergence_start", "divergence_start_gradient", "divergence_end")
+                "divergence_start", "divergence_start_gradient", "divergence_end", "mass_matrix_eigvals")
 
 
 class NmDrawOutputs(C.Structure):
     _fields_ = ([("d_positions", C.c_void_p), ("d_stats", C.c_void_p)] + [("d_" + k, C.c_void_p) for k in VECTOR_STATS]
-                + [("reserved", C.c_uint64 * 6)])
+                + [("reserved", C.c_uint64 * 5)])
+
+
+# nm_lowrank_estimator_fn
+LOWRANK_ESTIMATOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 _lib = None
 
@@ -140,6 +150,15 @@ def load():
     L.nm_standard_normal_batch.argtypes = [u64, u64, vp, vp, vp, vp]
     L.nm_chain_rng_key.argtypes = [u64, u64, vp]
     L.nm_pick_tiling.argtypes = [u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.nm_settings_default_low_rank.argtypes = [C.POINTER(NmSettings)]
+    L.nm_settings_default_low_rank.restype = None
+    L.nm_engine_set_lowrank_estimator.argtypes = [vp, vp, vp, u64]
+    L.nm_lowrank_compute_update.argtypes = [vp, u64, u64, vp, vp, dbl, dbl, vp, vp, C.POINTER(u64), vp, vp, vp]
+    L.nm_engine_set_transform.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]
+    L.nm_engine_get_lowrank.argtypes = [vp, vp, vp, vp, vp]
+    L.nm_engine_lowrank_max_rank.argtypes = [vp]
+    L.nm_engine_lowrank_max_rank.restype = u64
+    L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_last_error.restype = C.c_char_p
     L.nm_abi_version.restype = u64

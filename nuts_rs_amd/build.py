@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnuts_amd.so")
 UNITS = ["nuts_engine.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_eight_schools.hip",
-         "kern_mvn_prec.hip", "probe_bw.hip"]
+         "kern_mvn_prec.hip", "probe_bw.hip", "lowrank_host.cpp",
+         "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_eight_schools.hip", "kern_lr_mvn_prec.hip"]
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
@@ -40,7 +41,7 @@ def build(force=False, verbose=False, extra_flags=()):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
     def compile_unit(u):
-        src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o"))
+        src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o").replace(".cpp", ".o"))
         if force or _newer(obj, [src] + hdrs):
             cmd = [hipcc] + FLAGS + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
             if verbose:

@@ -4,10 +4,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <dlfcn.h>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nuts_launch.hpp"
@@ -143,6 +146,11 @@ extern "C" void nm_settings_default(nm_settings* s) {
     s->step_size_method = NM_STEP_DUAL_AVERAGE; s->fixed_step_size = 0.0;
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;
+    s->adaptation = NM_ADAPT_DIAG; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;
+}
+extern "C" void nm_settings_default_low_rank(nm_settings* s) {     // LowRankNutsSettings::default (src/sampler.rs:636-642)
+    nm_settings_default(s);
+    s->num_tune = 800; s->mass_matrix_update_freq = 20; s->adaptation = NM_ADAPT_LOW_RANK;
 }
 extern "C" void nm_engine_config_default(nm_engine_config* c) {
     memset(c, 0, sizeof *c);
@@ -157,8 +165,18 @@ typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blo
 typedef void (*module_info_fn)(uint64_t out[5]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
-                         module_launch_fn module = nullptr) {
-    if (logp_kind == NM_LOGP_MODULE) return module ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
+                         module_launch_fn module = nullptr, bool lr = false) {
+    if (logp_kind == NM_LOGP_MODULE) return module && !lr ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
+    if (lr) {      // the kernels that carry the low-rank transformation (LrWrap<Density>, kern_lr_*.hip)
+        switch (logp_kind) {
+        case NM_LOGP_IID_NORMAL: return launch_iid_normal_lr(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_DIAG_NORMAL: return launch_diag_normal_lr(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_FUNNEL: return launch_funnel_lr(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools_lr(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_MVN_PREC: return launch_mvn_prec_lr(dpl, w, kind, P, grid, stream, occ);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (logp_kind) {
     case NM_LOGP_IID_NORMAL: return launch_iid_normal(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_DIAG_NORMAL: return launch_diag_normal(dpl, w, kind, P, grid, stream, occ);
@@ -254,8 +272,8 @@ struct nm_engine {
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
     double* d_x0 = nullptr;
-    void* staging[10] = {};                 // device staging of the *_to_host calls, one per output array, grow-only
-    size_t staging_bytes[10] = {};
+    void* staging[11] = {};                 // device staging of the *_to_host calls, one per output array, grow-only
+    size_t staging_bytes[11] = {};
     void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
     module_launch_fn module_launch = nullptr;
     int module_group_lanes = 0;             // lanes per chain of the module's group form (0: it has none)
@@ -267,6 +285,15 @@ struct nm_engine {
     uint64_t group_launches = 0;
     uint64_t draws_launched = 0;            // draw index of the healthy chain that is furthest behind (set_positions + launches)
     bool pending_timing = false;
+    // low-rank transformation (settings.adaptation == NM_ADAPT_LOW_RANK)
+    bool lr = false;
+    uint64_t lr_rmax = 0, lr_cap = 0;
+    double *d_lrvec = nullptr, *d_lrval = nullptr, *d_lrwin = nullptr;
+    nm_lowrank_estimator_fn lr_estimator = nm_lowrank_compute_update;
+    void* lr_estimator_ctx = nullptr;
+    uint64_t lr_threads = 0;
+    uint64_t lr_updates = 0, lr_rounds = 0;  // estimator calls / pause-resume rounds so far
+    double lr_host_seconds = 0.0;
 };
 
 static void engine_free(nm_engine* e) {
@@ -280,6 +307,9 @@ static void engine_free(nm_engine* e) {
     if (e->d_zig) (void)hipFree(e->d_zig);
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->d_x0) (void)hipFree(e->d_x0);
+    if (e->d_lrvec) (void)hipFree(e->d_lrvec);
+    if (e->d_lrval) (void)hipFree(e->d_lrval);
+    if (e->d_lrwin) (void)hipFree(e->d_lrwin);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -305,6 +335,10 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (!(early_end < s.num_tune)) return fail(NM_ERR_INVALID_ARG, "early_end < num_tune violated (reference asserts, adapt_strategy.rs:83)");
     if (!(s.mass_matrix_window_growth >= 1.0)) return fail(NM_ERR_INVALID_ARG, "mass_matrix_window_growth must be >= 1");
     if (s.has_jitter && !(1.0 - s.jitter < 1.0 + s.jitter)) return fail(NM_ERR_INVALID_ARG, "invalid jitter");
+    if (s.adaptation > NM_ADAPT_LOW_RANK) return fail(NM_ERR_INVALID_ARG, "adaptation %llu is not one of NM_ADAPT_*", (unsigned long long)s.adaptation);
+    const bool lr = s.adaptation == NM_ADAPT_LOW_RANK;
+    if (lr && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "NM_ADAPT_LOW_RANK with a density module: modules carry the diagonal kernels only");
+    if (lr && !(s.lr_gamma > 0.0) ) return fail(NM_ERR_INVALID_ARG, "lr_gamma must be > 0");
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
     int dpl = 0, wv = 0;
@@ -318,6 +352,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     nm_engine* e = new (std::nothrow) nm_engine();
     if (!e) return fail(NM_ERR_HIP, "out of host memory");
     e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl; e->wpc = wv;
+    e->lr = lr;
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;
     const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
@@ -345,7 +380,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         int occ = 0, cus = 0;
         KParams dummy;
         memset(&dummy, 0, sizeof dummy);
-        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch));
+        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch, lr));
         E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
         const uint64_t wave_slots = resident;                      // chains the wave-per-chain kernel runs at once
@@ -354,7 +389,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const int gs = grp::group_size(logp->dim);
         const bool group_density = logp->kind != NM_LOGP_MODULE || (gs && e->module_group_lanes == gs);   // every built-in density has a group form
-        if (cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
+        if (!lr && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
@@ -378,6 +413,20 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMalloc(&e->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
     if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    if (lr) {   // eigenvector slots, eigenvalue arrays and the window of draws / gradients of every chain
+        const uint64_t most = std::min<uint64_t>(logp->dim, 2 * (s.num_tune + 1));     // rank <= min(dim, 2 n_draws)
+        e->lr_rmax = cfg.lowrank_max_rank ? std::min<uint64_t>(cfg.lowrank_max_rank, logp->dim) : most;
+        if (e->lr_rmax == 0) e->lr_rmax = 1;
+        e->lr_cap = s.num_tune + 2;
+        const size_t vb = (size_t)n_chains * (1 + e->lr_rmax) * dpad * sizeof(double);
+        const size_t lb = (size_t)n_chains * 2 * e->lr_rmax * sizeof(double);
+        const size_t wb = (size_t)n_chains * e->lr_cap * 2 * logp->dim * sizeof(double);
+        E_TRY(hipMalloc(&e->d_lrvec, vb));
+        E_TRY(hipMemsetAsync(e->d_lrvec, 0, vb, e->stream));
+        E_TRY(hipMalloc(&e->d_lrval, lb));
+        E_TRY(hipMemsetAsync(e->d_lrval, 0, lb, e->stream));
+        E_TRY(hipMalloc(&e->d_lrwin, wb));
+    }
     {   // ziggurat tables of rand_distr's StandardNormal (Marsaglia & Tsang, 256 layers)
         std::vector<double> t(2 * 257);
         double* x = t.data();
@@ -422,6 +471,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         P.jitter_low = low; P.jitter_scale = scale;
     }
     P.x0 = e->d_x0;
+    P.lrvec = e->d_lrvec; P.lrval = e->d_lrval; P.lrwin = e->d_lrwin; P.lr_rmax = e->lr_rmax; P.lr_cap = e->lr_cap;
     E_TRY(hipStreamSynchronize(e->stream));
 #undef E_TRY
     *out = e;
@@ -444,7 +494,7 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     KParams P = e->P;
-    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->lr));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
@@ -464,6 +514,167 @@ extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, u
     return NM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// low-rank transformation: uploads and the estimator rounds between launches
+// ---------------------------------------------------------------------------------------------
+// One chain's LowRankMassMatrix::update input -> device (sigma, 1/sigma, mean into the chain's P slots; mu_lr and the
+// eigenvectors into lrvec; lambda^(+-1/2) into lrval) and the scalars the kernel commits it with.  Returns false (and
+// leaves the device untouched) when the reference's update() would return early on non-finite input.
+static bool lr_stage_update(nm_engine* e, uint64_t c, ChainScalars& q, uint64_t n_eig, const double* stds, const double* mean,
+                            const double* vals, const double* vecs /*[n_eig][dim]*/, const double* mu_lr, hipError_t* err) {
+    const uint64_t dim = e->dim, dpad = e->P.dpad;
+    auto finite = [](const double* a, uint64_t n) { for (uint64_t i = 0; i < n; ++i) if (!std::isfinite(a[i])) return false; return true; };
+    *err = hipSuccess;
+    q.lr_upd_ok = 0; q.lr_upd_rank = 0; q.lr_upd_logdet = 0.0;
+    if (!finite(stds, dim) || !finite(mean, dim) || !finite(vals, n_eig) || !finite(vecs, n_eig * dim)) return false;
+    std::vector<double> isig(dim), vs(n_eig ? n_eig : 1), vi(n_eig ? n_eig : 1);
+    for (uint64_t i = 0; i < dim; ++i) isig[i] = 1.0 / stds[i];                       // array_recip (diagonal.rs:158)
+    double ld = -0.0;                                                                  // InnerMatrix::new (low_rank.rs:55-92)
+    for (uint64_t k = 0; k < n_eig; ++k) { ld += -0.5 * dlog(vals[k]); vs[k] = std::sqrt(vals[k]); vi[k] = 1.0 / vs[k]; }
+    double* pv = e->d_pvec + (size_t)c * NUM_PSLOT * dpad;
+    double* lv = e->d_lrvec + (size_t)c * (1 + e->lr_rmax) * dpad;
+    double* lw = e->d_lrval + (size_t)c * 2 * e->lr_rmax;
+    hipError_t er = hipMemcpy(pv + (size_t)P_SIG * dpad, stds, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(pv + (size_t)P_ISIG * dpad, isig.data(), dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(pv + (size_t)P_MU * dpad, mean, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = hipMemcpy(lv, mu_lr, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = hipMemcpy2D(lv + dpad, dpad * 8, vecs, dim * 8, dim * 8, n_eig, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = hipMemcpy(lw, vs.data(), n_eig * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = hipMemcpy(lw + e->lr_rmax, vi.data(), n_eig * 8, hipMemcpyHostToDevice);
+    *err = er;
+    if (er != hipSuccess) return false;
+    q.lr_upd_ok = 1; q.lr_upd_rank = n_eig; q.lr_upd_logdet = ld;
+    return true;
+}
+
+extern "C" nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_estimator_fn fn, void* ctx, uint64_t n_threads) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (!e->lr) return fail(NM_ERR_STATE, "the engine was not created with adaptation = NM_ADAPT_LOW_RANK");
+    e->lr_estimator = fn ? fn : nm_lowrank_compute_update;
+    e->lr_estimator_ctx = fn ? ctx : nullptr;
+    e->lr_threads = n_threads;
+    return NM_OK;
+}
+extern "C" uint64_t nm_engine_lowrank_max_rank(const nm_engine* e) { return e ? e->lr_rmax : 0; }
+
+extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, uint64_t n_eig, const double* h_stds, const double* h_mean,
+                                             const double* h_vals, const double* h_vecs, const double* h_mu_lr) {
+    if (!e || !h_stds || !h_mean || !h_mu_lr || (n_eig && (!h_vals || !h_vecs))) return fail(NM_ERR_INVALID_ARG, "null argument");
+    if (!e->lr) return fail(NM_ERR_STATE, "nm_engine_set_transform needs settings.adaptation == NM_ADAPT_LOW_RANK");
+    if (!e->positioned) return fail(NM_ERR_STATE, "nm_engine_set_transform before nm_engine_set_positions");
+    if (n_eig > e->lr_rmax) return fail(NM_ERR_UNSUPPORTED, "%llu eigenvectors > lowrank_max_rank %llu", (unsigned long long)n_eig, (unsigned long long)e->lr_rmax);
+    HIP_TRY(hipSetDevice(e->device));
+    nm_status st = nm_engine_synchronize(e);
+    if (st != NM_OK) return st;
+    std::vector<ChainScalars> sc(e->n_chains);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    const uint64_t dim = e->dim;
+    for (uint64_t c = 0; c < e->n_chains; ++c) {
+        if (sc[c].lr_pending != LR_IDLE && sc[c].lr_pending != LR_SET_TRANSFORM) return fail(NM_ERR_STATE, "chain %llu is waiting for its estimator", (unsigned long long)c);
+        const uint64_t k = per_chain ? c : 0;
+        hipError_t er;
+        (void)lr_stage_update(e, c, sc[c], n_eig, h_stds + k * dim, h_mean + k * dim, h_vals ? h_vals + k * n_eig : nullptr,
+                              h_vecs ? h_vecs + k * n_eig * dim : nullptr, h_mu_lr + k * dim, &er);
+        if (er != hipSuccess) return fail(NM_ERR_HIP, "upload of the transformation: %s", hipGetErrorString(er));
+        sc[c].lr_pending = LR_SET_TRANSFORM;            // committed by the next launch (LowRankMassMatrix::update)
+    }
+    HIP_TRY(hipMemcpy(e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    return NM_OK;
+}
+
+extern "C" nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_sqrt, double* h_vecs, double* h_mu_lr) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (!e->lr) return fail(NM_ERR_STATE, "the engine was not created with adaptation = NM_ADAPT_LOW_RANK");
+    nm_status st = nm_engine_synchronize(e);
+    if (st != NM_OK) return st;
+    std::vector<ChainScalars> sc(e->n_chains);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    const uint64_t dim = e->dim, dpad = e->P.dpad, R = e->lr_rmax;
+    for (uint64_t c = 0; c < e->n_chains; ++c) {
+        if (h_n_eig) h_n_eig[c] = sc[c].lr_has_inner ? sc[c].lr_rank : 0;
+        const double* lv = e->d_lrvec + (size_t)c * (1 + R) * dpad;
+        if (h_mu_lr) HIP_TRY(hipMemcpy(h_mu_lr + c * dim, lv, dim * 8, hipMemcpyDeviceToHost));
+        if (h_vecs) HIP_TRY(hipMemcpy2D(h_vecs + c * R * dim, dim * 8, lv + dpad, dpad * 8, dim * 8, R, hipMemcpyDeviceToHost));
+        if (h_vals_sqrt) HIP_TRY(hipMemcpy(h_vals_sqrt + c * R, e->d_lrval + (size_t)c * 2 * R, R * 8, hipMemcpyDeviceToHost));
+    }
+    return NM_OK;
+}
+
+// The draw loop of an NM_ADAPT_LOW_RANK engine: launch; chains whose schedule asks for a new matrix pause inside
+// GlobalStrategy::adapt; their windows go through the estimator on host threads; the answers are uploaded; relaunch.
+static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
+    KParams P = P_in;
+    P.row_base = e->draws_launched;
+    P.draw_end = e->draws_launched + n_draws;
+    const uint64_t dim = e->dim, nc = e->n_chains;
+    std::vector<ChainScalars> sc(nc);
+    for (;;) {
+        HIP_TRY(hipEventRecord(e->ev0, e->stream));
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch, true));
+        HIP_TRY(hipEventRecord(e->ev1, e->stream));
+        e->pending_timing = true;
+        e->kernel_launches += 1;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        nm_status st = collect_timing(e);
+        if (st != NM_OK) return st;
+        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        std::vector<uint64_t> pend;
+        for (uint64_t c = 0; c < nc; ++c)
+            if (sc[c].status == NM_CHAIN_OK && sc[c].lr_pending == LR_WAIT_HOST) pend.push_back(c);
+        if (pend.empty()) break;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned nt = (unsigned)(e->lr_threads ? e->lr_threads : std::thread::hardware_concurrency());
+        if (nt == 0) nt = 1;
+        if (nt > pend.size()) nt = (unsigned)pend.size();
+        std::atomic<size_t> next{0};
+        std::atomic<int> hip_failed{0};
+        auto work = [&]() {
+            (void)hipSetDevice(e->device);
+            std::vector<double> win, draws, grads, stds(dim), mean(dim), mu(dim), vals, vecs;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= pend.size()) break;
+                const uint64_t c = pend[i];
+                ChainScalars& q = sc[c];
+                const uint64_t n = q.lr_len;
+                win.resize(n * 2 * dim); draws.resize(n * dim); grads.resize(n * dim);
+                if (hipMemcpy(win.data(), e->d_lrwin + ((size_t)c * e->lr_cap + q.lr_start) * 2 * dim, n * 2 * dim * 8,
+                              hipMemcpyDeviceToHost) != hipSuccess) { hip_failed++; continue; }
+                for (uint64_t r = 0; r < n; ++r) {
+                    memcpy(&draws[r * dim], &win[(2 * r) * dim], dim * 8);
+                    memcpy(&grads[r * dim], &win[(2 * r + 1) * dim], dim * 8);
+                }
+                const uint64_t most = std::min<uint64_t>(dim, 2 * n);
+                vals.assign(most, 0.0); vecs.assign(most * dim, 0.0);
+                uint64_t n_eig = 0;
+                const int rc = e->lr_estimator(e->lr_estimator_ctx, dim, n, draws.data(), grads.data(), e->s.lr_gamma,
+                                               e->s.lr_eigval_cutoff, stds.data(), mean.data(), &n_eig, vals.data(), vecs.data(), mu.data());
+                q.lr_upd_ok = 0; q.lr_upd_rank = 0; q.lr_upd_logdet = 0.0;
+                if (rc == 0) {
+                    if (n_eig > e->lr_rmax) { hip_failed += 1000; continue; }
+                    hipError_t er;
+                    (void)lr_stage_update(e, c, q, n_eig, stds.data(), mean.data(), vals.data(), vecs.data(), mu.data(), &er);
+                    if (er != hipSuccess) { hip_failed++; continue; }
+                }
+                q.lr_pending = LR_ANSWERED;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t + 1 < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        e->lr_updates += pend.size();
+        e->lr_rounds += 1;
+        e->lr_host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (hip_failed.load() >= 1000) return fail(NM_ERR_UNSUPPORTED, "the estimator returned more eigenvectors than lowrank_max_rank %llu", (unsigned long long)e->lr_rmax);
+        if (hip_failed.load()) return fail(NM_ERR_HIP, "window download / transformation upload failed for %d chain(s)", hip_failed.load());
+        HIP_TRY(hipMemcpy(e->d_sc, sc.data(), nc * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    }
+    e->draws_total += n_draws;
+    e->draws_launched += n_draws;
+    return NM_OK;
+}
+
 extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* out) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
     if (!out) return fail(NM_ERR_INVALID_ARG, "null nm_draw_outputs");
@@ -479,6 +690,8 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_mm_inv = out->d_mass_matrix_inv; P.out_mm_mu = out->d_transformation_mu;
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
+    P.out_mm_eigvals = out->d_mass_matrix_eigvals;
+    if (e->lr) return lr_draw(e, n_draws, P);           // synchronous: the estimator rounds need the host between launches
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     // small chains, many of them: the several-chains-per-wavefront kernels compute the same draws and statistics
     if (e->group_grid) {
@@ -536,6 +749,7 @@ extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, c
         {h_out->d_divergence_start, (void**)&d.d_divergence_start, vec_bytes, true},
         {h_out->d_divergence_start_gradient, (void**)&d.d_divergence_start_gradient, vec_bytes, true},
         {h_out->d_divergence_end, (void**)&d.d_divergence_end, vec_bytes, true},
+        {h_out->d_mass_matrix_eigvals, (void**)&d.d_mass_matrix_eigvals, vec_bytes, true},
     };
     nm_status st = NM_OK;
     int idx = 0;
@@ -695,6 +909,59 @@ __global__ __launch_bounds__(64) void leapfrog_batch_kernel(const LfArgs A) {
         A.err_out[i] = (s.ke - (s.logp + A.logdet[i])) - A.e0[i];
     }
 }
+// the three maps of the low-rank transformation for chain i of a batch (nm_lowrank_transform_batch): the block first
+// packs its chain's unpadded inputs into the engine's layouts (pvec slots, lrvec rows, lrval), then applies the map
+struct LrtArgs {
+    KParams P;
+    uint64_t which, n_eig;
+    const double *stds, *mean, *vals, *vecs, *mu_lr, *in;
+    double* out;
+};
+template <int DPL>
+__global__ __launch_bounds__(64) void lowrank_transform_batch_kernel(const LrtArgs A) {
+    dm_init_lds();
+    typedef LrWrap<IidNormal> D;
+    const uint64_t i = blockIdx.x;
+    const int dim = (int)A.P.dim;
+    __shared__ double lsig[64 * DPL], lmu[64 * DPL], lred[2 * RED_MAX_VALUES];
+    __shared__ ChainScalars lsc;
+    ChainCtx<DPL, 1, D> C(A.P, lsc);
+    C.dim = dim;
+    C.red.init(lred);
+    C.lsig = lsig; C.lmu = lmu;
+    C.slot_bytes = (int)(A.P.dpad * 8);
+    C.voff = tid() * 16;
+    C.pv = A.P.pvec + (size_t)i * NUM_PSLOT * A.P.dpad;
+    C.rp = make_rsrc(C.pv, (uint64_t)NUM_PSLOT * A.P.dpad * 8);
+    double* lv = A.P.lrvec + (size_t)i * (1 + A.P.lr_rmax) * A.P.dpad;
+    double* lw = A.P.lrval + (size_t)i * 2 * A.P.lr_rmax;
+    C.rl = make_rsrc(lv, (uint64_t)(1 + A.P.lr_rmax) * A.P.dpad * 8);
+    C.lvals = lw;
+    Tile<DPL> t, u;
+    load_row(t, A.stds + i * dim, dim); C.store(t, C.lsig);
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) u.a[k] = elem_index<1>(k) < dim ? 1.0 / t.a[k] : 0.0;
+    C.storeP(u, P_ISIG);
+    load_row(t, A.mean + i * dim, dim); C.store(t, C.lmu);
+    load_row(t, A.mu_lr + i * dim, dim); C.store(t, lv);
+    for (uint64_t k = 0; k < A.n_eig; ++k) {
+        load_row(t, A.vecs + (i * A.n_eig + k) * dim, dim);
+        C.store(t, lv + (1 + k) * A.P.dpad);
+    }
+    for (uint64_t k = tid(); k < A.n_eig; k += 64) {
+        const double sq = __builtin_sqrt(A.vals[i * A.n_eig + k]);
+        lw[k] = sq; lw[A.P.lr_rmax + k] = 1.0 / sq;
+    }
+    if (tid() == 0) { lsc.lr_has_inner = 1; lsc.lr_rank = A.n_eig; }
+    __threadfence_block();
+    __syncthreads();
+    load_row(t, A.in + i * dim, dim);
+    if (A.which == 0) transform_to_z(C, t, u);
+    else if (A.which == 1) transform_to_x(C, t, u);
+    else transform_to_gz(C, t, u);
+    store_row(u, A.out + i * dim, dim);
+}
+
 template <int DPL>
 __global__ __launch_bounds__(64) void turning_batch_kernel(uint64_t dim, const double* zs, const double* vs,
                                                            const double* ze, const double* ve, double* out) {
@@ -794,6 +1061,44 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
     if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d_params);
     if (er != hipSuccess) return fail(NM_ERR_HIP, "leapfrog_batch: %s", hipGetErrorString(er));
+    return NM_OK;
+}
+
+extern "C" nm_status nm_lowrank_transform_batch(uint64_t which, uint64_t n, uint64_t dim, uint64_t n_eig, uint64_t dims_per_lane,
+                                                const double* d_stds, const double* d_mean, const double* d_vals, const double* d_vecs,
+                                                const double* d_mu_lr, const double* d_in, double* d_out, void* stream) {
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    if (which > 2) return fail(NM_ERR_INVALID_ARG, "which must be 0 (x -> z), 1 (z -> x) or 2 (g_x -> g_z)");
+    const int dpl = pick_dpl(dim, dims_per_lane);
+    if (!dpl) return fail(NM_ERR_UNSUPPORTED, "unsupported dim / dims_per_lane (one wavefront per chain: dim <= 1024)");
+    if (n == 0) return NM_OK;
+    LrtArgs A;
+    memset(&A, 0, sizeof A);
+    const uint64_t dpad = 64ull * dpl, R = n_eig ? n_eig : 1;
+    double *pv = nullptr, *lv = nullptr, *lw = nullptr;
+    HIP_TRY(hipMalloc(&pv, n * NUM_PSLOT * dpad * 8));
+    HIP_TRY(hipMalloc(&lv, n * (1 + R) * dpad * 8));
+    HIP_TRY(hipMalloc(&lw, n * 2 * R * 8));
+    A.P.dim = dim; A.P.dpad = dpad; A.P.n_chains = n; A.P.pvec = pv; A.P.lrvec = lv; A.P.lrval = lw; A.P.lr_rmax = R;
+    A.which = which; A.n_eig = n_eig; A.stds = d_stds; A.mean = d_mean; A.vals = d_vals; A.vecs = d_vecs; A.mu_lr = d_mu_lr;
+    A.in = d_in; A.out = d_out;
+    dim3 g((unsigned)n), b(64);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t er = hipMemsetAsync(pv, 0, n * NUM_PSLOT * dpad * 8, s);
+    if (er == hipSuccess) er = hipMemsetAsync(lv, 0, n * (1 + R) * dpad * 8, s);
+    if (er == hipSuccess) {
+        switch (dpl) {
+        case 2: hipLaunchKernelGGL((lowrank_transform_batch_kernel<2>), g, b, 0, s, A); break;
+        case 4: hipLaunchKernelGGL((lowrank_transform_batch_kernel<4>), g, b, 0, s, A); break;
+        case 8: hipLaunchKernelGGL((lowrank_transform_batch_kernel<8>), g, b, 0, s, A); break;
+        case 16: hipLaunchKernelGGL((lowrank_transform_batch_kernel<16>), g, b, 0, s, A); break;
+        }
+        er = hipGetLastError();
+    }
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    (void)hipFree(pv); (void)hipFree(lv); (void)hipFree(lw);
+    if (er != hipSuccess) return fail(NM_ERR_HIP, "lowrank_transform_batch: %s", hipGetErrorString(er));
     return NM_OK;
 }
 

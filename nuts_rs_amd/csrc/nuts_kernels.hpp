@@ -94,7 +94,21 @@ struct ChainScalars {
     uint64_t total_steps;  // leapfrogs since creation (metric)
     uint64_t px_stale;     // 1: P_X / P_GX do not hold the current point (they equal what P_Z recomputes to)
     int64_t stats_last_id; // mass-matrix id at the previous statistics extraction (chain.rs:195-200), starts at -1
+    // ---- low-rank transformation and its adaptation (NM_ADAPT_LOW_RANK; LrWrap kernels only)
+    uint64_t lr_has_inner;        // LowRankMassMatrix.inner.is_some() (low_rank.rs:112)
+    uint64_t lr_rank;             // InnerMatrix.num_eigenvalues
+    // LowRankMassMatrixStrategy (adapt/low_rank.rs:14-21): the deque is rows [lr_start, lr_start + lr_len) of the chain's
+    // window buffer; lr_split = background_split
+    uint64_t lr_start, lr_len, lr_split;
+    // hand-off with the host's estimator: 1 = GlobalStrategy::adapt paused at `mass_matrix_adapt.adapt(..)`, waiting;
+    // 2 = the host answered (lr_upd_*); 3 = a transformation from nm_engine_set_transform waits to be committed
+    uint64_t lr_pending;
+    uint64_t lr_upd_ok, lr_upd_rank;   // the answer: a finite update was uploaded (P_SIG / P_ISIG / P_MU, lrvec, lrval), its rank
+    double lr_upd_logdet;              // its -1/2 sum ln lambda (InnerMatrix::new, low_rank.rs:57)
+    uint64_t lr_is_late;               // is_late of the paused adapt call
+    uint64_t lr_row;                   // output row of the paused draw
 };
+enum { LR_IDLE = 0, LR_WAIT_HOST = 1, LR_ANSWERED = 2, LR_SET_TRANSFORM = 3 };
 
 struct KParams {
     nm_settings s;
@@ -118,6 +132,14 @@ struct KParams {
     uint64_t n_draws;
     unsigned long long* prof;    // NM_PROF builds: cycle counters of block 0 (tools/prof_phases.py)
     const double* x0;            // init kernel: [n_chains][dim]
+    // low-rank transformation (LrWrap kernels): per chain [1 + lr_rmax][dpad] (row 0 = mu_lr, row 1 + k = eigenvector k,
+    // tile layout like every chain vector), [2][lr_rmax] (lambda^1/2, lambda^-1/2), and the window [lr_cap][2][dim]
+    double* lrvec;
+    double* lrval;
+    double* lrwin;
+    uint64_t lr_rmax, lr_cap;
+    uint64_t draw_end, row_base;  // LrWrap draw kernel: chains draw until draw_count == draw_end; output row = draw_count - row_base
+    double* out_mm_eigvals;
 };
 
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
@@ -410,6 +432,13 @@ struct EightSchools {
     }
 };
 
+// A density wrapped in LrWrap selects the kernels that carry the low-rank transformation (LowRankMassMatrix, reference
+// src/transform/low_rank.rs) and its adaptation protocol; plain densities compile the diagonal-only code they always had.
+template <class D>
+struct LrWrap : D {};
+template <class D> struct lr_trait { static constexpr bool value = false; };
+template <class D> struct lr_trait<LrWrap<D>> { static constexpr bool value = true; };
+
 // ---------------------------------------------------------------------------------------------
 // Per-wave context: everything a chain keeps in registers / SGPRs while its kernel runs
 // ---------------------------------------------------------------------------------------------
@@ -459,6 +488,8 @@ struct ChainCtx {
 
     __device__ ChainCtx(const KParams& p, ChainScalars& lds_sc) : P(p), sc(lds_sc) {}
     rsrc_t rp, rs;      // buffer descriptors of this chain's persistent slots / this block's tree scratch
+    rsrc_t rl;          // LrWrap: this chain's low-rank vectors (mu_lr, eigenvectors)
+    const double* lvals;   // LrWrap: this chain's [2][lr_rmax] eigenvalue arrays
     int voff;           // tid * 16: byte offset of this thread's first pair inside a chain vector
     int slot_bytes;     // DP * 8
     NM_DEV double* slot(int s) const { return pv + (size_t)s * P.dpad; }
@@ -531,6 +562,10 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.voff = tid() * 16;
     C.rp = make_rsrc(C.pv, (uint64_t)NUM_PSLOT * P.dpad * 8);
     C.rs = make_rsrc(C.sv, (uint64_t)P.nsslot * P.dpad * 8);
+    if constexpr (lr_trait<Dens>::value) {
+        C.rl = make_rsrc(P.lrvec + (size_t)chain * (1 + P.lr_rmax) * P.dpad, (uint64_t)(1 + P.lr_rmax) * P.dpad * 8);
+        C.lvals = P.lrval + (size_t)chain * 2 * P.lr_rmax;
+    }
     C.lsig = sh.sig;
     C.l1z = NM_LDS_L1 ? sh.l1_z : C.sslot(slot_L(C.maxdepth_cfg, 1));
     C.l1v = NM_LDS_L1 ? sh.l1_v : C.sslot(slot_L(C.maxdepth_cfg, 1) + 1);
@@ -571,6 +606,114 @@ struct Pt {
     int64_t idx;
 };
 
+// apply_lowrank_transform_inplace (reference src/math/cpu_math.rs:383-425): v += U ((vals - 1) . (U' v)).
+// One pass over the eigenvectors: row k (a chain vector in tile layout, 16 B / lane loads) is dotted with the ORIGINAL v
+// (per-lane serial fma in register order, then the block reduction: the oracle's vector_dot order), scaled, and
+// accumulated into the result with one fma per element while it is still in registers — U is read once per call.
+// `which` = 0: lambda^1/2, 1: lambda^-1/2.
+template <int DPL, int W, class Dens>
+NM_DEV void lr_apply(ChainCtx<DPL, W, Dens>& C, int which, Tile<DPL>& v) {
+    const int r = (int)C.sc.lr_rank;
+    if (r == 0) return;
+    constexpr int NB = DPL >= 8 ? 2 : 4;          // eigenvectors in flight (register budget)
+    const double* vals = C.lvals + (size_t)which * C.P.lr_rmax;
+    Tile<DPL> out = v;
+    for (int k0 = 0; k0 < r; k0 += NB) {
+        double u[NB][DPL];
+        double p[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            p[j] = 0.0;
+            if (k0 + j < r) {
+                const int so = force_sgpr((1 + k0 + j) * C.slot_bytes);
+#pragma unroll
+                for (int m = 0; m < DPL / 2; ++m) {
+                    const double2 q = buf_load2(C.rl, C.voff + m * (64 * W * 16), so);
+                    u[j][2 * m] = q.x; u[j][2 * m + 1] = q.y;
+                }
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) p[j] = __builtin_fma(u[j][k], v.a[k], p[j]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) u[j][k] = 0.0;
+            }
+        }
+        C.red.sum_n(p);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (k0 + j < r) {
+                const double sc_ = p[j] * (vals[k0 + j] - 1.0);
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) out.a[k] = __builtin_fma(u[j][k], sc_, out.a[k]);
+            }
+        }
+    }
+    v = out;
+}
+template <int DPL, int W, class Dens>
+NM_DEV void lr_load_mu(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& mu_lr) {
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 q = buf_load2(C.rl, C.voff + m * (64 * W * 16), 0);
+        mu_lr.a[2 * m] = q.x; mu_lr.a[2 * m + 1] = q.y;
+    }
+}
+// compute_untransformed_position: x = F(z)  (diagonal.rs:248-257; low_rank.rs:349-375)
+template <int DPL, int W, class Dens>
+NM_DEV void transform_to_x(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& z, Tile<DPL>& x) {
+    Tile<DPL> t = z;
+    bool inner = false;
+    if constexpr (lr_trait<Dens>::value) inner = C.sc.lr_has_inner != 0;
+    if (inner) {
+        lr_apply(C, 0, t);
+        Tile<DPL> ml;
+        lr_load_mu(C, ml);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) t.a[k] = __builtin_fma(1.0, ml.a[k], t.a[k]);
+    }
+    const double2* sg2 = C.tptr(C.lsig);
+    const double2* mu2 = C.tptr(C.lmu);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64 * W], mm = mu2[m * 64 * W];
+        x.a[2 * m] = __builtin_fma(1.0, mm.x, t.a[2 * m] * sg.x);
+        x.a[2 * m + 1] = __builtin_fma(1.0, mm.y, t.a[2 * m + 1] * sg.y);
+    }
+}
+// compute_transformed_gradient: g_z = J_F' g_x  (diagonal.rs:258-265; low_rank.rs:377-393)
+template <int DPL, int W, class Dens>
+NM_DEV void transform_to_gz(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& gx, Tile<DPL>& gz) {
+    const double2* sg2 = C.tptr(C.lsig);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64 * W];
+        gz.a[2 * m] = gx.a[2 * m] * sg.x;
+        gz.a[2 * m + 1] = gx.a[2 * m + 1] * sg.y;
+    }
+    if constexpr (lr_trait<Dens>::value) { if (C.sc.lr_has_inner) lr_apply(C, 0, gz); }
+}
+// compute_transformed_position: z = F^-1(x)  (diagonal.rs:233-246; low_rank.rs:325-347)
+template <int DPL, int W, class Dens>
+NM_DEV void transform_to_z(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Tile<DPL>& z) {
+    Tile<DPL> isig, mu;
+    C.loadP(isig, P_ISIG);
+    C.load(mu, C.lmu);
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+        const double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
+        z.a[k] = isig.a[k] * t;
+    }
+    if constexpr (lr_trait<Dens>::value) {
+        if (C.sc.lr_has_inner) {
+            Tile<DPL> ml;
+            lr_load_mu(C, ml);
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) z.a[k] = __builtin_fma(-1.0, ml.a[k], z.a[k]);
+            lr_apply(C, 1, z);
+        }
+    }
+}
+
 // One leapfrog, registers to registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
 //   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
@@ -578,6 +721,29 @@ template <int DPL, int W, class Dens>
 NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     const double half = epsilon / 2.;
     Tile<DPL> x, gx;
+    if constexpr (lr_trait<Dens>::value) {
+        if (C.sc.lr_has_inner) {              // the same steps with F = the low-rank transformation (low_rank.rs:286-300)
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) {
+                const double vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                o.v.a[k] = vh;
+                o.z.a[k] = __builtin_fma(epsilon, vh, s.z.a[k]);
+            }
+            transform_to_x(C, o.z, x);
+            o.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+            transform_to_gz(C, gx, o.g);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) {
+                o.v.a[k] = __builtin_fma(half, o.g.a[k], o.v.a[k]);
+                acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
+            }
+            o.ke = 0.5 * C.red.sum(acc);
+            if (x_out) *x_out = x;
+            if (gx_out) *gx_out = gx;
+            return;
+        }
+    }
     const double2* sg2 = C.tptr(C.lsig);
     const double2* mu2 = C.tptr(C.lmu);
 #pragma unroll
@@ -749,6 +915,18 @@ NM_DEV double powi_rs(double a, int32_t b) {
 template <int DPL, int W, class Dens>
 NM_DEV bool init_state(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
     st.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+    if constexpr (lr_trait<Dens>::value) {
+        transform_to_z(C, x, st.z);
+        transform_to_gz(C, gx, st.g);
+        bool ok_lr = true;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const bool valid = C.elem(k) < C.dim;
+            ok_lr = ok_lr && (!valid || (is_finite(st.z.a[k]) && is_finite(st.g.a[k]) && st.g.a[k] != 0.0 &&
+                                         is_finite(gx.a[k]) && is_finite(x.a[k])));
+        }
+        return C.red.all(ok_lr);
+    }
     Tile<DPL> isig, sig, mu;
     C.loadP(isig, P_ISIG);
     C.load(sig, C.lsig);
@@ -894,6 +1072,7 @@ NM_DEV void mass_matrix_from_grad(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x,
         mu.a[k] = valid ? mean : 0.0;
     }
     commit_mass_matrix(C, sig, isig, mu);
+    if constexpr (lr_trait<Dens>::value) { C.sc.lr_has_inner = 0; C.sc.lr_rank = 0; }   // update_from_grad: inner = None (low_rank.rs:147)
 }
 
 // Strategy::adapt -> update_diag_draw_grad / update_diag_draw (reference adapt/diagonal.rs:161-196,
@@ -972,7 +1151,8 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
         C.loadP(fdm, E_DM); C.loadP(fdv, E_DV); C.loadP(fgm, E_GM); C.loadP(fgv, E_GV);
         C.loadP(bdm, B_DM); C.loadP(bdv, B_DV); C.loadP(bgm, B_GM); C.loadP(bgv, B_GV);
         bool dirty = false;
-        if (is_good) {                                           // update_estimators (adapt/diagonal.rs:134-141)
+        const bool frozen = s.freeze_transform != 0;            // engine knob: the transformation is given, no estimator
+        if (is_good && !frozen) {                                // update_estimators (adapt/diagonal.rs:134-141)
             sc.cnt_fg += 1;
             sc.cnt_bg += 1;
             running_variance_add_regs(fdm, fdv, sc.cnt_fg, x);
@@ -981,7 +1161,7 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
             running_variance_add_regs(bgm, bgv, sc.cnt_bg, gx);
             dirty = true;
         }
-        const bool could_switch = sc.cnt_bg >= switch_freq;
+        const bool could_switch = !frozen && sc.cnt_bg >= switch_freq;
         uint64_t next_window_size;
         if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
         else {
@@ -1008,7 +1188,7 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
             C.storeP(fdm, E_DM); C.storeP(fdv, E_DV); C.storeP(fgm, E_GM); C.storeP(fgv, E_GV);
         }
         bool did_change = false;
-        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
+        if (!frozen && (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq))) did_change = mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
         if (did_change) sc.last_update = draw;
         update_estimator(C, is_late);
         if (did_change & (sc.has_initial_mass_matrix != 0)) {
@@ -1021,6 +1201,104 @@ NM_DEV uint64_t adapt(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col, bool is_g
     update_estimator(C, true);
     update_stepsize(C, draw == s.num_tune - 1);
     return NM_CHAIN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GlobalStrategy<LowRankMassMatrixStrategy> (reference src/adapt_strategy.rs:121-222 over src/transform/adapt/low_rank.rs).
+// The schedule, the window bookkeeping and the step-size part run here; `mass_matrix_adapt.adapt()` itself — the dense
+// linear algebra of compute_update — is the host's: the chain pauses (LR_WAIT_HOST) and the next launch resumes it.
+// ---------------------------------------------------------------------------------------------
+template <int DPL, int W, class Dens>
+NM_DEV void lr_push(ChainCtx<DPL, W, Dens>& C, uint64_t chain, const Tile<DPL>& x, const Tile<DPL>& gx) {
+    const KParams& P = C.P;
+    const uint64_t idx = C.sc.lr_start + C.sc.lr_len;            // draws.push_back / grads.push_back (adapt/low_rank.rs:323-333)
+    if (idx < P.lr_cap) {
+        double* base = P.lrwin + ((size_t)chain * P.lr_cap + idx) * 2 * P.dim;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = C.elem(k);
+            if (d < C.dim) { base[d] = x.a[k]; base[P.dim + d] = gx.a[k]; }
+        }
+    }
+    C.sc.lr_len += 1;
+}
+// what follows `mass_matrix_adapt.adapt()` in GlobalStrategy::adapt (adapt_strategy.rs:190-213)
+template <int DPL, int W, class Dens>
+NM_DEV uint64_t adapt_tail(ChainCtx<DPL, W, Dens>& C, bool did_change, bool is_late, const Tile<DPL>& x) {
+    ChainScalars& sc = C.sc;
+    if (did_change) sc.last_update = sc.draw_count;
+    update_estimator(C, is_late);
+    if (did_change & (sc.has_initial_mass_matrix != 0)) {
+        sc.has_initial_mass_matrix = 0;
+        return stepsize_init(C, x);
+    }
+    update_stepsize(C, false);
+    return NM_CHAIN_OK;
+}
+template <int DPL, int W, class Dens>
+NM_DEV uint64_t adapt_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain, AcceptCollector& col, bool is_good,
+                         const Tile<DPL>& x, const Tile<DPL>& gx) {
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const uint64_t draw = sc.draw_count;
+    sc.last_mean_tree_accept = col.mean();
+    sc.last_sym_mean_tree_accept = col.mean_sym();
+    sc.last_n_steps = col.count;
+    sc.last_max_energy_error = col.max_energy_error;
+    if (draw >= s.num_tune) {
+        update_stepsize(C, true);
+        sc.tuning = 0;
+        return NM_CHAIN_OK;
+    }
+    if (draw < C.P.final_step_size_window) {
+        const bool frozen = s.freeze_transform != 0;
+        const bool is_early = draw < C.P.early_end;
+        const uint64_t bg0 = frozen ? 0 : sc.lr_len - sc.lr_split;          // background_count (adapt/low_rank.rs:343-345)
+        if (!is_early && draw == C.P.early_end) sc.current_window_size = sc.current_window_size > bg0 ? sc.current_window_size : bg0;
+        const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
+        if (is_good && !frozen) lr_push(C, chain, x, gx);                  // update_estimators
+        const bool could_switch = !frozen && (sc.lr_len - sc.lr_split) >= switch_freq;
+        uint64_t next_window_size;
+        if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
+        else {
+            double gv = (double)sc.current_window_size * s.mass_matrix_window_growth;
+            double fl = __builtin_floor(gv);
+            uint64_t grown = (uint64_t)((gv - fl >= 0.5) ? fl + 1.0 : fl);
+            next_window_size = sc.current_window_size + 1 > grown ? sc.current_window_size + 1 : grown;
+        }
+        const bool is_late = next_window_size + draw > C.P.final_step_size_window;
+        bool force_update = false;
+        if (could_switch && !is_late) {                                    // switch (adapt/low_rank.rs:335-342)
+            sc.lr_start += sc.lr_split;
+            sc.lr_len -= sc.lr_split;
+            sc.lr_split = sc.lr_len;
+            force_update = true;
+            if (!is_early) sc.current_window_size = next_window_size;
+        }
+        if (!frozen && (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) && sc.lr_len >= 3) {
+            sc.lr_pending = LR_WAIT_HOST;                                   // adapt() -> update(): the host's part
+            sc.lr_is_late = is_late ? 1 : 0;
+            return NM_CHAIN_OK;
+        }
+        return adapt_tail(C, false, is_late, x);
+    }
+    update_estimator(C, true);
+    update_stepsize(C, draw == s.num_tune - 1);
+    return NM_CHAIN_OK;
+}
+// LowRankMassMatrix::update (low_rank.rs:155-186) once the host has written sigma / 1/sigma / mean (P_SIG, P_ISIG, P_MU),
+// mu_lr and the eigenvectors (lrvec), lambda^(+-1/2) (lrval) and -1/2 sum ln lambda (lr_upd_logdet)
+template <int DPL, int W, class Dens>
+NM_DEV void lr_commit_update(ChainCtx<DPL, W, Dens>& C) {
+    Tile<DPL> t;
+    C.loadP(t, P_SIG); C.store(t, C.lsig);
+    C.loadP(t, P_MU); C.store(t, C.lmu);
+    C.loadP(t, P_ISIG);
+    const double diag_logdet = sum_ln_tile(C, t);                 // DiagMassMatrix::set_transform (diagonal.rs:155-161)
+    C.sc.mm_logdet = C.sc.lr_upd_logdet + diag_logdet;            // inner.logdet() + diag.logdet()
+    C.sc.mm_id += 1;
+    C.sc.lr_has_inner = 1;
+    C.sc.lr_rank = C.sc.lr_upd_rank;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1107,6 +1385,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         Tile<DPL> x, gx, isig, sig, mu;
         C.loadP(x, P_X);
         C.loadP(gx, P_GX);
+        if constexpr (lr_trait<Dens>::value) {                   // low_rank.rs:302-314
+            transform_to_z(C, x, E.z);
+            transform_to_gz(C, gx, E.g);
+        } else {
         C.loadP(isig, P_ISIG);
         C.load(sig, C.lsig);
         C.load(mu, C.lmu);
@@ -1115,6 +1397,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
             E.z.a[k] = isig.a[k] * t;
             E.g.a[k] = gx.a[k] * sig.a[k];
+        }
         }
         C.storeP(E.z, P_Z);
         C.storeP(E.g, P_GZ);
@@ -1480,15 +1763,21 @@ NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx
         C.loadP(x, P_X); C.loadP(gx, P_GX);
     } else {
         C.loadS(zt, slot_F(0));
+        if constexpr (lr_trait<Dens>::value) transform_to_x(C, zt, x);
+        else {
 #pragma unroll
         for (int k = 0; k < DPL; ++k) x.a[k] = __builtin_fma(1.0, mu.a[k], zt.a[k] * sig.a[k]);
+        }
         (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
     }
     write_row(C, P.out_div_start, row, x);
     write_row(C, P.out_div_start_grad, row, gx);
     C.loadS(zt, slot_F(0) + 1);
+    if constexpr (lr_trait<Dens>::value) transform_to_x(C, zt, x);
+    else {
 #pragma unroll
     for (int k = 0; k < DPL; ++k) x.a[k] = __builtin_fma(1.0, mu.a[k], zt.a[k] * sig.a[k]);
+    }
     write_row(C, P.out_div_end, row, x);
 }
 
@@ -1573,6 +1862,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     out.chain_status = ast;
     // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70): an event when the version moved since the last draw
     out.transformation_update_id = -1;
+    out.num_eigenvalues = 0;
     if (sc.mm_id != sc.stats_last_id) {
         out.transformation_update_id = sc.mm_id;
         if (P.out_mm_inv) { C.load(x, C.lsig); write_row(C, P.out_mm_inv, row, x); }
@@ -1582,6 +1872,124 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     NM_MARK(C, 5)
     if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same draw for the LrWrap kernels: the transformation may carry a low-rank part, the adaptation is
+// GlobalStrategy<LowRankMassMatrixStrategy>, and a draw can pause inside `adapt` for the host's estimator (its statistics
+// row is completed when the chain resumes).  Output rows are addressed by the chain's own draw counter.
+// ---------------------------------------------------------------------------------------------
+template <int DPL, int W, class Dens>
+NM_DEV void finish_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain, nm_draw_stats& out, uint64_t ast, uint64_t row_idx) {
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    const size_t row = (size_t)(row_idx * P.n_chains + chain) * P.dim;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.step_size = sc.step_size;
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size
+                      : P.s.step_size_method == NM_STEP_ADAM ? uexp(sc.log_step) : uexp(sc.log_step_adapted);
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.chain_status = ast;
+    out.transformation_update_id = -1;                            // LowRankMassMatrix::extract_stats (low_rank.rs:218-262)
+    out.num_eigenvalues = 0;
+    if (sc.mm_id != sc.stats_last_id) {
+        out.transformation_update_id = sc.mm_id;
+        out.num_eigenvalues = sc.lr_has_inner ? sc.lr_rank : 0;
+        Tile<DPL> t;
+        if (P.out_mm_inv) { C.load(t, C.lsig); write_row(C, P.out_mm_inv, row, t); }
+        if (P.out_mm_mu) { C.load(t, C.lmu); write_row(C, P.out_mm_mu, row, t); }
+        if (P.out_mm_eigvals && sc.lr_has_inner) {
+            double* dst = P.out_mm_eigvals + row;
+            for (int d = tid(); d < C.dim; d += 64 * W) dst[d] = d < (int)sc.lr_rank ? C.lvals[d] : __builtin_nan("");
+        }
+    }
+    sc.stats_last_id = sc.mm_id;
+    if (P.out_stats && tid() == 0) P.out_stats[row_idx * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
+// returns false when the chain cannot go on in this launch (paused for the host, or failed)
+template <int DPL, int W, class Dens>
+NM_DEV bool chain_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    const uint64_t row_idx = sc.draw_count - P.row_base;
+    AcceptCollector col;
+    DrawResult R;
+    Tile<DPL> x, gx, z, gz;
+    uint64_t st = nuts_transition(C, col, R, z);
+    nm_draw_stats out = {};
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    if (st != NM_CHAIN_OK) {
+        sc.status = st;
+        out.chain_status = st;
+        if (P.out_stats && tid() == 0) P.out_stats[row_idx * P.n_chains + chain] = out;
+        return false;
+    }
+    const size_t row = (size_t)(row_idx * P.n_chains + chain) * P.dim;
+    if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
+        emit_divergence_vectors(C, R.div_start_idx, row);
+    if (R.chosen.slot == -1 && !sc.px_stale) {
+        C.loadP(x, P_X); C.loadP(gx, P_GX);
+        C.loadP(z, P_Z); C.loadP(gz, P_GZ);
+    } else {
+        if (R.chosen.slot == -1) C.loadP(z, P_Z);
+        transform_to_x(C, z, x);                                  // the leapfrog's own operations => the same bits
+        (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+        transform_to_gz(C, gx, gz);
+        const bool need_x = sc.tuning || sc.draw_count + 1 == P.draw_end || P.out_div_start || P.out_div_start_grad;
+        if (need_x) { C.storeP_nt(x, P_X); C.storeP_nt(gx, P_GX); }
+        sc.px_stale = need_x ? 0 : 1;
+        C.storeP(z, P_Z); C.storeP(gz, P_GZ);
+        sc.logp = R.chosen.logp;
+    }
+    const int64_t idx = R.chosen.idx;
+    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
+    write_row(C, P.out_positions, row, x);
+    write_row(C, P.out_gradient, row, gx);
+    write_row(C, P.out_tpos, row, z);
+    write_row(C, P.out_tgrad, row, gz);
+    double fd = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) fd = fd + (z.a[k] + gz.a[k]) * (z.a[k] + gz.a[k]);
+    fd = C.red.sum(fd);
+    const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
+    out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
+    out.index_in_trajectory = idx; out.transformation_index = sc.transform_id;
+    out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
+    sc.total_steps += col.count;
+    const uint64_t ast = adapt_lr(C, chain, col, is_good, x, gx);
+    if (sc.lr_pending == LR_WAIT_HOST) {                          // the rest of this draw happens in lr_resume
+        sc.lr_row = row_idx;
+        if (P.out_stats && tid() == 0) P.out_stats[row_idx * P.n_chains + chain] = out;
+        return false;
+    }
+    finish_draw_lr(C, chain, out, ast, row_idx);
+    return sc.status == NM_CHAIN_OK;
+}
+
+// the host answered: LowRankMassMatrixStrategy::adapt returned true (adapt/low_rank.rs:347-353); finish GlobalStrategy::adapt
+// and the draw's statistics
+template <int DPL, int W, class Dens>
+NM_DEV void lr_resume(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    if (sc.lr_upd_ok) lr_commit_update(C);
+    Tile<DPL> x;
+    C.loadP(x, P_X);
+    sc.lr_pending = LR_IDLE;
+    const uint64_t ast = adapt_tail(C, true, sc.lr_is_late != 0, x);
+    nm_draw_stats out = {};
+    if (P.out_stats) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&P.out_stats[sc.lr_row * P.n_chains + chain]);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&out);
+        for (int i = 0; i < (int)(sizeof(nm_draw_stats) / 8); ++i) dst[i] = src[i];
+    }
+    finish_draw_lr(C, chain, out, ast, sc.lr_row);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1623,9 +2031,19 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
 #if NM_PROF
             C.prof_t = __builtin_amdgcn_s_memtime();
 #endif
+            if constexpr (lr_trait<Dens>::value) {
+                if (C.sc.lr_pending == LR_SET_TRANSFORM) {              // nm_engine_set_transform: LowRankMassMatrix::update
+                    if (C.sc.lr_upd_ok) lr_commit_update(C);
+                    C.sc.lr_pending = LR_IDLE;
+                }
+                if (C.sc.lr_pending == LR_ANSWERED) lr_resume(C, chain);
+                if (C.sc.lr_pending == LR_IDLE && C.sc.status == NM_CHAIN_OK)
+                    while (C.sc.draw_count < P.draw_end) { if (!chain_draw_lr(C, chain)) break; }
+            } else {
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
                 if (C.sc.status != NM_CHAIN_OK) break;
+            }
             }
         }
         ctx_end(C, chain);
@@ -1658,9 +2076,15 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         if (!C.red.all(ok)) status = NM_CHAIN_BAD_INIT;
         if (status == NM_CHAIN_OK) {
             // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
+            if constexpr (lr_trait<Dens>::value) {
+                // LowRankMassMatrixStrategy::init (adapt/low_rank.rs:299-317): add_draw(point), update_from_grad
+                sc.lr_start = 0; sc.lr_len = 0; sc.lr_split = 0; sc.lr_pending = LR_IDLE;
+                lr_push(C, chain, x, gx);
+            } else {
             C.storeP(x, E_DM); C.storeP(x, B_DM);
             C.storeP(gx, E_GM); C.storeP(gx, B_GM);
             sc.cnt_fg = 1; sc.cnt_bg = 1;
+            }
             mass_matrix_from_grad(C, x, gx);
             status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)
         }

@@ -77,4 +77,10 @@ hipError_t launch_diag_normal(int dpl, int w, KernelKind kind, const KParams& P,
 hipError_t launch_funnel(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_eight_schools(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_mvn_prec(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+// the same kernels with the low-rank transformation compiled in (LrWrap<Density>), in kern_lr_<density>.hip
+hipError_t launch_iid_normal_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_diag_normal_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_funnel_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_eight_schools_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_mvn_prec_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 }  // namespace nm

@@ -21,6 +21,7 @@ from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAm
 
 LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE = 0, 1, 2, 3, 4, 5
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
+ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
 
 
 @dataclass
@@ -57,9 +58,16 @@ class DiagAdaptExpSettings:        # src/transform/adapt/diagonal.rs:92-106
 
 
 @dataclass
+class LowRankSettings:             # src/transform/low_rank.rs:188-203
+    store_mass_matrix: bool = False
+    gamma: float = 1e-5
+    eigval_cutoff: float = 2.0
+
+
+@dataclass
 class EuclideanAdaptOptions:       # src/adapt_strategy.rs:41-69
     step_size_settings: StepSizeSettings = field(default_factory=StepSizeSettings)
-    mass_matrix_options: DiagAdaptExpSettings = field(default_factory=DiagAdaptExpSettings)
+    mass_matrix_options: object = field(default_factory=DiagAdaptExpSettings)   # DiagAdaptExpSettings | LowRankSettings
     early_window: float = 0.3
     step_size_window: float = 0.15
     mass_matrix_switch_freq: int = 80
@@ -85,6 +93,7 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
     num_chains: int = 6
     seed: int = 0
     extra_doublings: int = 0
+    freeze_transform: bool = False   # engine knob (not a reference setting): see nm_settings.freeze_transform
 
     def to_c(self) -> NmSettings:
         s = NmSettings()
@@ -103,8 +112,15 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
         s.early_mass_matrix_switch_freq = a.early_mass_matrix_switch_freq
         s.mass_matrix_update_freq = a.mass_matrix_update_freq
         s.mass_matrix_window_growth = a.mass_matrix_window_growth
-        s.store_mass_matrix = int(a.mass_matrix_options.store_mass_matrix)
-        s.use_grad_based_estimate = int(a.mass_matrix_options.use_grad_based_estimate)
+        mo = a.mass_matrix_options
+        s.store_mass_matrix = int(mo.store_mass_matrix)
+        if isinstance(mo, LowRankSettings):          # LowRankNutsSettings = NutsSettings<EuclideanAdaptOptions<LowRankSettings>>
+            s.adaptation = ADAPT_LOW_RANK
+            s.lr_gamma, s.lr_eigval_cutoff = mo.gamma, mo.eigval_cutoff
+        else:
+            s.adaptation = ADAPT_DIAG
+            s.use_grad_based_estimate = int(mo.use_grad_based_estimate)
+        s.freeze_transform = int(self.freeze_transform)
         s.target_accept, s.initial_step = st.target_accept, st.initial_step
         s.has_jitter, s.jitter = int(st.jitter is not None), st.jitter or 0.0
         s.step_size_method, s.fixed_step_size = st.method, st.fixed_step_size
@@ -113,6 +129,15 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
         s.adam_beta1, s.adam_beta2 = st.adam.beta1, st.adam.beta2
         s.adam_epsilon, s.adam_learning_rate = st.adam.epsilon, st.adam.learning_rate
         return s
+
+
+def LowRankNutsSettings(**kw):     # src/sampler.rs:245; Default: :636-642 (num_tune 800, mass_matrix_update_freq 20)
+    """`LowRankNutsSettings`: the same settings struct with `LowRankSettings` as mass_matrix_options."""
+    lr = {k: kw.pop(k) for k in ("gamma", "eigval_cutoff", "store_mass_matrix") if k in kw}
+    ao = kw.pop("adapt_options", None) or EuclideanAdaptOptions(mass_matrix_update_freq=20)
+    ao.mass_matrix_options = LowRankSettings(**lr)
+    kw.setdefault("num_tune", 800)
+    return DiagNutsSettings(adapt_options=ao, **kw)
 
 
 @dataclass
@@ -177,7 +202,7 @@ class ChainBatch:
 
     def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
                  chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0, waves_per_chain: int = 0,
-                 grid_blocks: int = 0, lane_groups: int = 0):
+                 grid_blocks: int = 0, lane_groups: int = 0, lowrank_max_rank: int = 0):
         self.settings = settings
         self.logp = logp
         self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
@@ -187,6 +212,7 @@ class ChainBatch:
         L.nm_engine_config_default(C.byref(cfg))
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
         cfg.waves_per_chain, cfg.grid_blocks, cfg.lane_groups = waves_per_chain, grid_blocks, lane_groups
+        cfg.lowrank_max_rank = lowrank_max_rank
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()
@@ -261,6 +287,8 @@ class ChainBatch:
             names += ["transformed_position", "transformed_gradient"]
         if s.adapt_options.mass_matrix_options.store_mass_matrix:
             names += ["mass_matrix_inv", "transformation_mu"]
+            if isinstance(s.adapt_options.mass_matrix_options, LowRankSettings):
+                names += ["mass_matrix_eigvals"]
         if s.store_divergences:
             names += ["divergence_start", "divergence_start_gradient", "divergence_end"]
         return names
@@ -292,6 +320,40 @@ class ChainBatch:
 
     def synchronize(self):
         check(_lib.load().nm_engine_synchronize(self._h))
+
+    # ---- the low-rank transformation (LowRankNutsSettings; reference src/transform/low_rank.rs) ----
+    def set_transform(self, stds, mean, vals, vecs, mu_low_rank):
+        """`LowRankMassMatrix::update(stds, mean, vals, vecs, mean_low_rank)` for every chain.  vecs: [n_eig, dim] (one
+        eigenvector per row); give every array a leading [n_chains] axis for per-chain transformations."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        stds, mean, vals, vecs, mu = f(stds), f(mean), f(vals), f(vecs), f(mu_low_rank)
+        per_chain = int(stds.ndim == 2)
+        n_eig = int(vals.shape[-1]) if vals.size else 0
+        want = (self.n_chains, self.logp.dim) if per_chain else (self.logp.dim,)
+        if stds.shape != want or mean.shape != want or mu.shape != want:
+            raise ValueError(f"stds, mean, mu_low_rank must have shape {want}")
+        if vecs.size != (self.n_chains if per_chain else 1) * n_eig * self.logp.dim:
+            raise ValueError("vecs must be [n_eig, dim] (or [n_chains, n_eig, dim])")
+        self._keep_tr = (stds, mean, vals, vecs, mu)
+        check(_lib.load().nm_engine_set_transform(self._h, per_chain, n_eig, stds.ctypes.data, mean.ctypes.data,
+                                                  vals.ctypes.data if n_eig else None, vecs.ctypes.data if n_eig else None,
+                                                  mu.ctypes.data))
+
+    def set_lowrank_estimator(self, fn=None, n_threads=0):
+        """Replace the built-in host estimator of `compute_update` (a _lib.LOWRANK_ESTIMATOR_FN; None restores it)."""
+        self._keep_est = fn
+        check(_lib.load().nm_engine_set_lowrank_estimator(self._h, C.cast(fn, C.c_void_p) if fn is not None else None, None, n_threads))
+
+    def lowrank(self):
+        """Current low-rank part per chain: (n_eig [n_chains], lambda^(1/2) [n_chains, max_rank], vecs [n_chains, max_rank, dim],
+        mu_low_rank [n_chains, dim])."""
+        L = _lib.load()
+        R = int(L.nm_engine_lowrank_max_rank(self._h))
+        n = np.zeros(self.n_chains, dtype=np.uint64)
+        vals, vecs = np.zeros((self.n_chains, R)), np.zeros((self.n_chains, R, self.logp.dim))
+        mu = np.zeros((self.n_chains, self.logp.dim))
+        check(L.nm_engine_get_lowrank(self._h, n.ctypes.data, vals.ctypes.data, vecs.ctypes.data, mu.ctypes.data))
+        return n, vals, vecs, mu
 
     def positions(self):
         out = np.empty((self.n_chains, self.logp.dim))

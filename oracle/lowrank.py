@@ -64,18 +64,34 @@ def estimate_mass_matrix(draws, grads, gamma):
     return vals, vecs
 
 
-def compute_update(draws, grads, gamma=1e-5, eigval_cutoff=2.0):
-    """draws, grads: [ndim][ndraws].  -> (stds, mean, vals, vecs [ndim][n_eig], mu_low_rank) or None."""
+def _basis(a, rank_revealing, tol=1e-10):
+    """orthonormal basis of the columns of `a`: the thin SVD's U (literal), or only its numerically non-null part"""
+    u, sv, _ = np.linalg.svd(a, full_matrices=False)
+    if rank_revealing and len(sv):
+        u = u[:, sv > tol * sv[0]]
+    return u
+
+
+def compute_update(draws, grads, gamma=1e-5, eigval_cutoff=2.0, rank_revealing=False):
+    """draws, grads: [ndim][ndraws].  -> (stds, mean, vals, vecs [ndim][n_eig], mu_low_rank) or None.
+
+    rank_revealing=False follows the reference literally (thin SVD U with LAPACK's completion of null directions, full
+    thin Q of the pivoted QR).  rank_revealing=True drops numerically null directions — in exact arithmetic the same
+    result (those directions carry eigenvalue 1 and are filtered), in floating point free of the eps / gamma^2 noise the
+    literal form has there; it is what the engine's host estimator (csrc/lowrank_host.cpp) computes."""
     draws, grads, stds, mean, draw_mean, grad_mean = rescale_points(np.asarray(draws, float), np.asarray(grads, float))
     if not (np.isfinite(draws).all() and np.isfinite(grads).all()):
         return None                                    # faer's SVD fails on non-finite input (`.ok()?`)
     try:
-        ud = np.linalg.svd(draws, full_matrices=False)[0]
-        ug = np.linalg.svd(grads, full_matrices=False)[0]
+        ud = _basis(draws, rank_revealing)
+        ug = _basis(grads, rank_revealing)
     except np.linalg.LinAlgError:
         return None
     subspace = np.concatenate([ud, ug], axis=1)
-    q = scipy.linalg.qr(subspace, mode="economic", pivoting=True)[0]
+    if rank_revealing:
+        q = _basis(subspace, True)
+    else:
+        q = scipy.linalg.qr(subspace, mode="economic", pivoting=True)[0]
     dp, gp = q.T @ draws, q.T @ grads
     est = estimate_mass_matrix(dp, gp, gamma)
     if est is None:
@@ -89,14 +105,14 @@ def compute_update(draws, grads, gamma=1e-5, eigval_cutoff=2.0):
     return stds, mean, vals, vecs, mu
 
 
-def estimator_callback(record=None):
+def estimator_callback(record=None, rank_revealing=False):
     """An oracle.ESTIMATOR_FN around compute_update.  `record` (a list) receives every (draws, grads, result)."""
     from . import oracle as O
 
     def cb(ctx, ndim, ndraws, draws, grads, gamma, cutoff, stds, mean, n_eig, vals, vecs, mu):
         d = np.ctypeslib.as_array(draws, shape=(ndraws, ndim)).T.copy()
         g = np.ctypeslib.as_array(grads, shape=(ndraws, ndim)).T.copy()
-        res = compute_update(d, g, gamma, cutoff)
+        res = compute_update(d, g, gamma, cutoff, rank_revealing)
         if record is not None:
             record.append((d, g, res))
         if res is None:

@@ -1,0 +1,236 @@
+"""GPU parity of the low-rank transformation (reference src/transform/low_rank.rs,
+src/transform/adapt/low_rank.rs, src/math/cpu_math.rs:332-425) against the CPU oracle, through the C ABI.
+
+  * the three maps of LowRankMassMatrix on device vectors (nm_lowrank_transform_batch)            — bit-exact
+  * whole chains with a FIXED transformation (nm_engine_set_transform; per chain and shared; rank << dim and rank = dim,
+    BASELINE config 5's "dense" case at dim 256)                                                   — bit-exact
+  * whole chains with LowRankNutsSettings' ADAPTATION, the estimator's dense linear algebra injected identically on both
+    sides (the oracle's LAPACK restatement), so that everything else — windows, schedule, pause / resume protocol,
+    re-whitening, step-size search after the first update, statistics — must agree                 — bit-exact
+  * the built-in host estimator end to end (statistical) and the full-size K5 run (properties)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nuts_rs_amd as N
+from nuts_rs_amd import _lib
+from helpers import assert_bit_exact, oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+
+def random_transform(rng, dim, rank, per_chain=0):
+    shape = (per_chain,) if per_chain else ()
+    stds = np.exp(rng.normal(0, 0.5, shape + (dim,)))
+    mean = rng.normal(0, 1, shape + (dim,))
+    mu = rng.normal(0, 0.3, shape + (dim,))
+    vals = np.exp(rng.uniform(-2, 3, shape + (rank,)))
+    if per_chain:
+        vecs = np.stack([np.linalg.qr(rng.normal(size=(dim, rank)))[0].T for _ in range(per_chain)])
+    else:
+        vecs = np.linalg.qr(rng.normal(size=(dim, rank)))[0].T
+    return stds, mean, vals, np.ascontiguousarray(vecs), mu
+
+
+def correlated_precision(rng, dim, rank, scale=50.0):
+    u = np.linalg.qr(rng.normal(size=(dim, rank)))[0]
+    sigma = np.eye(dim) + u @ np.diag(rng.uniform(5.0, scale, rank)) @ u.T
+    sc = np.exp(rng.normal(0, 0.5, dim))
+    sigma = np.diag(sc) @ sigma @ np.diag(sc)
+    prec = np.linalg.inv(sigma)
+    return (prec + prec.T) / 2, sigma
+
+
+@pytest.mark.parametrize("dim,rank", [(3, 1), (10, 4), (40, 40), (100, 7), (256, 16), (256, 256), (1000, 5)])
+def test_lowrank_maps_bit_exact(oracle, dim, rank):
+    import torch
+    rng = np.random.default_rng(dim * 1000 + rank)
+    n = 3
+    stds, mean, vals, vecs, mu = random_transform(rng, dim, rank, per_chain=n)
+    vin = rng.normal(size=(n, dim))
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    t = [dev(a) for a in (stds, mean, vals, vecs, mu, vin)]
+    out = torch.empty((n, dim), dtype=torch.float64, device="cuda")
+    cfg = oracle.gpu_cfg(64)
+    for which in (0, 1, 2):
+        _lib.check(_lib.load().nm_lowrank_transform_batch(which, n, dim, rank, 0, *[x.data_ptr() for x in t], out.data_ptr(), None))
+        got = out.cpu().numpy()
+        for i in range(n):
+            want = oracle.lowrank_kat(cfg, np.ones(dim), stds[i], mean[i], vals[i], vecs[i], mu[i], vin[i], which=which)["z"]
+            bad = np.argwhere(got[i].view(np.uint64) != want.view(np.uint64))
+            assert bad.size == 0, f"map {which} chain {i}: first difference at element {bad[0]}: {got[i][bad[0][0]]!r} vs {want[bad[0][0]]!r}"
+
+
+def lowrank_settings(**kw):
+    return N.LowRankNutsSettings(**kw)
+
+
+def run_fixed(oracle, logp, settings, n_chains, transform, n_draws, waves_per_chain=0, dims_per_lane=0):
+    x0 = oracle.init_positions_uniform(settings.seed, 0, n_chains, logp.dim)
+    b = N.ChainBatch(settings, logp, n_chains, waves_per_chain=waves_per_chain, dims_per_lane=dims_per_lane)
+    assert (b.set_position(x0) == 0).all()
+    b.set_transform(*transform)
+    pos, st = b.draw_many(n_draws)
+    tpc = b.threads_per_chain()
+    b.close()
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, settings), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc),
+                                        n_chains, x0, n_draws, n_threads=8, transform=transform)
+    assert failed == 0
+    return pos, st, pos_o, st_o
+
+
+@pytest.mark.parametrize("case", ["dim10_rank3_shared", "dim100_rank6_per_chain", "dim40_full_rank", "dim300_rank12_two_waves",
+                                  "dim256_rank256_mvn"])
+def test_fixed_transform_chains_bit_exact(oracle, case):
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    kw = {}
+    if case == "dim10_rank3_shared":
+        dim, n, tr, logp, draws = 10, 5, random_transform(rng, 10, 3), None, 120
+    elif case == "dim100_rank6_per_chain":
+        dim, n, tr, logp, draws = 100, 4, random_transform(rng, 100, 6, per_chain=4), None, 90
+    elif case == "dim40_full_rank":
+        dim, n, tr, logp, draws = 40, 3, random_transform(rng, 40, 40), None, 90
+    elif case == "dim300_rank12_two_waves":
+        dim, n, tr, logp, draws = 300, 3, random_transform(rng, 300, 12), None, 60
+        kw = dict(waves_per_chain=2, dims_per_lane=8)
+    else:   # BASELINE config 5: N(0, Sigma) with full Sigma at dim 256, the exact "dense" preconditioner as a rank-256 transform
+        dim, n, draws = 256, 3, 40
+        prec, sigma = correlated_precision(rng, dim, 6)
+        w, u = np.linalg.eigh(sigma)
+        tr = (np.ones(dim), np.zeros(dim), w, np.ascontiguousarray(u.T), np.zeros(dim))
+        logp = N.LogpSpec.mvn_precision(prec)
+    if logp is None:
+        logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-2, 2, dim)))
+    s = lowrank_settings(num_chains=n, seed=31, num_tune=draws - 20, freeze_transform=True)
+    pos, st, pos_o, st_o = run_fixed(oracle, logp, s, n, tr, draws, **kw)
+    assert_bit_exact(pos, st, pos_o, st_o)
+    assert (st["transformation_update_id"][0] == 1).all() and (st["num_eigenvalues"][0] == len(tr[2].reshape(-1, tr[2].shape[-1])[0])).all()
+    if case == "dim256_rank256_mvn":   # the exact preconditioner whitens the target: shallow trees at a large step size
+        assert st["depth"][-10:].mean() <= 3.5 and st["step_size"][-1].min() > 0.3
+
+
+def estimator_pair(oracle):
+    """the oracle's LAPACK estimator, as a callback for the oracle and as a callback for the engine (same function)"""
+    from oracle import lowrank as LR
+    rec = []
+    cb_o = LR.estimator_callback(rec)
+    cb_e = C.cast(cb_o, _lib.LOWRANK_ESTIMATOR_FN)
+    return cb_o, cb_e, rec
+
+
+@pytest.mark.parametrize("case", ["diag_normal_dim12", "mvn_dim20_correlated", "funnel_dim11", "mvn_dim64_update_freq5"])
+def test_lowrank_adaptation_bit_exact(oracle, case):
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    n, tune, draws, freq = 4, 120, 150, 20
+    if case == "diag_normal_dim12":
+        logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-2, 2, 12)))
+    elif case == "mvn_dim20_correlated":
+        logp = N.LogpSpec.mvn_precision(correlated_precision(rng, 20, 2)[0])
+    elif case == "funnel_dim11":
+        logp = N.LogpSpec.funnel(11)
+    else:
+        logp, n, tune, draws, freq = N.LogpSpec.mvn_precision(correlated_precision(rng, 64, 3)[0]), 3, 100, 120, 5
+    s = lowrank_settings(num_chains=n, seed=5, num_tune=tune, store_mass_matrix=True)
+    s.adapt_options.mass_matrix_update_freq = freq
+    cb_o, cb_e, rec = estimator_pair(oracle)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, logp.dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_lowrank_estimator(cb_e, n_threads=1)
+    pos, st, vec = b.expanded_draw_many(draws, vectors=["mass_matrix_inv", "mass_matrix_eigvals", "gradient"])
+    tpc = b.threads_per_chain()
+    n_eng = len(rec)
+    b.close()
+    vo = {}
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc), n, x0,
+                                        draws, estimator=cb_o, vectors=vo)
+    assert failed == 0 and len(rec) == 2 * n_eng and n_eng >= n * 3          # both sides asked the estimator equally often
+    assert_bit_exact(pos, st, pos_o, st_o)
+    assert (st["num_eigenvalues"] == st_o["num_eigenvalues"]).all()
+    for k in vec:
+        both_nan = np.isnan(vec[k]) & np.isnan(vo[k])
+        assert ((vec[k].view(np.uint64) == vo[k].view(np.uint64)) | both_nan).all(), k
+    assert (st["transformation_update_id"] >= 0).sum() >= n * 3 and st["num_eigenvalues"].max() >= (1 if "mvn" in case else 0)
+
+
+def test_builtin_estimator_matches_lapack_restatement(oracle):
+    """nm_lowrank_compute_update (csrc/lowrank_host.cpp) against oracle/lowrank.py on well-conditioned windows."""
+    from oracle import lowrank as LR
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+    for dim, n, rank in ((12, 60, 2), (64, 200, 5), (30, 90, 3)):
+        prec, sigma = correlated_precision(rng, dim, rank)
+        x = np.linalg.cholesky(sigma) @ rng.normal(size=(dim, n)) + rng.normal(size=(dim, 1))
+        g = -prec @ (x - 1.0)
+        d, gg = np.ascontiguousarray(x.T), np.ascontiguousarray(g.T)
+        m = min(dim, 2 * n)
+        stds, mean, vals, vecs, mu = np.empty(dim), np.empty(dim), np.empty(m), np.empty((m, dim)), np.empty(dim)
+        ne = C.c_uint64()
+        rc = L.nm_lowrank_compute_update(None, dim, n, d.ctypes.data, gg.ctypes.data, 1e-5, 2.0, stds.ctypes.data, mean.ctypes.data,
+                                         C.byref(ne), vals.ctypes.data, vecs.ctypes.data, mu.ctypes.data)
+        ref = LR.compute_update(x, g, 1e-5, 2.0, rank_revealing=True)
+        assert rc == 0 and ref is not None and ne.value == len(ref[2])
+        k = ne.value
+        op = lambda v, u: u.T @ np.diag(np.sqrt(v) - 1) @ u
+        assert np.allclose(stds, ref[0], rtol=1e-12) and np.allclose(mean, ref[1], atol=1e-10)
+        assert np.allclose(np.sort(vals[:k]), np.sort(ref[2]), rtol=1e-8)
+        assert np.abs(op(vals[:k], vecs[:k]) - op(ref[2], ref[3].T)).max() < 1e-8 * max(1.0, np.abs(op(ref[2], ref[3].T)).max())
+        assert np.allclose(mu, ref[4], atol=1e-8)
+
+
+def test_builtin_estimator_end_to_end(oracle):
+    """LowRankNutsSettings with the engine's own estimator on a correlated normal: the adapted transformation shortens the
+    trajectories compared with DiagNutsSettings, and the draws have the target's covariance."""
+    rng = np.random.default_rng(21)
+    dim, n = 48, 64
+    prec, sigma = correlated_precision(rng, dim, 3, scale=200.0)
+    logp = N.LogpSpec.mvn_precision(prec)
+    res = {}
+    for name, s in (("diag", N.DiagNutsSettings(num_chains=n, seed=9, num_tune=300)),
+                    ("low_rank", lowrank_settings(num_chains=n, seed=9, num_tune=300))):
+        b = N.ChainBatch(s, logp, n)
+        b.set_position(b.init_positions_uniform())
+        pos, st = b.draw_many(500)
+        res[name] = (pos[300:], st[300:])
+        if name == "low_rank":
+            n_eig = b.lowrank()[0]
+            assert (n_eig >= 2).all() and (n_eig <= 12).all()
+        b.close()
+    steps = {k: v[1]["n_steps"].mean() for k, v in res.items()}
+    assert steps["low_rank"] < 0.6 * steps["diag"], steps
+    cov = np.cov(res["low_rank"][0].reshape(-1, dim).T)
+    assert np.abs(cov - sigma).max() < 0.15 * np.abs(sigma).max()
+    assert res["low_rank"][1]["diverging"].mean() < 0.01
+
+
+def test_k5_full_size_properties(oracle):
+    """BASELINE config 5 at full size: N(0, Sigma), full Sigma, dim 256 x 4096 chains, the exact dense preconditioner as a
+    rank-256 transformation shared by all chains (frozen), step size adapted.  Size-independent properties: moments of the
+    draws, chains 0-1 bit-exact against the oracle, results independent of how the batch is cut into launches."""
+    rng = np.random.default_rng(55)
+    dim, n, tune, draws = 256, 4096, 60, 80
+    prec, sigma = correlated_precision(rng, dim, 8, scale=100.0)
+    w, u = np.linalg.eigh(sigma)
+    tr = (np.ones(dim), np.zeros(dim), w, np.ascontiguousarray(u.T), np.zeros(dim))
+    logp = N.LogpSpec.mvn_precision(prec)
+    s = lowrank_settings(num_chains=n, seed=77, num_tune=tune, freeze_transform=True)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_transform(*tr)
+    pos1, st1 = b.draw_many(50)
+    pos2, st2 = b.draw_many(draws - 50)
+    pos, st = np.concatenate([pos1, pos2]), np.concatenate([st1, st2])
+    tpc = b.threads_per_chain()
+    b.close()
+    assert (st["chain_status"] == 0).all() and st["diverging"].mean() < 1e-3
+    sample = pos[tune:].reshape(-1, dim)
+    z = sample @ (u / np.sqrt(w))                                   # whitened draws ~ N(0, I)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
+    assert np.abs(np.cov(z.T) - np.eye(dim)).max() < 0.06
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc), 2, x0[:2], draws,
+                                        n_threads=2, transform=tr)
+    assert failed == 0
+    assert_bit_exact(pos[:, :2], st[:, :2], pos_o, st_o)
