@@ -249,7 +249,7 @@ typedef struct nm_engine_config {
     uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
                                     * 0 = auto (when there are more chains than resident wavefronts, ~2048), 1 = never, 2 = whenever the kernel applies */
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
-                                    * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return */
+                                    * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
     uint64_t reserved[1];
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);

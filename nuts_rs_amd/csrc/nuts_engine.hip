@@ -414,7 +414,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
     if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     if (lr) {   // eigenvector slots, eigenvalue arrays and the window of draws / gradients of every chain
-        const uint64_t most = std::min<uint64_t>(logp->dim, 2 * (s.num_tune + 1));     // rank <= min(dim, 2 n_draws)
+        // the estimator's rank is <= min(dim, 2 n_draws); a transformation given from outside may have any rank <= dim
+        const uint64_t most = s.freeze_transform ? logp->dim : std::min<uint64_t>(logp->dim, 2 * (s.num_tune + 1));
         e->lr_rmax = cfg.lowrank_max_rank ? std::min<uint64_t>(cfg.lowrank_max_rank, logp->dim) : most;
         if (e->lr_rmax == 0) e->lr_rmax = 1;
         e->lr_cap = s.num_tune + 2;
