@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 6
+#define NM_ABI_VERSION 7
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -267,12 +267,28 @@ void      nm_engine_destroy(nm_engine* e);
  * h_chain_status (optional) receives NM_CHAIN_* per chain.  Returns NM_ERR_BAD_INIT /
  * NM_ERR_LOGP_FAILURE if any chain failed (the other chains are still initialised). */
 nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, uint64_t* h_chain_status);
+/* The same for the chains with h_mask[c] != 0 only (h_mask NULL = all): the others keep their state untouched — their
+ * adapted mass matrix, step-size adaptation and random stream.  This is the per-chain `Chain::set_position` the
+ * reference's init loop needs: a chain whose initial point fails with BadInitGrad draws another one and tries again,
+ * up to 500 times (src/sampler.rs:1133-1147), without disturbing the chains that started.  Calling it again for a
+ * chain does what the reference's second `set_position` does: the mass-matrix estimators take the new point as one
+ * more sample (src/transform/adapt/diagonal.rs:209-231), the mass matrix is re-derived from its gradient, the
+ * step-size search runs again, the random stream continues. */
+nm_status nm_engine_set_positions_masked(nm_engine* e, const double* h_x0, const uint8_t* h_mask, uint64_t* h_chain_status);
+/* The whole init loop of the reference's ChainProcess (src/sampler.rs:1126-1147): attempt 0 is h_x0 (NULL: the uniform
+ * init_position), every failed chain is retried with its next init_position, at most max_tries (reference: 500) in all.
+ * h_tries (optional) receives the attempts used per chain.  Returns NM_ERR_BAD_INIT if a chain never started. */
+nm_status nm_engine_init_positions_retry(nm_engine* e, const double* h_x0, uint64_t max_tries, uint64_t* h_chain_status, uint64_t* h_tries);
 
 /* The `init_position` of the reference's CpuMath (src/math/cpu_math.rs:171-199): x0 ~ U(-1,1) drawn
  * from each chain's OUTER generator right after the 32 seed bytes (Sampler order, src/sampler.rs:1126-1136).
  * Fills h_x0 [n_chains][dim]; pure host helper. */
 nm_status nm_init_positions_uniform(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains,
                                     uint64_t dim, double* h_x0);
+/* The `attempt`-th init_position of every chain (attempt 0 is nm_init_positions_uniform): the outer generator keeps
+ * running through the retries of the init loop (src/sampler.rs:1133-1143). */
+nm_status nm_init_positions_uniform_at(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains, uint64_t dim,
+                                       uint64_t attempt, double* h_x0);
 
 /* Advance ALL chains by n_draws draws (`Chain::draw` x n_draws per chain, reference src/chain.rs:151-188).
  * The whole loop runs on the device; this call enqueues the launches and returns after they finish.

@@ -176,6 +176,18 @@ public:
         if (x0.size() != n_ * dim_) throw NutsError(NM_ERR_INVALID_ARG, "x0 must hold n_chains * dim values");
         check(nm_engine_set_positions(h_, x0.data(), nullptr));
     }
+    // per-chain `Chain::set_position`: chains with mask[c] == 0 keep their whole state
+    void set_position(const std::vector<double>& x0, const std::vector<uint8_t>& mask) {
+        if (x0.size() != n_ * dim_ || mask.size() != n_) throw NutsError(NM_ERR_INVALID_ARG, "x0 / mask size");
+        check(nm_engine_set_positions_masked(h_, x0.data(), mask.data(), nullptr));
+    }
+    // the init loop of the reference's ChainProcess (src/sampler.rs:1126-1147): failed chains retry with their next
+    // init_position, at most max_tries times; x0 == nullptr starts from the uniform init_position
+    std::vector<uint64_t> init_with_retries(const std::vector<double>* x0 = nullptr, uint64_t max_tries = 500) {
+        std::vector<uint64_t> tries(n_);
+        check(nm_engine_init_positions_retry(h_, x0 ? x0->data() : nullptr, max_tries, nullptr, tries.data()));
+        return tries;
+    }
     // One `Chain::draw` per chain: (positions [n_chains][dim], one Progress per chain)
     std::pair<std::vector<double>, std::vector<Progress>> draw() {
         std::vector<double> pos(n_ * dim_);
@@ -276,7 +288,7 @@ private:
     void run(DiagNutsSettings settings, LogpSpec logp, std::optional<std::vector<double>> x0, int64_t device) {
         try {
             ChainBatch batch(settings, logp, n_, 0, device);
-            batch.set_position(x0 ? *x0 : batch.init_positions_uniform());
+            batch.init_with_retries(x0 ? &*x0 : nullptr);
             { std::lock_guard<std::mutex> g(m_); for (ChainProgress& p : progress_) p.started = true;
               trace_.n_chains = n_; trace_.dim = dim_; }
             uint64_t finished = 0;

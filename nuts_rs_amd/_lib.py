@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
-    "nm_lowrank_transform_batch",
+    "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
+    "nm_init_positions_uniform_at",
 ]
 
 
@@ -119,6 +120,9 @@ def load():
     L.nm_engine_destroy.restype = None
     L.nm_engine_set_positions.argtypes = [vp, vp, vp]
     L.nm_init_positions_uniform.argtypes = [u64, u64, u64, u64, vp]
+    L.nm_init_positions_uniform_at.argtypes = [u64, u64, u64, u64, u64, vp]
+    L.nm_engine_set_positions_masked.argtypes = [vp, vp, vp, vp]
+    L.nm_engine_init_positions_retry.argtypes = [vp, vp, u64, vp, vp]
     L.nm_engine_draw.argtypes = [vp, u64, vp, vp]
     L.nm_engine_draw_async.argtypes = [vp, u64, vp, vp]
     L.nm_engine_synchronize.argtypes = [vp]

@@ -98,9 +98,7 @@ class Sampler:
         batch = None
         try:
             batch = factory(self.settings, logp, self._n, chain_id_offset, device)
-            if x0 is None:
-                x0 = batch.init_positions_uniform()
-            batch.set_position(x0)
+            batch.init_with_retries(x0)              # ChainProcess init loop: up to 500 initial points per chain (sampler.rs:1133-1147)
             with self._lock:
                 self._started = True
             start, pause_time, last_cb = time.monotonic(), 0.0, None

@@ -361,7 +361,7 @@ struct DevRng {
 };
 
 struct ZigTables { const double* x; const double* f; };   // 257 entries each, HBM (L1/L2 resident)
-constexpr double ZIG_R = 3.654152885361008796;
+constexpr double ZIG_R = 3.654152885361008796;   // rand_distr's ZIG_NORM_R; the tables are the fixed constants of zig_tables.hpp
 
 // Tail of rand_distr's ziggurat loop for ONE sample whose first fast-path test failed; uniform over the wave.
 NM_DEV double normal_slow_path(DevRng& rng, uint64_t bits, ZigTables T) {

@@ -17,6 +17,13 @@
 
 using namespace nm;
 
+#include "zig_tables.hpp"
+// rand_distr's ZIG_NORM_X then ZIG_NORM_F (257 + 257 fixed constants; tools/gen_ziggurat_tables.py)
+static const double kZigX[257] = NM_ZIG_NORM_X, kZigF[257] = NM_ZIG_NORM_F;
+static const struct ZigInit { double t[2 * 257]; ZigInit() { memcpy(t, kZigX, sizeof kZigX); memcpy(t + 257, kZigF, sizeof kZigF); } } kZigInit;
+static const double* const kZigTablesPtr = kZigInit.t;
+#define kZigTables kZigInit.t
+
 // ---------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------
@@ -117,12 +124,19 @@ extern "C" nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t 
     return NM_OK;
 }
 
+extern "C" nm_status nm_init_positions_uniform_at(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains, uint64_t dim,
+                                                  uint64_t attempt, double* h_x0);
 extern "C" nm_status nm_init_positions_uniform(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains,
                                                uint64_t dim, double* h_x0) {
+    return nm_init_positions_uniform_at(seed, chain_id_offset, n_chains, dim, 0, h_x0);
+}
+extern "C" nm_status nm_init_positions_uniform_at(uint64_t seed, uint64_t chain_id_offset, uint64_t n_chains, uint64_t dim,
+                                                  uint64_t attempt, double* h_x0) {
     if (!h_x0) return fail(NM_ERR_INVALID_ARG, "h_x0 is null");
     for (uint64_t c = 0; c < n_chains; ++c) {
         HostRng o = outer_rng(seed, chain_id_offset + c);
         for (int i = 0; i < 8; ++i) (void)o.next_u32();
+        o.pos += 2 * attempt * dim;                            // the earlier attempts' draws (one u64 per coordinate)
         for (uint64_t d = 0; d < dim; ++d) {                   // CpuMath::init_position (cpu_math.rs:184-187)
             double val = (double)(o.next_u64() >> 11) * (1.0 / 9007199254740992.0);
             h_x0[c * dim + d] = val * 2.0 - 1.0;
@@ -272,6 +286,7 @@ struct nm_engine {
     double* d_zig = nullptr;      // x[257] then f[257]
     double* d_params = nullptr;
     double* d_x0 = nullptr;
+    uint8_t* d_init_mask = nullptr;
     void* staging[11] = {};                 // device staging of the *_to_host calls, one per output array, grow-only
     size_t staging_bytes[11] = {};
     void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
@@ -307,6 +322,7 @@ static void engine_free(nm_engine* e) {
     if (e->d_zig) (void)hipFree(e->d_zig);
     if (e->d_params) (void)hipFree(e->d_params);
     if (e->d_x0) (void)hipFree(e->d_x0);
+    if (e->d_init_mask) (void)hipFree(e->d_init_mask);
     if (e->d_lrvec) (void)hipFree(e->d_lrvec);
     if (e->d_lrval) (void)hipFree(e->d_lrval);
     if (e->d_lrwin) (void)hipFree(e->d_lrwin);
@@ -428,18 +444,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         E_TRY(hipMemsetAsync(e->d_lrval, 0, lb, e->stream));
         E_TRY(hipMalloc(&e->d_lrwin, wb));
     }
-    {   // ziggurat tables of rand_distr's StandardNormal (Marsaglia & Tsang, 256 layers)
-        std::vector<double> t(2 * 257);
-        double* x = t.data();
-        double* f = t.data() + 257;
-        const double r = ZIG_R, v = 0.00492867323399;
-        auto pdf = [](double u) { return std::exp(-u * u / 2.0); };
-        x[0] = v / pdf(r); x[1] = r;
-        for (int i = 2; i < 256; ++i) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + pdf(x[i - 1])));
-        x[256] = 0.0;
-        for (int i = 0; i < 257; ++i) f[i] = pdf(x[i]);
-        E_TRY(hipMemcpy(e->d_zig, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    // ziggurat tables of rand_distr's StandardNormal: the fixed ZIG_NORM_X / ZIG_NORM_F constants (zig_tables.hpp), x then f
+    E_TRY(hipMemcpy(e->d_zig, kZigTables, sizeof kZigTables, hipMemcpyHostToDevice));
     // per-chain scalars: NutsChain::new / GlobalStrategy::new state (the DualAverage is reset on the device)
     {
         std::vector<ChainScalars> sc(n_chains);
@@ -491,10 +497,45 @@ static nm_status collect_timing(nm_engine* e) {
 }
 
 extern "C" nm_status nm_engine_set_positions(nm_engine* e, const double* h_x0, uint64_t* h_chain_status) {
+    return nm_engine_set_positions_masked(e, h_x0, nullptr, h_chain_status);
+}
+extern "C" nm_status nm_engine_init_positions_retry(nm_engine* e, const double* h_x0, uint64_t max_tries, uint64_t* h_chain_status, uint64_t* h_tries) {
+    if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
+    if (max_tries == 0) max_tries = 500;
+    const uint64_t n = e->n_chains, dim = e->dim;
+    std::vector<double> x0(n * dim);
+    std::vector<uint64_t> status(n, NM_CHAIN_BAD_INIT), tries(n, 0);
+    std::vector<uint8_t> mask(n, 1);
+    nm_status st = NM_OK;
+    for (uint64_t attempt = 0; attempt < max_tries; ++attempt) {
+        if (attempt == 0 && h_x0) memcpy(x0.data(), h_x0, n * dim * sizeof(double));
+        else nm_init_positions_uniform_at(e->s.seed, e->cfg.chain_id_offset, n, dim, h_x0 ? attempt - 1 : attempt, x0.data());
+        std::vector<uint64_t> now(n);
+        st = nm_engine_set_positions_masked(e, x0.data(), mask.data(), now.data());
+        if (st != NM_OK && st != NM_ERR_BAD_INIT) break;                 // a fatal logp error ends the loop like the reference's `?`
+        uint64_t left = 0;
+        for (uint64_t c = 0; c < n; ++c) {
+            if (!mask[c]) continue;
+            status[c] = now[c]; tries[c] = attempt + 1;
+            mask[c] = now[c] == NM_CHAIN_BAD_INIT ? 1 : 0;
+            left += mask[c];
+        }
+        if (!left) { st = NM_OK; break; }
+    }
+    if (h_chain_status) memcpy(h_chain_status, status.data(), n * sizeof(uint64_t));
+    if (h_tries) memcpy(h_tries, tries.data(), n * sizeof(uint64_t));
+    return st;
+}
+extern "C" nm_status nm_engine_set_positions_masked(nm_engine* e, const double* h_x0, const uint8_t* h_mask, uint64_t* h_chain_status) {
     if (!e || !h_x0) return fail(NM_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_x0, h_x0, e->n_chains * e->dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     KParams P = e->P;
+    if (h_mask) {
+        if (!e->d_init_mask) HIP_TRY(hipMalloc(&e->d_init_mask, e->n_chains));
+        HIP_TRY(hipMemcpyAsync(e->d_init_mask, h_mask, e->n_chains, hipMemcpyHostToDevice, e->stream));
+        P.init_mask = e->d_init_mask;
+    }
     HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->lr));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
@@ -765,7 +806,9 @@ extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, c
             if (er == hipSuccess) e->staging_bytes[k] = it.bytes;
         }
         *it.dev = e->staging[k];
-        if (er == hipSuccess && it.event) er = hipMemsetAsync(*it.dev, 0xFF, it.bytes, e->stream);   // all-ones = NaN
+        // rows a chain never writes (it stopped mid-launch, or the event did not happen) must not show an earlier call's
+        // data: vectors read as NaN (all-ones), statistics as zeros
+        if (er == hipSuccess) er = hipMemsetAsync(*it.dev, k == 1 ? 0x00 : 0xFF, it.bytes, e->stream);
         if (er != hipSuccess) { *it.dev = nullptr; st = fail(NM_ERR_HIP, "device buffer of %zu bytes: %s", it.bytes, hipGetErrorString(er)); break; }
     }
     if (st == NM_OK) st = nm_engine_draw_ex(e, n_draws, &d);
@@ -1144,17 +1187,7 @@ extern "C" nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const 
     std::vector<uint32_t> keys(8 * n);
     for (uint64_t i = 0; i < 8 * n; ++i)
         keys[i] = (uint32_t)h_keys[4 * i] | ((uint32_t)h_keys[4 * i + 1] << 8) | ((uint32_t)h_keys[4 * i + 2] << 16) | ((uint32_t)h_keys[4 * i + 3] << 24);
-    std::vector<double> t(2 * 257);
-    {
-        double* x = t.data();
-        double* f = t.data() + 257;
-        const double r = ZIG_R, v = 0.00492867323399;
-        auto pdf = [](double u) { return std::exp(-u * u / 2.0); };
-        x[0] = v / pdf(r); x[1] = r;
-        for (int i = 2; i < 256; ++i) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + pdf(x[i - 1])));
-        x[256] = 0.0;
-        for (int i = 0; i < 257; ++i) f[i] = pdf(x[i]);
-    }
+    std::vector<double> t(kZigTables, kZigTables + 2 * 257);
     uint32_t* d_keys = nullptr; double* d_zig = nullptr; uint64_t* d_words = nullptr;
     HIP_TRY(hipMalloc(&d_keys, keys.size() * 4));
     HIP_TRY(hipMalloc(&d_zig, t.size() * 8));

@@ -140,6 +140,7 @@ struct KParams {
     uint64_t lr_rmax, lr_cap;
     uint64_t draw_end, row_base;  // LrWrap draw kernel: chains draw until draw_count == draw_end; output row = draw_count - row_base
     double* out_mm_eigvals;
+    const uint8_t* init_mask;     // init kernel: chains with mask 0 are left untouched (null = all)
 };
 
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
@@ -2057,10 +2058,13 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
+        if (P.init_mask && !P.init_mask[chain]) continue;                  // per-chain Chain::set_position: the others keep their state
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
-        stepsize_adapt_reset(sc, P.s, P.s.initial_step);                    // stepsize::Strategy::new (stepsize/adapt.rs:67-72)
+        // stepsize::Strategy::new (stepsize/adapt.rs:67-72) belongs to the chain's construction: only the first
+        // set_position of a chain does it (mm_id is still -1); a retry after BadInitGrad keeps the adaptation state
+        if (sc.mm_id < 0) stepsize_adapt_reset(sc, P.s, P.s.initial_step);
         Tile<DPL> x, gx;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
@@ -2077,13 +2081,18 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         if (status == NM_CHAIN_OK) {
             // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
             if constexpr (lr_trait<Dens>::value) {
-                // LowRankMassMatrixStrategy::init (adapt/low_rank.rs:299-317): add_draw(point), update_from_grad
-                sc.lr_start = 0; sc.lr_len = 0; sc.lr_split = 0; sc.lr_pending = LR_IDLE;
+                // LowRankMassMatrixStrategy::init (adapt/low_rank.rs:299-317): add_draw(point), update_from_grad.  (A retry
+                // after a failed set_position pushes again: the reference's deque keeps the failed attempt's point.)
                 lr_push(C, chain, x, gx);
             } else {
-            C.storeP(x, E_DM); C.storeP(x, B_DM);
-            C.storeP(gx, E_GM); C.storeP(gx, B_GM);
-            sc.cnt_fg = 1; sc.cnt_bg = 1;
+                // DiagAdaptStrategy::init: add_sample on all four estimators.  The first call of a chain sets the means
+                // (count 1); a retry after BadInitGrad accumulates, exactly as the reference's second init does.
+                Tile<DPL> m_, v_;
+                sc.cnt_fg += 1; sc.cnt_bg += 1;
+                C.loadP(m_, E_DM); C.loadP(v_, E_DV); running_variance_add_regs(m_, v_, sc.cnt_fg, x); C.storeP(m_, E_DM); C.storeP(v_, E_DV);
+                C.loadP(m_, E_GM); C.loadP(v_, E_GV); running_variance_add_regs(m_, v_, sc.cnt_fg, gx); C.storeP(m_, E_GM); C.storeP(v_, E_GV);
+                C.loadP(m_, B_DM); C.loadP(v_, B_DV); running_variance_add_regs(m_, v_, sc.cnt_bg, x); C.storeP(m_, B_DM); C.storeP(v_, B_DV);
+                C.loadP(m_, B_GM); C.loadP(v_, B_GV); running_variance_add_regs(m_, v_, sc.cnt_bg, gx); C.storeP(m_, B_GM); C.storeP(v_, B_GV);
             }
             mass_matrix_from_grad(C, x, gx);
             status = stepsize_init(C, x);                             // step_size.init (adapt_strategy.rs:117-118)

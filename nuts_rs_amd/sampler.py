@@ -247,16 +247,31 @@ class ChainBatch:
                                                     self.logp.dim, x0.ctypes.data))
         return x0
 
-    def set_position(self, x0, raise_on_error=True):
-        """`Chain::set_position` for every chain; x0 is [n_chains, dim].  Returns per-chain status codes."""
+    def set_position(self, x0, raise_on_error=True, mask=None):
+        """`Chain::set_position` for every chain; x0 is [n_chains, dim].  Returns per-chain status codes.
+        mask (bool [n_chains]): only these chains are (re-)initialised, the others keep their whole state."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         if x0.shape != (self.n_chains, self.logp.dim):
             raise ValueError(f"x0 must have shape {(self.n_chains, self.logp.dim)}")
         status = np.zeros(self.n_chains, dtype=np.uint64)
-        rc = _lib.load().nm_engine_set_positions(self._h, x0.ctypes.data, status.ctypes.data)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        rc = _lib.load().nm_engine_set_positions_masked(self._h, x0.ctypes.data, m.ctypes.data if m is not None else None,
+                                                        status.ctypes.data)
         if rc != 0 and raise_on_error:
             check(rc)
         return status
+
+    def init_with_retries(self, x0=None, max_tries=500, raise_on_error=True):
+        """The init loop of the reference's ChainProcess (src/sampler.rs:1126-1147): every chain whose initial point fails
+        with BadInitGrad draws its next init_position and tries again (at most 500 times), without touching the chains
+        that started.  Returns (status [n_chains], tries [n_chains])."""
+        status, tries = np.zeros(self.n_chains, dtype=np.uint64), np.zeros(self.n_chains, dtype=np.uint64)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        rc = _lib.load().nm_engine_init_positions_retry(self._h, x.ctypes.data if x is not None else None, max_tries,
+                                                        status.ctypes.data, tries.ctypes.data)
+        if rc != 0 and raise_on_error:
+            check(rc)
+        return status, tries
 
     def draw(self):
         """One `Chain::draw` per chain -> (positions [n_chains, dim], [Progress])."""
@@ -390,14 +405,22 @@ class ChainBatch:
         return _lib.load().nm_engine_stream(self._h)
 
 
-def sample(settings: DiagNutsSettings, logp: LogpSpec, x0=None, chain_id_offset=0, device=-1):
+def sample(settings: DiagNutsSettings, logp: LogpSpec, x0=None, chain_id_offset=0, device=-1, chunk_bytes=0):
     """The reference's `Sampler` loop for every chain (src/sampler.rs:1120-1199): init, num_tune + num_draws draws.
 
     Returns (positions [num_tune+num_draws, n_chains, dim], stats)."""
     batch = ChainBatch(settings, logp, settings.num_chains, chain_id_offset, device)
-    if x0 is None:
-        x0 = batch.init_positions_uniform()
-    batch.set_position(x0)
-    out = batch.draw_many(settings.num_tune + settings.num_draws)
+    batch.init_with_retries(x0)                      # up to 500 initial points per chain, like the reference
+    total = settings.num_tune + settings.num_draws
+    # in chunks: a call stages its whole [draws][chains][dim] trace on the device before copying it out
+    per_draw = settings.num_chains * (logp.dim * 8 + STATS_DTYPE.itemsize)
+    chunk = max(1, min(total, (chunk_bytes or (1 << 30)) // per_draw))
+    pos, st = [], []
+    done = 0
+    while done < total:
+        n = min(chunk, total - done)
+        p, q = batch.draw_many(n)
+        pos.append(p); st.append(q)
+        done += n
     batch.close()
-    return out
+    return np.concatenate(pos), np.concatenate(st)

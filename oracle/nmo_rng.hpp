@@ -123,18 +123,16 @@ struct UniformF64 {
     }
 };
 
+// rand_distr ships FIXED tables (ZIG_NORM_X / ZIG_NORM_F: its generator's doubles after a '%.18f' round trip); they are
+// restated by tools/gen_ziggurat_tables.py into nmo_zig_tables.hpp as hex floats — no run-time libm, same bits everywhere.
+#include "nmo_zig_tables.hpp"
 struct ZigguratTables {
     double x[257], f[257];
     double r;
     ZigguratTables() {
-        r = 3.654152885361008796;
-        const double v = 0.00492867323399;
-        auto pdf = [](double t) { return std::exp(-t * t / 2.0); };
-        x[0] = v / pdf(r);
-        x[1] = r;
-        for (int i = 2; i < 256; ++i) x[i] = std::sqrt(-2.0 * std::log(v / x[i - 1] + pdf(x[i - 1])));
-        x[256] = 0.0;
-        for (int i = 0; i < 257; ++i) f[i] = pdf(x[i]);
+        static const double X[257] = NM_ZIG_NORM_X, F[257] = NM_ZIG_NORM_F;
+        r = NM_ZIG_NORM_R;
+        for (int i = 0; i < 257; ++i) { x[i] = X[i]; f[i] = F[i]; }
     }
 };
 static inline const ZigguratTables& zig_tables() { static ZigguratTables t; return t; }

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libnuts_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("nuts_oracle.cpp", "nmo_math.hpp", "nmo_rng.hpp", "nmo_nuts.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("nuts_oracle.cpp", "nmo_math.hpp", "nmo_rng.hpp", "nmo_zig_tables.hpp", "nmo_nuts.hpp")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH

@@ -21,6 +21,10 @@ class FakeBatch:
     def init_positions_uniform(self):
         return np.zeros((self.n, self.dim))
 
+    def init_with_retries(self, x0=None, max_tries=500):
+        self.set_position(self.init_positions_uniform() if x0 is None else x0)
+        return None, None
+
     def set_position(self, x0):
         assert x0.shape == (self.n, self.dim)
 

@@ -530,3 +530,37 @@ def test_k4_full_size_one_gpu():
     by_group = mu.reshape(20, C_ // 8, 8).mean(axis=(0, 1))          # chains by their position inside the wavefront
     assert np.ptp(by_group) < 0.25
     assert 0.7 < st["mean_tree_accept"].mean() < 0.9 and st["diverging"].mean() < 0.02
+
+
+def test_init_retry_loop_matches_reference_semantics(oracle):
+    """The ChainProcess init loop (src/sampler.rs:1133-1147): a chain whose first initial point is rejected (BadInitGrad:
+    an iid normal started exactly at its mean has a zero whitened gradient) takes its next init_position; the chains that
+    started are not touched.  The oracle does the same two `set_position` calls on that chain."""
+    dim, n = 20, 6
+    s = N.DiagNutsSettings(num_chains=n, seed=13, num_tune=60)
+    logp = N.LogpSpec.iid_normal(dim, 3.0)
+    b = N.ChainBatch(s, logp, n)
+    x0 = b.init_positions_uniform()
+    x0[1] = 3.0
+    x0[4, 7] = np.nan                                   # non-finite start: BadInitGrad as well
+    status, tries = b.init_with_retries(x0)
+    assert (status == 0).all() and list(tries) == [1, 2, 1, 1, 2, 1]
+    L = N.load_library()
+    x1 = np.empty_like(x0)
+    L.nm_init_positions_uniform_at(s.seed, 0, n, dim, 0, x1.ctypes.data)     # the retry of a chain = its init_position #0
+    pos, st = b.draw_many(90)
+    b.close()
+    so = oracle_settings(oracle, s)
+    for c in range(n):
+        ch = oracle.Chain(so, logp.kind, dim, logp.params, oracle.gpu_cfg(64), chain_id=c)
+        rc = ch.set_position(x0[c])
+        if c in (1, 4):
+            assert rc == 1                               # ST_BAD_INIT
+            assert ch.set_position(x1[c]) == 0
+        else:
+            assert rc == 0
+        for t in range(90):
+            p, q, rc = ch.draw()
+            assert rc == 0
+            assert (p.view(np.uint64) == pos[t, c].view(np.uint64)).all(), (c, t)
+            assert q["n_steps"] == st["n_steps"][t, c] and q["step_size"] == st["step_size"][t, c]

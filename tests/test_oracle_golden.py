@@ -72,8 +72,15 @@ def test_standard_normal_ziggurat(oracle):
     x, f = np.empty(257), np.empty(257)
     L.nmo_zig_tables(x, f)
     assert x[1] == 3.654152885361008796 and x[256] == 0.0
-    assert abs(x[0] - 3.910757959537090045) < 1e-12          # v / f(r), the published ZIG_NORM_X[0]
-    assert (np.diff(x) < 0).all() and abs(f[256] - 1.0) < 1e-15
+    assert x[0] == 3.910757959537090045 and x[2] == 3.449278298560964462   # rand_distr's ZIG_NORM_X[0], [2] as printed there
+    assert (np.diff(x) < 0).all() and f[256] == 1.0
+    # the tables are fixed constants ('%.18f' round trip of the generator's doubles), the same in the engine's header
+    for v in np.concatenate([x, f]):
+        assert float("%.18f" % v) == v
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nuts_rs_amd", "csrc", "zig_tables.hpp")).read()
+    vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+", hdr)]
+    assert vals[:257] == list(x) and vals[257:514] == list(f)
     key = (C.c_uint8 * 32).from_buffer_copy(bytes(range(32)))
     n = 200000
     out = np.empty(n)
