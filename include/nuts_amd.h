@@ -248,9 +248,11 @@ typedef struct nm_engine_config {
     uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
     uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
                                     * 0 = auto (when there are more chains than resident wavefronts, ~2048), 1 = never, 2 = whenever the kernel applies */
+    uint64_t chain_tiles;          /* one transformation shared by all chains (nm_engine_set_transform per_chain = 0, freeze_transform) on
+                                    * the full-precision normal, dim and rank multiples of 8 and <= 256: draw 16 chains per block with the
+                                    * dense products on the matrix cores (v_mfma_f64_16x16x4_f64).  0 = auto (whenever it applies), 1 = never */
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
-    uint64_t reserved[1];
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 
@@ -348,6 +350,8 @@ nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, uint64_t n_e
  * h_vecs [n_chains][max_rank][dim], h_mu_low_rank [n_chains][dim]. */
 nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_sqrt, double* h_vecs, double* h_mu_low_rank);
 uint64_t  nm_engine_lowrank_max_rank(const nm_engine* e);
+/* draw launches served by the 16-chains-per-block matrix-core kernel so far (nm_engine_config.chain_tiles) */
+uint64_t  nm_engine_tile_launches(const nm_engine* e);
 
 /* Current per-chain quantities, host copies ([n_chains][dim] unless noted). */
 nm_status nm_engine_get_positions(nm_engine* e, double* h_x);

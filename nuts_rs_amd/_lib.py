@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
-    "nm_init_positions_uniform_at",
+    "nm_init_positions_uniform_at", "nm_engine_tile_launches",
 ]
 
 
@@ -63,7 +63,7 @@ class NmLogpSpec(C.Structure):
 class NmEngineConfig(C.Structure):
     _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
                 ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("lane_groups", C.c_uint64),
-                ("lowrank_max_rank", C.c_uint64), ("reserved", C.c_uint64 * 1)]
+                ("chain_tiles", C.c_uint64), ("lowrank_max_rank", C.c_uint64)]
 
 
 STATS_DTYPE = np.dtype([
@@ -162,6 +162,8 @@ def load():
     L.nm_engine_get_lowrank.argtypes = [vp, vp, vp, vp, vp]
     L.nm_engine_lowrank_max_rank.argtypes = [vp]
     L.nm_engine_lowrank_max_rank.restype = u64
+    L.nm_engine_tile_launches.argtypes = [vp]
+    L.nm_engine_tile_launches.restype = u64
     L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_last_error.restype = C.c_char_p

@@ -22,15 +22,23 @@ namespace nm {
 #define NM_HD __host__ __device__ __forceinline__
 NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+// Tile mode (nuts_tile.hpp): a block holds 16 independent chains, one wavefront each, so "the chain's block" is the
+// wavefront: tid() is the lane, chain-wide synchronisation is wave-local; real block barriers exist only in the tile
+// kernel's own rendezvous code.  A translation unit is compiled entirely in one mode.
+#ifndef NM_TILE_MODE
+#define NM_TILE_MODE 0
+#endif
+#define NM_ONE_WAVE_BLOCK (NM_TILE_MODE || blockDim.x == 64)
 NM_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 // Block-wide synchronisation point.  With one wavefront per block the LDS pipeline is already in order (a lane sees
 // what another lane of its wave wrote earlier), so nothing has to be waited for: __syncthreads() would still stall
 // on every outstanding global store (s_waitcnt vmcnt(0)) — a compiler-level barrier is all that is needed.
 NM_DEV void block_sync(bool single_wave) {
-    if (single_wave) asm volatile("" ::: "memory");
+    if (single_wave || NM_TILE_MODE) asm volatile("" ::: "memory");
     else __syncthreads();
 }
-NM_DEV int tid() { return (int)threadIdx.x; }          // thread within the chain's block (64*W threads)
+NM_DEV void chain_sync() { block_sync(false); }         // all threads of the CHAIN (the block, or in tile mode the wavefront)
+NM_DEV int tid() { return NM_TILE_MODE ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }   // thread within the chain's block (64*W threads)
 // wave index inside the block; IS wave-uniform, but anything derived from threadIdx is divergent to the compiler
 // unless it goes through readfirstlane (guide T20) — and values loaded through a "divergent" index poison everything
 NM_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -323,7 +331,7 @@ struct DevRng {
     }
     NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)cap; }
     NM_DEV void refill() {
-        block_sync(blockDim.x == 64);
+        block_sync(NM_ONE_WAVE_BLOCK);
         base = pos & ~15ull;
         cap = RNG_CACHE_WORDS;
         if (tid() < RNG_CACHE_WORDS / 16) {
@@ -335,7 +343,7 @@ struct DevRng {
             dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
             dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
         }
-        block_sync(blockDim.x == 64);
+        block_sync(NM_ONE_WAVE_BLOCK);
     }
     NM_DEV uint32_t next_u32() {
         if (!has(1)) refill();
@@ -414,7 +422,7 @@ NM_DEV void fill_standard_normals(DevRng& rng, double* stage, int count, ZigTabl
             i += 1;
         }
     }
-    __syncthreads();
+    chain_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -17,6 +17,11 @@
 
 using namespace nm;
 
+// the matrix-core kernel for shared matrices lives in its own (tile-mode) translation unit: kern_tile_mvn_prec.hip.
+// POD mirror of nm::tile::TileMats (nuts_tile.hpp) — that header switches the whole TU to tile mode, so it is not included here.
+namespace nm { namespace tile { struct TileMats { const double *ut, *u, *p; int dim, rank, dim_kp, rank_kp, dim_st, rank_st; }; } }
+namespace nm { hipError_t launch_tile_mvn_prec(int dpl, int query, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream, int* occ); }
+
 #include "zig_tables.hpp"
 // rand_distr's ZIG_NORM_X then ZIG_NORM_F (257 + 257 fixed constants; tools/gen_ziggurat_tables.py)
 static const double kZigX[257] = NM_ZIG_NORM_X, kZigF[257] = NM_ZIG_NORM_F;
@@ -309,6 +314,13 @@ struct nm_engine {
     uint64_t lr_threads = 0;
     uint64_t lr_updates = 0, lr_rounds = 0;  // estimator calls / pause-resume rounds so far
     double lr_host_seconds = 0.0;
+    // shared transformation + full-precision normal: 16 chains per block, products on the matrix cores (nuts_tile.hpp)
+    bool tile_active = false;
+    tile::TileMats tile_mats = {};
+    double *d_tile_ut = nullptr, *d_tile_u = nullptr, *d_tile_p = nullptr;
+    unsigned tile_grid = 0;
+    uint64_t tile_launches = 0;
+    std::vector<double> h_params;           // the density's parameters (the tile kernel packs P from them)
 };
 
 static void engine_free(nm_engine* e) {
@@ -326,6 +338,9 @@ static void engine_free(nm_engine* e) {
     if (e->d_lrvec) (void)hipFree(e->d_lrvec);
     if (e->d_lrval) (void)hipFree(e->d_lrval);
     if (e->d_lrwin) (void)hipFree(e->d_lrwin);
+    if (e->d_tile_ut) (void)hipFree(e->d_tile_ut);
+    if (e->d_tile_u) (void)hipFree(e->d_tile_u);
+    if (e->d_tile_p) (void)hipFree(e->d_tile_p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -417,7 +432,15 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         }
     }
     const size_t pvec_bytes = (size_t)n_chains * NUM_PSLOT * dpad * sizeof(double);
-    const size_t svec_bytes = (size_t)(e->n_waves > e->group_grid ? e->n_waves : e->group_grid) * nsslot * dpad * sizeof(double);
+    {   // the matrix-core kernel's grid: 16-chain tiles on resident blocks (one 16-wave block fills a CU's wave slots)
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+        const uint64_t n_tiles = (n_chains + 15) / 16;
+        e->tile_grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(cus > 0 ? cus : 1));
+    }
+    size_t scratch_slots = e->n_waves > e->group_grid ? e->n_waves : e->group_grid;
+    if (lr && logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1) scratch_slots = std::max<size_t>(scratch_slots, (size_t)e->tile_grid * 16);
+    const size_t svec_bytes = scratch_slots * nsslot * dpad * sizeof(double);
     E_TRY(hipMalloc(&e->d_pvec, pvec_bytes));
     E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_svec, svec_bytes));
@@ -429,6 +452,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMalloc(&e->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
     if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    if (lr && logp->kind == NM_LOGP_MVN_PREC) e->h_params.assign(logp->h_params, logp->h_params + logp->n_params);
     if (lr) {   // eigenvector slots, eigenvalue arrays and the window of draws / gradients of every chain
         // the estimator's rank is <= min(dim, 2 n_draws); a transformation given from outside may have any rank <= dim
         const uint64_t most = s.freeze_transform ? logp->dim : std::min<uint64_t>(logp->dim, 2 * (s.num_tune + 1));
@@ -621,8 +645,42 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
         sc[c].lr_pending = LR_SET_TRANSFORM;            // committed by the next launch (LowRankMassMatrix::update)
     }
     HIP_TRY(hipMemcpy(e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    // One transformation for all chains, frozen, on the full-precision normal: the draws can run 16 chains per block with
+    // U', U and P on the matrix cores (nuts_tile.hpp).  The matrices are packed in MFMA operand order once, here.
+    e->tile_active = false;
+    if (!per_chain && e->s.freeze_transform && e->logp_kind == NM_LOGP_MVN_PREC && e->cfg.chain_tiles != 1 && e->wpc == 1 &&
+        (e->dpl == 2 || e->dpl == 4) && dim <= 256 && n_eig >= 8 && n_eig <= 256 && dim % 8 == 0 && n_eig % 8 == 0 && !e->h_params.empty() &&
+        sc[0].lr_upd_ok) {
+        auto pack = [](uint64_t R, uint64_t K, auto&& elem) {      // [stripes][kpairs][64 lanes][2]
+            const uint64_t st = (R + 15) / 16, kp = (K + 7) / 8;
+            std::vector<double> out(st * kp * 128, 0.0);
+            for (uint64_t s_ = 0; s_ < st; ++s_)
+                for (uint64_t q = 0; q < kp; ++q)
+                    for (uint64_t l = 0; l < 64; ++l)
+                        for (uint64_t j = 0; j < 2; ++j) {
+                            const uint64_t row = 16 * s_ + (l & 15), k = 8 * q + 4 * j + (l >> 4);
+                            out[((s_ * kp + q) * 64 + l) * 2 + j] = (row < R && k < K) ? elem(row, k) : 0.0;
+                        }
+            return out;
+        };
+        const double* P_ = e->h_params.data();
+        const std::vector<double> ut = pack(n_eig, dim, [&](uint64_t k, uint64_t d) { return h_vecs[k * dim + d]; });
+        const std::vector<double> u = pack(dim, n_eig, [&](uint64_t d, uint64_t k) { return h_vecs[k * dim + d]; });
+        const std::vector<double> pp = pack(dim, dim, [&](uint64_t d, uint64_t j) { return P_[j * dim + d]; });
+        auto up = [&](double** dst, const std::vector<double>& src) -> hipError_t {
+            if (*dst) (void)hipFree(*dst);
+            *dst = nullptr;
+            hipError_t er = hipMalloc(dst, src.size() * 8);
+            return er != hipSuccess ? er : hipMemcpy(*dst, src.data(), src.size() * 8, hipMemcpyHostToDevice);
+        };
+        HIP_TRY(up(&e->d_tile_ut, ut)); HIP_TRY(up(&e->d_tile_u, u)); HIP_TRY(up(&e->d_tile_p, pp));
+        e->tile_mats = {e->d_tile_ut, e->d_tile_u, e->d_tile_p, (int)dim, (int)n_eig, (int)((dim + 7) / 8), (int)((n_eig + 7) / 8),
+                        (int)((dim + 15) / 16), (int)((n_eig + 15) / 16)};
+        e->tile_active = true;
+    }
     return NM_OK;
 }
+extern "C" uint64_t nm_engine_tile_launches(const nm_engine* e) { return e ? e->tile_launches : 0; }
 
 extern "C" nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_sqrt, double* h_vecs, double* h_mu_lr) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
@@ -652,7 +710,11 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
     std::vector<ChainScalars> sc(nc);
     for (;;) {
         HIP_TRY(hipEventRecord(e->ev0, e->stream));
-        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch, true));
+        if (e->tile_active) {
+            HIP_TRY(launch_tile_mvn_prec(e->dpl, 0, P, e->tile_mats, e->tile_grid, e->stream, nullptr));
+            e->tile_launches += 1;
+        } else
+            HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch, true));
         HIP_TRY(hipEventRecord(e->ev1, e->stream));
         e->pending_timing = true;
         e->kernel_launches += 1;

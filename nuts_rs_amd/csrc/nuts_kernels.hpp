@@ -21,6 +21,7 @@
 //   src/transform/diagonal.rs:85-265, src/transform/adapt/diagonal.rs:17-236, src/adapt_strategy.rs:77-222,
 //   src/stepsize/adapt.rs:52-272, src/stepsize/dual_avg.rs:34-166, src/chain.rs:137-188.
 #pragma once
+#include <type_traits>
 #include "dev_math.hpp"
 #include "../../include/nuts_amd.h"
 
@@ -439,6 +440,10 @@ template <class D>
 struct LrWrap : D {};
 template <class D> struct lr_trait { static constexpr bool value = false; };
 template <class D> struct lr_trait<LrWrap<D>> { static constexpr bool value = true; };
+// densities of the tile kernel (nuts_tile.hpp) set kTile: products with the SHARED matrices (U', U, P) are rendezvous
+// GEMMs of the block's 16 chains on the matrix cores
+template <class D, class = void> struct tile_trait { static constexpr bool value = false; };
+template <class D> struct tile_trait<D, typename std::enable_if<D::kTile>::type> { static constexpr bool value = true; };
 
 // ---------------------------------------------------------------------------------------------
 // Per-wave context: everything a chain keeps in registers / SGPRs while its kernel runs
@@ -454,8 +459,8 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
 template <int DPL, int W, class Dens>
 struct BlockShared {      // LDS of one block (one block = W waves = one resident chain)
     uint32_t rng_cache[RNG_CACHE_WORDS];
-    double sig[64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
-    double mu[64 * W * DPL];      // DiagMassMatrix mean
+    double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
+    double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
     double red[2 * RED_MAX_VALUES * W];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
     double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
@@ -578,9 +583,9 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
         uint64_t* dst = reinterpret_cast<uint64_t*>(&sh.sc[W == 1 ? 0 : wave_id()]);
         constexpr int NW = (int)(sizeof(ChainScalars) / 8);
         static_assert(sizeof(ChainScalars) % 8 == 0 && NW <= 64, "ChainScalars must be <= 64 u64 words");
-        __syncthreads();
+        chain_sync();
         if (lane_id() < NW) dst[lane_id()] = src[lane_id()];
-        __syncthreads();
+        chain_sync();
     }
     C.red.init(sh.red);
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
@@ -590,7 +595,7 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_end(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
     C.sc.rng_pos = C.rng.pos;
-    __syncthreads();
+    chain_sync();
     {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(&C.sc);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&C.P.sc[chain]);
@@ -614,6 +619,7 @@ struct Pt {
 // `which` = 0: lambda^1/2, 1: lambda^-1/2.
 template <int DPL, int W, class Dens>
 NM_DEV void lr_apply(ChainCtx<DPL, W, Dens>& C, int which, Tile<DPL>& v) {
+    if constexpr (tile_trait<Dens>::value) { C.dens.tile_apply(which, v); return; }
     const int r = (int)C.sc.lr_rank;
     if (r == 0) return;
     constexpr int NB = DPL >= 8 ? 2 : 4;          // eigenvectors in flight (register budget)
@@ -1388,6 +1394,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         C.loadP(gx, P_GX);
         if constexpr (lr_trait<Dens>::value) {                   // low_rank.rs:302-314
             transform_to_z(C, x, E.z);
+            if constexpr (tile_trait<Dens>::value) C.dens.tile_skip_density();   // keeps the block's (apply, density, apply) cadence
             transform_to_gz(C, gx, E.g);
         } else {
         C.loadP(isig, P_ISIG);

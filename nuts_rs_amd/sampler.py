@@ -202,7 +202,7 @@ class ChainBatch:
 
     def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
                  chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0, waves_per_chain: int = 0,
-                 grid_blocks: int = 0, lane_groups: int = 0, lowrank_max_rank: int = 0):
+                 grid_blocks: int = 0, lane_groups: int = 0, lowrank_max_rank: int = 0, chain_tiles: int = 0):
         self.settings = settings
         self.logp = logp
         self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
@@ -212,7 +212,7 @@ class ChainBatch:
         L.nm_engine_config_default(C.byref(cfg))
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
         cfg.waves_per_chain, cfg.grid_blocks, cfg.lane_groups = waves_per_chain, grid_blocks, lane_groups
-        cfg.lowrank_max_rank = lowrank_max_rank
+        cfg.lowrank_max_rank, cfg.chain_tiles = lowrank_max_rank, chain_tiles
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()
@@ -239,6 +239,10 @@ class ChainBatch:
     def group_launches(self) -> int:
         """Draw launches served by the 8-chains-per-wavefront kernel (small chains, after warm-up)."""
         return int(_lib.load().nm_engine_group_launches(self._h))
+
+    def tile_launches(self) -> int:
+        """Draw launches served by the 16-chains-per-block matrix-core kernel (shared transformation, nuts_tile.hpp)."""
+        return int(_lib.load().nm_engine_tile_launches(self._h))
 
     def init_positions_uniform(self):
         """x0 ~ U(-1,1) from each chain's outer generator: `CpuMath::init_position` in Sampler order."""

@@ -33,6 +33,8 @@ struct MathCfg {
     int64_t reduce_mode = REDUCE_REF_SIMD;
     int64_t simd_lanes = 4;     // REDUCE_REF_SIMD: f64 lanes of the SIMD register (1, 2, 4, 8)
     int64_t gpu_threads = 64;   // REDUCE_GPU: threads cooperating on one chain (64 * waves)
+    int64_t lr_seq_dots = 0;    // the low-rank transformation's U'v as sequential fma dot products (the engine's matrix-core
+                                // kernel for shared matrices: an MFMA accumulates over the inner index in ascending order)
 };
 
 static inline uint64_t f2u(double x) { uint64_t u; std::memcpy(&u, &x, 8); return u; }
@@ -192,6 +194,14 @@ struct Ctx {
         double result = simd_combine(acc.data(), L);
         for (size_t i = nvec * L; i < n; ++i) result += a[i] * b[i];
         return result;
+    }
+
+    // U_k . v of apply_lowrank_transform (cpu_math.rs:350-357; faer's own order is not reproducible)
+    double lowrank_dot(const double* a, const double* b, size_t n) const {
+        if (!cfg.lr_seq_dots) return vector_dot(a, b, n);
+        double acc = 0.0;
+        for (size_t i = 0; i < n; ++i) acc = std::fma(a[i], b[i], acc);
+        return acc;
     }
 
     // reference src/math/util.rs:221-347 (scalar_prods3): s=(p1+p2)-n1 ; (sum s*x, sum s*y)

@@ -312,7 +312,7 @@ struct MassMatrix : DiagMassMatrix {
         if (rank == 0) return;
         const size_t n = v.size();
         Vec sc(rank);
-        for (size_t k = 0; k < rank; ++k) sc[k] = m.vector_dot(&vecs[k * n], v.data(), n);
+        for (size_t k = 0; k < rank; ++k) sc[k] = m.lowrank_dot(&vecs[k * n], v.data(), n);
         for (size_t k = 0; k < rank; ++k) sc[k] *= vals[k] - 1.0;
         for (size_t k = 0; k < rank; ++k)
             for (size_t i = 0; i < n; ++i) v[i] = std::fma(vecs[k * n + i], sc[k], v[i]);

@@ -67,22 +67,28 @@ def lowrank_settings(**kw):
     return N.LowRankNutsSettings(**kw)
 
 
-def run_fixed(oracle, logp, settings, n_chains, transform, n_draws, waves_per_chain=0, dims_per_lane=0):
+def run_fixed(oracle, logp, settings, n_chains, transform, n_draws, waves_per_chain=0, dims_per_lane=0, chain_tiles=0,
+              expect_tiles=None, splits=()):
     x0 = oracle.init_positions_uniform(settings.seed, 0, n_chains, logp.dim)
-    b = N.ChainBatch(settings, logp, n_chains, waves_per_chain=waves_per_chain, dims_per_lane=dims_per_lane)
+    b = N.ChainBatch(settings, logp, n_chains, waves_per_chain=waves_per_chain, dims_per_lane=dims_per_lane, chain_tiles=chain_tiles)
     assert (b.set_position(x0) == 0).all()
     b.set_transform(*transform)
-    pos, st = b.draw_many(n_draws)
+    cuts = [0] + [c for c in splits if 0 < c < n_draws] + [n_draws]
+    parts = [b.draw_many(hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    pos, st = np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
     tpc = b.threads_per_chain()
+    tiles = b.tile_launches() > 0              # the matrix-core kernel sums U'v sequentially: the oracle's lr_seq_dots mode
+    if expect_tiles is not None:
+        assert tiles == expect_tiles
     b.close()
-    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, settings), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc),
-                                        n_chains, x0, n_draws, n_threads=8, transform=transform)
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, settings), logp.kind, logp.dim, logp.params,
+                                        oracle.gpu_cfg(tpc, lr_seq_dots=int(tiles)), n_chains, x0, n_draws, n_threads=8, transform=transform)
     assert failed == 0
     return pos, st, pos_o, st_o
 
 
 @pytest.mark.parametrize("case", ["dim10_rank3_shared", "dim100_rank6_per_chain", "dim40_full_rank", "dim300_rank12_two_waves",
-                                  "dim256_rank256_mvn"])
+                                  "dim256_rank256_mvn", "dim256_rank256_mvn_one_chain_per_block"])
 def test_fixed_transform_chains_bit_exact(oracle, case):
     rng = np.random.default_rng(abs(hash(case)) % 2**31)
     kw = {}
@@ -104,11 +110,30 @@ def test_fixed_transform_chains_bit_exact(oracle, case):
     if logp is None:
         logp = N.LogpSpec.diag_normal(np.exp(rng.uniform(-2, 2, dim)))
     s = lowrank_settings(num_chains=n, seed=31, num_tune=draws - 20, freeze_transform=True)
+    if case == "dim256_rank256_mvn":
+        kw = dict(expect_tiles=True)                     # shared + frozen + full-precision normal: the matrix-core kernel
+    elif case.endswith("one_chain_per_block"):
+        kw = dict(chain_tiles=1, expect_tiles=False)
     pos, st, pos_o, st_o = run_fixed(oracle, logp, s, n, tr, draws, **kw)
     assert_bit_exact(pos, st, pos_o, st_o)
     assert (st["transformation_update_id"][0] == 1).all() and (st["num_eigenvalues"][0] == len(tr[2].reshape(-1, tr[2].shape[-1])[0])).all()
-    if case == "dim256_rank256_mvn":   # the exact preconditioner whitens the target: shallow trees at a large step size
+    if case.startswith("dim256_rank256_mvn"):   # the exact preconditioner whitens the target: shallow trees at a large step size
         assert st["depth"][-10:].mean() <= 4.5 and st["step_size"][-1].min() > 0.25
+
+
+@pytest.mark.parametrize("dim,rank,n_chains", [(64, 16, 21), (128, 64, 40), (256, 32, 35), (200, 200, 16)])
+def test_matrix_core_kernel_bit_exact(oracle, dim, rank, n_chains):
+    """nuts_tile.hpp: 16 chains per block, U'z / U s / P x as MFMA products over the block's column tile.  Ragged chain
+    counts (empty columns in the last tile), several tiles per block, launches cut in the middle, dims that are not 256."""
+    rng = np.random.default_rng(dim + rank)
+    prec, sigma = correlated_precision(rng, dim, 4)
+    w, u = np.linalg.eigh(sigma)
+    keep = np.argsort(np.abs(np.log(w)))[::-1][:rank]
+    tr = (np.exp(rng.normal(0, 0.2, dim)), rng.normal(0, 0.5, dim), w[keep], np.ascontiguousarray(u[:, keep].T), rng.normal(0, 0.1, dim))
+    s = lowrank_settings(num_chains=n_chains, seed=17, num_tune=40, freeze_transform=True)
+    pos, st, pos_o, st_o = run_fixed(oracle, N.LogpSpec.mvn_precision(prec), s, n_chains, tr, 60, expect_tiles=True, splits=(1, 33))
+    assert_bit_exact(pos, st, pos_o, st_o)
+    assert len(np.unique(st["depth"])) >= 2                       # trees of different sizes inside a tile
 
 
 def estimator_pair(oracle):
@@ -234,13 +259,14 @@ def test_k5_full_size_properties(oracle):
     pos2, st2 = b.draw_many(draws - 50)
     pos, st = np.concatenate([pos1, pos2]), np.concatenate([st1, st2])
     tpc = b.threads_per_chain()
+    assert b.tile_launches() == 2                                   # both launches ran on the matrix cores
     b.close()
     assert (st["chain_status"] == 0).all() and st["diverging"].mean() < 1e-3
     sample = pos[tune:].reshape(-1, dim)
     z = sample @ (u / np.sqrt(w))                                   # whitened draws ~ N(0, I)
     assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
     assert np.abs(np.cov(z.T) - np.eye(dim)).max() < 0.06
-    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc), 2, x0[:2], draws,
-                                        n_threads=2, transform=tr)
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc, lr_seq_dots=1), 2,
+                                        x0[:2], draws, n_threads=2, transform=tr)
     assert failed == 0
     assert_bit_exact(pos[:, :2], st[:, :2], pos_o, st_o)

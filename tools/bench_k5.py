@@ -48,7 +48,7 @@ def main():
     keep = np.argsort(np.abs(np.log(w)))[::-1][:r]            # the r eigenvalues furthest from 1
     tr = (np.ones(D), np.zeros(D), w[keep], np.ascontiguousarray(u[:, keep].T), np.zeros(D))
     s = N.LowRankNutsSettings(num_chains=C, seed=20260928, num_tune=a.tune, num_draws=a.draws, freeze_transform=True)
-    b = N.ChainBatch(s, N.LogpSpec.mvn_precision(prec), C, lowrank_max_rank=r)
+    b = N.ChainBatch(s, N.LogpSpec.mvn_precision(prec), C, lowrank_max_rank=r, chain_tiles=0 if a.mode == "shared" else 1)
     b.set_position(b.init_positions_uniform())
     t = time.time()
     b.set_transform(*tr)
@@ -71,7 +71,7 @@ def main():
     flop_per_leapfrog = 2.0 * (4 * D * r + D * D)            # 2 flop per fma: U'v and U s for x and for g_z, P x for the density
     out = {"config": f"K5: N(0, Sigma) full Sigma dim {D} x {C} chains, low-rank transformation rank {r} ({a.mode}), frozen; "
                      f"step size adapted over {a.tune} draws",
-           "mode": a.mode, "leapfrogs_per_s": steps / dt, "M1_steps_dims_per_s": steps * D / dt, "draws_per_s_per_chain": a.draws / dt,
+           "mode": a.mode, "matrix_core_launches": b.tile_launches(), "leapfrogs_per_s": steps / dt, "M1_steps_dims_per_s": steps * D / dt, "draws_per_s_per_chain": a.draws / dt,
            "leapfrogs_per_draw": steps / (a.draws * C), "mean_depth": float(st["depth"].mean()), "step_size_mean": float(st["step_size"][-1].mean()),
            "divergence_rate": float(st["diverging"].mean()), "kernel_ms": c["kernel_ms"], "wall_s": dt, "tune_s": t_tune, "upload_s": t_up,
            "f64_dense_TFLOPs": steps * flop_per_leapfrog / kern_s / 1e12,
