@@ -80,7 +80,7 @@ template <bool SCALE>
 NM_DEV v4d gemm_stripe(const double* packed, int s, int kpairs, const double* b, v4d acc, const TileShared& T) {
     const int l = lane_id(), kk = l >> 4, c = l & 15;
     const double2* ap = reinterpret_cast<const double2*>(packed) + (size_t)s * (size_t)kpairs * 64 + l;
-    const double* scale = T.scale[SCALE ? T.which[c] : 0];
+    const double* scale = T.scale[SCALE ? (T.which[c] & 1) : 0];
 #pragma unroll 4
     for (int q = 0; q < kpairs; ++q) {
         const double2 a = ap[(size_t)q * 64];
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64 * TC) void nuts_tile_draw_kernel(const KParams P
                 T.mu[i] = i < (int)P.dpad ? pv[(size_t)P_MU * P.dpad + i] : 0.0;
             }
             for (int i = (int)threadIdx.x; i < TD * TC; i += 64 * TC) { T.zin[i] = 0.0; T.sbuf[i] = 0.0; }
+            if (threadIdx.x < TC) T.which[threadIdx.x] = 0;       // columns of absent chains stay empty, with a valid scale index
         }
         __syncthreads();
         ChainCtx<DPL, 1, Dens> C(P, sh[w].sc[0]);
