@@ -10,3 +10,4 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT -o write -- python tools/hbm_probe.py run --i
 F=$(find $OUT -name fetch_results.db | head -1); D=$(dirname "$F")
 python tools/hbm_probe.py calibrate "$D" $OUT/hbm_calibration.json --rates $OUT/probe_rates.json > $OUT/calibrate.log 2>&1
 cat $OUT/probe_rates.json; cat $OUT/calibrate.log | tail -30
+find $OUT -name "*_results.db" -delete   # the summaries are what travels back (gpurun merges at most 64 MiB)

@@ -13,3 +13,4 @@ D=$(dirname $(find $OUT -name trace_results.db | head -1))
 python tools/rocprof_summary.py trace $D/trace_results.db $OUT/kernel_trace.txt > /dev/null
 python tools/rocprof_summary.py pmc $D $OUT/pmc_k2.json nuts_draw_kernel $OUT > /dev/null
 ls -la $OUT
+find $OUT -name "*_results.db" -delete   # the summaries are what travels back (gpurun merges at most 64 MiB)

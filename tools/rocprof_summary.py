@@ -79,8 +79,47 @@ def pmc(d, out, sub="nuts_draw_kernel", logdir=None):
     print(json.dumps(res, indent=1))
 
 
+def k5(d, out, sub, logdir):
+    """counters of the LAST dispatch of the kernel `sub` (bench_k5.py's timed launch) + the bench line of the un-profiled run"""
+    c = sqlite3.connect(os.path.join(d, "trace_results.db"))
+    durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + sub + "%",))]
+    res = {"kernel": sub, "dispatches": len(durs), "timed_launch_duration_ns": durs[-1] if durs else None}
+    for f in ("mfma", "sq", "lds", "fetch", "write", "tcc"):
+        p = os.path.join(d, f + "_results.db")
+        if os.path.exists(p):
+            for k, v in counters(p, sub).items():
+                res[k] = v[-1]
+    try:
+        res["bench"] = json.loads(open(os.path.join(logdir, "bench.json")).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+    g = res.get
+    if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE"):
+        # MfmaUtil of rocprofv3's derived metrics: busy cycles summed over SIMDs / (GPU active cycles x SIMDs); 256 CUs x 4
+        res["mfma_util"] = res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 1024.0)
+    if g("SQ_INSTS_VALU_MFMA_MOPS_F64") and res["timed_launch_duration_ns"]:
+        res["mfma_f64_TFLOPs"] = res["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / res["timed_launch_duration_ns"] / 1e3
+        res["mfma_f64_frac_of_78.6TF"] = res["mfma_f64_TFLOPs"] / 78.6
+    if g("SQ_WAVE_CYCLES"):
+        wc = res["SQ_WAVE_CYCLES"]
+        res["issue"] = {k: res.get(cn, 0.0) / wc for k, cn in (("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_frac", "SQ_WAIT_INST_ANY"),
+                        ("active_inst_frac", "SQ_ACTIVE_INST_ANY"), ("valu_active_frac", "SQ_ACTIVE_INST_VALU"), ("lds_active_frac", "SQ_ACTIVE_INST_LDS"))}
+    if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+        res["lds_bank_conflict_frac"] = res["SQ_LDS_BANK_CONFLICT"] / res["SQ_LDS_IDX_ACTIVE"]
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        res["hbm_bytes"] = res["FETCH_SIZE"] * 2048.0 + res["WRITE_SIZE"] * 1024.0
+        if res["timed_launch_duration_ns"]:
+            res["hbm_GBps"] = res["hbm_bytes"] / res["timed_launch_duration_ns"]
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum"):
+        res["l2_hit_rate"] = res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "k5":
+        k5(*sys.argv[2:6])
     else:
         pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:6]))
