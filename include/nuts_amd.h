@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 7
+#define NM_ABI_VERSION 8
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -138,6 +138,21 @@ void nm_settings_default_low_rank(nm_settings* s);
                                     full-P form of the MvNormal fixture, src/transform/mod.rs:98-112; defined by this repo) */
 
 #define NM_LOGP_MODULE 5         /* a user density compiled into its own shared object (see below) */
+#define NM_LOGP_HOST_CALLBACK 6  /* the slow path: a HOST function with the reference's own shape, evaluated once per leapfrog
+                                    through a mailbox in pinned host memory (see nm_host_logp_fn) */
+
+/* `CpuLogpFunc::logp(&mut self, position: &[f64], gradient: &mut [f64]) -> Result<f64, Self::LogpError>`
+ * (reference src/math/cpu_math.rs:885-891) as a C function pointer: fills gradient[dim] and *logp and returns
+ *   0  Ok(logp)
+ *   1  Err(e) with e.is_recoverable() == true   -> the leapfrog is a divergence with `energy_error: None`
+ *                                                  (src/math/math.rs:9-13, src/dynamics/transformed_hamiltonian.rs:562-578)
+ *   2  Err(e) with e.is_recoverable() == false  -> the chain stops: NutsError::LogpFailure (src/nuts.rs:15, :231),
+ *                                                  NM_CHAIN_LOGP_FATAL in its status
+ * `chain` is the global chain id (the reference builds one density per chain, src/sampler.rs:1121-1124: a callback may
+ * keep per-chain state in ctx).  Called from the engine's service threads, concurrently for DIFFERENT chains, never
+ * concurrently for one chain.  Besides the leapfrogs the engine evaluates the chosen point of every draw once more
+ * (it keeps positions, not gradients, of the tree's candidates). */
+typedef int (*nm_host_logp_fn)(void* ctx, uint64_t chain, uint64_t dim, const double* position, double* gradient, double* logp);
 
 typedef struct nm_logp_spec {
     uint64_t      kind;
@@ -145,6 +160,9 @@ typedef struct nm_logp_spec {
     uint64_t      n_params;
     const double* h_params;      /* host pointer, n_params doubles, copied at engine creation */
     const char*   module_path;   /* NM_LOGP_MODULE: path of the density module (.so); NULL otherwise */
+    nm_host_logp_fn host_fn;     /* NM_LOGP_HOST_CALLBACK: the function and its context; NULL otherwise */
+    void*         host_ctx;
+    uint64_t      host_threads;  /* NM_LOGP_HOST_CALLBACK: service threads calling host_fn (0 = min(cores, 16)) */
 } nm_logp_spec;
 
 /* ---------------------------------------------------------------------------------------------
@@ -352,6 +370,8 @@ nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_
 uint64_t  nm_engine_lowrank_max_rank(const nm_engine* e);
 /* draw launches served by the 16-chains-per-block matrix-core kernel so far (nm_engine_config.chain_tiles) */
 uint64_t  nm_engine_tile_launches(const nm_engine* e);
+/* calls of the host density function so far (NM_LOGP_HOST_CALLBACK) */
+uint64_t  nm_engine_host_logp_calls(const nm_engine* e);
 
 /* Current per-chain quantities, host copies ([n_chains][dim] unless noted). */
 nm_status nm_engine_get_positions(nm_engine* e, double* h_x);

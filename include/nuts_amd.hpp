@@ -107,24 +107,38 @@ struct LogpSpec {
     uint64_t kind = NM_LOGP_IID_NORMAL, dim = 0;
     std::vector<double> params;
     std::string module_path;
-    static LogpSpec iid_normal(uint64_t dim, double mu = 3.0) { return {NM_LOGP_IID_NORMAL, dim, {mu}, ""}; }
+    nm_host_logp_fn host_fn = nullptr;   // NM_LOGP_HOST_CALLBACK: a `CpuLogpFunc::logp` on the host (src/math/cpu_math.rs:885-891)
+    void* host_ctx = nullptr;
+    uint64_t host_threads = 0;
+    static LogpSpec make(uint64_t kind, uint64_t dim, std::vector<double> params, std::string path) {
+        LogpSpec l;
+        l.kind = kind; l.dim = dim; l.params = std::move(params); l.module_path = std::move(path);
+        return l;
+    }
+    static LogpSpec iid_normal(uint64_t dim, double mu = 3.0) { return make(NM_LOGP_IID_NORMAL, dim, {mu}, ""); }
     static LogpSpec diag_normal(std::vector<double> precision_diag) {
         const uint64_t d = precision_diag.size();
-        return {NM_LOGP_DIAG_NORMAL, d, std::move(precision_diag), ""};
+        return make(NM_LOGP_DIAG_NORMAL, d, std::move(precision_diag), "");
     }
-    static LogpSpec funnel(uint64_t dim = 101) { return {NM_LOGP_FUNNEL, dim, {}, ""}; }
+    static LogpSpec funnel(uint64_t dim = 101) { return make(NM_LOGP_FUNNEL, dim, {}, ""); }
     static LogpSpec eight_schools() {
-        return {NM_LOGP_EIGHT_SCHOOLS, 10, {28., 8., -3., 7., -1., 1., 18., 12., 15., 10., 16., 11., 9., 11., 10., 18.}, ""};
+        return make(NM_LOGP_EIGHT_SCHOOLS, 10, {28., 8., -3., 7., -1., 1., 18., 12., 15., 10., 16., 11., 9., 11., 10., 18.}, "");
     }
     static LogpSpec mvn_precision(uint64_t dim, std::vector<double> precision_row_major) {
-        return {NM_LOGP_MVN_PREC, dim, std::move(precision_row_major), ""};
+        return make(NM_LOGP_MVN_PREC, dim, std::move(precision_row_major), "");
     }
     static LogpSpec module(uint64_t dim, std::string path, std::vector<double> params = {}) {
-        return {NM_LOGP_MODULE, dim, std::move(params), std::move(path)};
+        return make(NM_LOGP_MODULE, dim, std::move(params), std::move(path));
+    }
+    // the slow, fully general route: fn(ctx, chain, dim, position, gradient, &logp) -> 0 ok | 1 recoverable | 2 fatal
+    static LogpSpec host_callback(uint64_t dim, nm_host_logp_fn fn, void* ctx = nullptr, uint64_t threads = 0) {
+        LogpSpec l = make(NM_LOGP_HOST_CALLBACK, dim, {}, "");
+        l.host_fn = fn; l.host_ctx = ctx; l.host_threads = threads;
+        return l;
     }
     nm_logp_spec to_c() const {
         return {kind, dim, (uint64_t)params.size(), params.empty() ? nullptr : params.data(),
-                module_path.empty() ? nullptr : module_path.c_str()};
+                module_path.empty() ? nullptr : module_path.c_str(), host_fn, host_ctx, host_threads};
     }
 };
 

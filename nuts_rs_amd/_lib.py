@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
-    "nm_init_positions_uniform_at", "nm_engine_tile_launches",
+    "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_host_logp_calls",
 ]
 
 
@@ -57,7 +57,12 @@ class NmSettings(C.Structure):
 
 class NmLogpSpec(C.Structure):
     _fields_ = [("kind", C.c_uint64), ("dim", C.c_uint64), ("n_params", C.c_uint64), ("h_params", C.c_void_p),
-                ("module_path", C.c_char_p)]
+                ("module_path", C.c_char_p), ("host_fn", C.c_void_p), ("host_ctx", C.c_void_p), ("host_threads", C.c_uint64)]
+
+
+# nm_host_logp_fn: (ctx, chain, dim, position*, gradient*, logp*) -> 0 ok | 1 recoverable error | 2 fatal
+HOST_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double))
 
 
 class NmEngineConfig(C.Structure):
@@ -164,6 +169,8 @@ def load():
     L.nm_engine_lowrank_max_rank.restype = u64
     L.nm_engine_tile_launches.argtypes = [vp]
     L.nm_engine_tile_launches.restype = u64
+    L.nm_engine_host_logp_calls.argtypes = [vp]
+    L.nm_engine_host_logp_calls.restype = u64
     L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_last_error.restype = C.c_char_p

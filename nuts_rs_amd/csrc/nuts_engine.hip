@@ -193,6 +193,7 @@ static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, co
         case NM_LOGP_FUNNEL: return launch_funnel_lr(dpl, w, kind, P, grid, stream, occ);
         case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools_lr(dpl, w, kind, P, grid, stream, occ);
         case NM_LOGP_MVN_PREC: return launch_mvn_prec_lr(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_HOST_CALLBACK: return launch_host_cb_lr(dpl, w, kind, P, grid, stream, occ);
         }
         return hipErrorInvalidValue;
     }
@@ -202,6 +203,7 @@ static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, co
     case NM_LOGP_FUNNEL: return launch_funnel(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools(dpl, w, kind, P, grid, stream, occ);
     case NM_LOGP_MVN_PREC: return launch_mvn_prec(dpl, w, kind, P, grid, stream, occ);
+    case NM_LOGP_HOST_CALLBACK: return launch_host_cb(dpl, w, kind, P, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }
@@ -248,6 +250,10 @@ static nm_status check_logp(const nm_logp_spec* l) {
         for (uint64_t i = 0; i < l->dim; ++i)
             for (uint64_t j = 0; j < i; ++j)
                 if (l->h_params[i * l->dim + j] != l->h_params[j * l->dim + i]) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_MVN_PREC: the precision matrix must be symmetric (entry %llu,%llu)", (unsigned long long)i, (unsigned long long)j);
+        return NM_OK;
+    }
+    if (l->kind == NM_LOGP_HOST_CALLBACK) {
+        if (!l->host_fn) return fail(NM_ERR_INVALID_ARG, "NM_LOGP_HOST_CALLBACK needs host_fn");
         return NM_OK;
     }
     if (l->kind == NM_LOGP_MODULE) {
@@ -321,10 +327,22 @@ struct nm_engine {
     unsigned tile_grid = 0;
     uint64_t tile_launches = 0;
     std::vector<double> h_params;           // the density's parameters (the tile kernel packs P from them)
+    // NM_LOGP_HOST_CALLBACK: mailboxes in pinned host memory and the threads that answer them
+    nm_host_logp_fn cb_fn = nullptr;
+    void* cb_ctx = nullptr;
+    unsigned char* cb_mail = nullptr;       // host pointer (hipHostMalloc, mapped, coherent)
+    unsigned char* cb_mail_dev = nullptr;   // the same memory as the device sees it
+    uint64_t cb_stride = 0;
+    std::vector<std::thread> cb_threads;
+    std::atomic<int> cb_stop{0}, cb_active{0};
+    std::atomic<uint64_t> cb_calls{0};
 };
 
 static void engine_free(nm_engine* e) {
     if (!e) return;
+    e->cb_stop.store(1);
+    for (auto& t : e->cb_threads) if (t.joinable()) t.join();
+    if (e->cb_mail) (void)hipHostFree(e->cb_mail);
     if (e->module_handle) dlclose(e->module_handle);
     for (void* q : e->staging) if (q) (void)hipFree(q);
     if (e->d_pvec) (void)hipFree(e->d_pvec);
@@ -419,7 +437,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const int gs = grp::group_size(logp->dim);
-        const bool group_density = logp->kind != NM_LOGP_MODULE || (gs && e->module_group_lanes == gs);   // every built-in density has a group form
+        const bool group_density = (logp->kind != NM_LOGP_MODULE && logp->kind != NM_LOGP_HOST_CALLBACK) || (logp->kind == NM_LOGP_MODULE && gs && e->module_group_lanes == gs);   // every built-in density has a group form
         if (!lr && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
@@ -503,6 +521,44 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     }
     P.x0 = e->d_x0;
     P.lrvec = e->d_lrvec; P.lrval = e->d_lrval; P.lrwin = e->d_lrwin; P.lr_rmax = e->lr_rmax; P.lr_cap = e->lr_cap;
+    if (logp->kind == NM_LOGP_HOST_CALLBACK) {
+        e->cb_fn = logp->host_fn; e->cb_ctx = logp->host_ctx;
+        e->cb_stride = ((sizeof(CbMail) + 2 * logp->dim * sizeof(double)) + 127) / 128 * 128;
+        E_TRY(hipHostMalloc((void**)&e->cb_mail, n_chains * e->cb_stride, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(e->cb_mail, 0, n_chains * e->cb_stride);
+        E_TRY(hipHostGetDevicePointer((void**)&e->cb_mail_dev, e->cb_mail, 0));
+        P.cb_mail = e->cb_mail_dev; P.cb_stride = e->cb_stride;
+        unsigned nt = (unsigned)(logp->host_threads ? logp->host_threads : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+        if (nt > n_chains) nt = (unsigned)n_chains;
+        for (unsigned t = 0; t < nt; ++t)
+            e->cb_threads.emplace_back([e, t, nt]() {
+                // thread t answers the mailboxes of chains t, t + nt, ...: a chain is never evaluated by two threads at once
+                std::vector<double> x(e->dim), g(e->dim);
+                unsigned idle = 0;
+                while (!e->cb_stop.load(std::memory_order_relaxed)) {
+                    if (!e->cb_active.load(std::memory_order_acquire)) { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
+                    bool any = false;
+                    for (uint64_t c = t; c < e->n_chains; c += nt) {
+                        CbMail* m = reinterpret_cast<CbMail*>(e->cb_mail + c * e->cb_stride);
+                        const uint64_t req = __atomic_load_n(&m->req, __ATOMIC_ACQUIRE);
+                        if (req == __atomic_load_n(&m->resp, __ATOMIC_RELAXED)) continue;
+                        any = true;
+                        double* mx = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(m) + sizeof(CbMail));
+                        double* mg = mx + e->dim;
+                        memcpy(x.data(), mx, e->dim * sizeof(double));
+                        double lp = 0.0;
+                        int st = e->cb_fn(e->cb_ctx, e->cfg.chain_id_offset + c, e->dim, x.data(), g.data(), &lp);
+                        if (st < 0 || st > 2) st = 2;
+                        memcpy(mg, g.data(), e->dim * sizeof(double));
+                        m->logp = lp; m->status = st;
+                        __atomic_store_n(&m->resp, req, __ATOMIC_RELEASE);
+                        e->cb_calls.fetch_add(1, std::memory_order_relaxed);
+                    }
+                    if (any) idle = 0;
+                    else if (++idle > 64) std::this_thread::yield();
+                }
+            });
+    }
     E_TRY(hipStreamSynchronize(e->stream));
 #undef E_TRY
     *out = e;
@@ -560,8 +616,10 @@ extern "C" nm_status nm_engine_set_positions_masked(nm_engine* e, const double* 
         HIP_TRY(hipMemcpyAsync(e->d_init_mask, h_mask, e->n_chains, hipMemcpyHostToDevice, e->stream));
         P.init_mask = e->d_init_mask;
     }
+    e->cb_active.store(1, std::memory_order_release);
     HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->lr));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->cb_active.store(0, std::memory_order_release);
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
     uint64_t bad = 0, fatal = 0, min_draws = ~0ull;
@@ -681,6 +739,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
     return NM_OK;
 }
 extern "C" uint64_t nm_engine_tile_launches(const nm_engine* e) { return e ? e->tile_launches : 0; }
+extern "C" uint64_t nm_engine_host_logp_calls(const nm_engine* e) { return e ? e->cb_calls.load() : 0; }
 
 extern "C" nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_sqrt, double* h_vecs, double* h_mu_lr) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
@@ -795,6 +854,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_div_start = out->d_divergence_start; P.out_div_start_grad = out->d_divergence_start_gradient;
     P.out_div_end = out->d_divergence_end;
     P.out_mm_eigvals = out->d_mass_matrix_eigvals;
+    e->cb_active.store(1, std::memory_order_release);   // NM_LOGP_HOST_CALLBACK: the service threads answer until the next synchronize
     if (e->lr) return lr_draw(e, n_draws, P);           // synchronous: the estimator rounds need the host between launches
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     // small chains, many of them: the several-chains-per-wavefront kernels compute the same draws and statistics
@@ -815,6 +875,7 @@ extern "C" nm_status nm_engine_synchronize(nm_engine* e) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->cb_active.store(0, std::memory_order_release);
     return collect_timing(e);
 }
 extern "C" nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats) {
@@ -1140,7 +1201,7 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
                                        double* d_logp_out, double* d_kinetic_out, double* d_energy_error_out,
                                        void* stream) {
     nm_status st = check_logp(logp);
-    if (st == NM_OK && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "nm_leapfrog_batch covers the built-in densities only");
+    if (st == NM_OK && (logp->kind == NM_LOGP_MODULE || logp->kind == NM_LOGP_HOST_CALLBACK)) return fail(NM_ERR_UNSUPPORTED, "nm_leapfrog_batch covers the built-in densities only");
     if (st != NM_OK) return st;
     st = ensure_device(-1);
     if (st != NM_OK) return st;

@@ -142,6 +142,9 @@ struct KParams {
     uint64_t draw_end, row_base;  // LrWrap draw kernel: chains draw until draw_count == draw_end; output row = draw_count - row_base
     double* out_mm_eigvals;
     const uint8_t* init_mask;     // init kernel: chains with mask 0 are left untouched (null = all)
+    // NM_LOGP_HOST_CALLBACK: one mailbox per chain in pinned host memory (CbMail header, then x[dim], grad[dim])
+    unsigned char* cb_mail;
+    uint64_t cb_stride;           // bytes per mailbox
 };
 
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
@@ -434,6 +437,68 @@ struct EightSchools {
     }
 };
 
+// The slow path of the boundary: a density evaluated by a HOST function pointer with the reference's own shape,
+// `CpuLogpFunc::logp(&mut self, position: &[f64], gradient: &mut [f64]) -> Result<f64, E>` (src/math/cpu_math.rs:885-891),
+// errors classified by `LogpError::is_recoverable` (src/math/math.rs:9-13).  A kernel cannot call the host, so every
+// evaluation is a round trip through the chain's mailbox in pinned, fine-grained host memory: the block writes x,
+// publishes a sequence number (system-scope release), and polls for the answer that the engine's service threads write
+// after calling the user's function (nuts_engine.hip).  Latency ~ PCIe round trip + the callback; it exists so that any
+// CpuLogpFunc drops in, not for throughput.
+struct CbMail { uint64_t req, resp; int64_t status; double logp; };
+struct HostCb {
+    static constexpr bool kNeedsLdsVector = false;
+    static constexpr bool kCanFail = true;
+    NM_DEV void set_lds(double*) {}
+    CbMail* mail = nullptr;
+    double *mx = nullptr, *mg = nullptr;
+    int status = 0;              // of the last evaluation: 0 ok, 1 recoverable error, 2 unrecoverable (or the host never answered)
+    template <int W>
+    NM_DEV void init(const double*, int, Reducer<W>&) {}
+    NM_DEV void bind(const KParams& P, uint64_t chain) {
+        unsigned char* base = P.cb_mail + (size_t)chain * P.cb_stride;
+        mail = reinterpret_cast<CbMail*>(base);
+        mx = reinterpret_cast<double*>(base + sizeof(CbMail));
+        mg = mx + P.dim;
+    }
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = elem_index<W>(k);
+            if (d < dim) __hip_atomic_store(&mx[d], x.a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: x is in host memory before the request is
+        block_sync(W == 1);
+        int failed = 0;
+        if (tid() == 0) {
+            const uint64_t seq = __hip_atomic_load(&mail->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+            __hip_atomic_store(&mail->req, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long t0 = wall_clock64();           // 100 MHz
+            while (__hip_atomic_load(&mail->resp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                __builtin_amdgcn_s_sleep(64);
+                if (wall_clock64() - t0 > 6000000000ull) { failed = 1; break; }      // 60 s without an answer: the chain fails
+            }
+        }
+        failed = R.sum(failed ? 1.0 : 0.0) != 0.0 ? 1 : 0;         // also the block-wide synchronisation point
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const int64_t st = failed ? 2 : __hip_atomic_load(&mail->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        status = __builtin_amdgcn_readfirstlane((int)st);
+        const double lp = __hip_atomic_load(&mail->logp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = elem_index<W>(k);
+            gx.a[k] = (d < dim && status == 0) ? __hip_atomic_load(&mg[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+        }
+        return uniform_f64(status == 0 ? lp : __builtin_nan(""));
+    }
+};
+template <class D, class = void> struct can_fail { static constexpr bool value = false; };
+template <class D> struct can_fail<D, typename std::enable_if<D::kCanFail>::type> { static constexpr bool value = true; };
+// status of the density's last evaluation (0 for densities that cannot fail)
+template <class Ctx_> NM_DEV int dens_status(Ctx_& C) {
+    if constexpr (can_fail<decltype(C.dens)>::value) return C.dens.status; else return 0;
+}
+
 // A density wrapped in LrWrap selects the kernels that carry the low-rank transformation (LowRankMassMatrix, reference
 // src/transform/low_rank.rs) and its adaptation protocol; plain densities compile the diagonal-only code they always had.
 template <class D>
@@ -591,6 +656,7 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
     C.dens.init(P.logp_params, C.dim, C.red);
     C.dens.set_lds(sh.dens_lds);
+    if constexpr (can_fail<Dens>::value) C.dens.bind(P, chain);
 }
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_end(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
@@ -922,6 +988,7 @@ NM_DEV double powi_rs(double a, int32_t b) {
 template <int DPL, int W, class Dens>
 NM_DEV bool init_state(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Pt<DPL>& st, Tile<DPL>& gx) {
     st.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+    if (dens_status(C) != 0) return false;                       // NutsError::LogpFailure: the caller reads dens_status
     if constexpr (lr_trait<Dens>::value) {
         transform_to_z(C, x, st.z);
         transform_to_gz(C, gx, st.g);
@@ -959,7 +1026,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
     Pt<DPL> st;
     {
         Tile<DPL> gx;
-        if (!init_state(C, x, st, gx)) return NM_CHAIN_BAD_INIT;
+        if (!init_state(C, x, st, gx)) return dens_status(C) != 0 ? NM_CHAIN_LOGP_FATAL : NM_CHAIN_BAD_INIT;
     }
     const double logdet = C.sc.mm_logdet;
     sample_velocity(C, st.v);                    // initialize_trajectory(resample) :687-736
@@ -975,6 +1042,10 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
         leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
         const double energy = o.ke - (o.logp + logdet);
         const double err = energy - e0;
+        if (dens_status(C) != 0) {                              // `let LeapfrogResult::Ok(_) = .. else { .. return Ok(()) }` (adapt.rs:122-150)
+            if (it > 0) C.sc.step_size = s.initial_step;
+            return NM_CHAIN_OK;
+        }
         if ((err > 1000.0) | !is_finite(err)) {                 // hard-coded 1000.0 (adapt.rs:118, :142)
             if (it > 0) C.sc.step_size = s.initial_step;
             return NM_CHAIN_OK;
@@ -1347,6 +1418,7 @@ NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b
 struct DrawResult {
     uint64_t depth;
     bool diverging, reached_maxdepth, has_divergence_energy_error;
+    bool has_div_end;            // DivergenceInfo.end_location is Some (None when the divergence is a recoverable logp error)
     double divergence_energy_error;
     int64_t div_start_idx;       // index_in_trajectory of the point the divergent leapfrog started from
     CandRef chosen;
@@ -1441,7 +1513,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         uint64_t xd = ce > mindepth ? ce : mindepth;
         maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
     }
-    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false;
+    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false; R.has_div_end = true;
     R.divergence_energy_error = 0.; R.div_start_idx = 0;
     const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
     bool fatal = false;
@@ -1477,6 +1549,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         {                                                                                                 \
             const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
             const double err_ = energy_ - e0;                                                             \
+            const int dst_ = dens_status(C);   /* logp error (transformed_hamiltonian.rs:562-578) */          \
+            if (dst_ == 2) { stop = STOP_FATAL; }                                                         \
+            else if (dst_ == 1) {              /* recoverable: a divergence without energy error / end point */ \
+                col.register_divergent();                                                                 \
+                R.diverging = true; R.has_divergence_energy_error = false; R.has_div_end = false;         \
+                R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
+                if (want_div) C.storeS((START).z, slot_F(0));                                             \
+                stop = STOP_DIVERGING;                                                                    \
+            } else                                                                                        \
             if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
@@ -1762,7 +1843,7 @@ NM_DEV void write_row(ChainCtx<DPL, W, Dens>& C, double* base, size_t row, const
 // gradient are recomputed with the leapfrog's own operations, hence the same bits.  A start point with index 0 is
 // the trajectory's initial point, whose x and g_x are still in P_X / P_GX.
 template <int DPL, int W, class Dens>
-NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx, size_t row) {
+NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx, size_t row, bool has_end = true) {
     const KParams& P = C.P;
     Tile<DPL> x, gx, zt, sig, mu;
     C.load(sig, C.lsig);
@@ -1780,6 +1861,7 @@ NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx
     }
     write_row(C, P.out_div_start, row, x);
     write_row(C, P.out_div_start_grad, row, gx);
+    if (!has_end) return;
     C.loadS(zt, slot_F(0) + 1);
     if constexpr (lr_trait<Dens>::value) transform_to_x(C, zt, x);
     else {
@@ -1811,7 +1893,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     }
     const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
     if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
-        emit_divergence_vectors(C, R.div_start_idx, row);         // before P_X / P_GX take the new draw
+        emit_divergence_vectors(C, R.div_start_idx, row, R.has_div_end);         // before P_X / P_GX take the new draw
     if (R.chosen.slot == -1 && !sc.px_stale) {                   // the draw is the trajectory's initial point
         C.loadP(x, P_X); C.loadP(gx, P_GX);
         C.loadP(z, P_Z); C.loadP(gz, P_GZ);
@@ -1938,7 +2020,7 @@ NM_DEV bool chain_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
     }
     const size_t row = (size_t)(row_idx * P.n_chains + chain) * P.dim;
     if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
-        emit_divergence_vectors(C, R.div_start_idx, row);
+        emit_divergence_vectors(C, R.div_start_idx, row, R.has_div_end);
     if (R.chosen.slot == -1 && !sc.px_stale) {
         C.loadP(x, P_X); C.loadP(gx, P_GX);
         C.loadP(z, P_Z); C.loadP(gz, P_GZ);
@@ -2084,7 +2166,8 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
 #pragma unroll
         for (int k = 0; k < DPL; ++k) ok = ok && is_finite(gx.a[k]) && is_finite(x.a[k]);
         uint64_t status = NM_CHAIN_OK;
-        if (!C.red.all(ok)) status = NM_CHAIN_BAD_INIT;
+        if (dens_status(C) != 0) status = NM_CHAIN_LOGP_FATAL;      // `?` on the logp error (transformed_hamiltonian.rs:668)
+        else if (!C.red.all(ok)) status = NM_CHAIN_BAD_INIT;
         if (status == NM_CHAIN_OK) {
             // DiagAdaptStrategy::init (adapt/diagonal.rs:209-231): seed the four estimators, mass matrix from |grad|
             if constexpr (lr_trait<Dens>::value) {
@@ -2107,7 +2190,7 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         if (status == NM_CHAIN_OK) {
             Pt<DPL> st;                                               // hamiltonian.init_state (chain.rs:147)
             Tile<DPL> g2;
-            if (!init_state(C, x, st, g2)) status = NM_CHAIN_BAD_INIT;
+            if (!init_state(C, x, st, g2)) status = dens_status(C) != 0 ? NM_CHAIN_LOGP_FATAL : NM_CHAIN_BAD_INIT;
             else {
                 C.storeP(x, P_X); C.storeP(g2, P_GX);
                 C.storeP(st.z, P_Z); C.storeP(st.g, P_GZ);

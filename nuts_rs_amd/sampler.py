@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAmdError, STATS_DTYPE, VECTOR_STATS,
                    check)
 
-LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE = 0, 1, 2, 3, 4, 5
+LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE, LOGP_HOST_CALLBACK = 0, 1, 2, 3, 4, 5, 6
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
 ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
 
@@ -150,6 +150,10 @@ class Progress:                    # src/sampler.rs:165-174, one per chain
     num_steps: int
 
 
+class RecoverableLogpError(Exception):
+    """`LogpError::is_recoverable() == true` (src/math/math.rs:9-13): the leapfrog becomes a divergence, the chain goes on."""
+
+
 @dataclass
 class LogpSpec:
     """A registered device density (the device-side stand-in for a `CpuLogpFunc`, src/math/cpu_math.rs:885-891)."""
@@ -157,6 +161,8 @@ class LogpSpec:
     dim: int
     params: np.ndarray
     module_path: Optional[str] = None
+    host_fn: object = None
+    host_threads: int = 0
 
     @staticmethod
     def iid_normal(dim, mu=3.0):
@@ -191,10 +197,35 @@ class LogpSpec:
         nuts_rs_amd.build.build_density_module builds one from a header that defines the functor)."""
         return LogpSpec(LOGP_MODULE, int(dim), np.asarray(params, dtype=np.float64), module_path=str(module_path))
 
+    @staticmethod
+    def host_callback(dim, logp, threads=0):
+        """A `CpuLogpFunc` on the host (the reference's own density interface, src/math/cpu_math.rs:885-891): `logp(chain,
+        position: ndarray) -> (logp, gradient)`, or raise `RecoverableLogpError` / any other exception (unrecoverable).
+        Evaluated once per leapfrog through the engine's mailbox path: the slow, fully general route."""
+        def trampoline(ctx, chain, d, px, pg, plogp):
+            try:
+                x = np.ctypeslib.as_array(px, shape=(d,))
+                lp, g = logp(int(chain), x.copy())
+                np.ctypeslib.as_array(pg, shape=(d,))[:] = g
+                plogp[0] = lp
+                return 0
+            except RecoverableLogpError:
+                return 1
+            except BaseException:     # noqa: BLE001 — an unrecoverable LogpError
+                return 2
+        spec = LogpSpec(LOGP_HOST_CALLBACK, int(dim), np.zeros(0))
+        spec.host_fn = _lib.HOST_LOGP_FN(trampoline)
+        spec.host_threads = threads
+        return spec
+
     def to_c(self):
         self._keep = np.ascontiguousarray(self.params, dtype=np.float64)
         path = self.module_path.encode() if self.module_path else None
-        return NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data if len(self._keep) else None, path)
+        c = NmLogpSpec(self.kind, self.dim, len(self._keep), self._keep.ctypes.data if len(self._keep) else None, path)
+        if self.host_fn is not None:
+            c.host_fn = C.cast(self.host_fn, C.c_void_p)
+            c.host_threads = self.host_threads
+        return c
 
 
 class ChainBatch:
@@ -239,6 +270,10 @@ class ChainBatch:
     def group_launches(self) -> int:
         """Draw launches served by the 8-chains-per-wavefront kernel (small chains, after warm-up)."""
         return int(_lib.load().nm_engine_group_launches(self._h))
+
+    def host_logp_calls(self) -> int:
+        """Calls of the host density function so far (LogpSpec.host_callback)."""
+        return int(_lib.load().nm_engine_host_logp_calls(self._h))
 
     def tile_launches(self) -> int:
         """Draw launches served by the 16-chains-per-block matrix-core kernel (shared transformation, nuts_tile.hpp)."""

@@ -75,6 +75,10 @@ ESTIMATOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTE
                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
+# CpuLogpFunc::logp shape of the oracle's LOGP_HOST_CALLBACK: (ctx, dim, x*, grad*, logp*) -> 0 ok, 1 recoverable, 2 fatal
+HOST_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
 class RunExtras(C.Structure):
     _fields_ = [("stds", C.c_void_p), ("mean", C.c_void_p), ("vals", C.c_void_p), ("vecs", C.c_void_p),
                 ("mu_lr", C.c_void_p), ("n_eig", C.c_uint64), ("per_chain", C.c_uint64),
@@ -113,6 +117,9 @@ def lib():
     L.nmo_chain_create.restype = C.c_void_p
     L.nmo_chain_create.argtypes = [C.POINTER(Settings), C.c_int64, C.c_uint64, _dp, C.c_uint64,
                                    C.POINTER(MathCfg), C.c_uint64, C.c_void_p]
+    L.nmo_chain_create_callback.restype = C.c_void_p
+    L.nmo_chain_create_callback.argtypes = [C.POINTER(Settings), C.c_uint64, HOST_LOGP_FN, C.c_void_p, C.POINTER(MathCfg),
+                                            C.c_uint64, C.c_void_p]
     L.nmo_chain_destroy.argtypes = [C.c_void_p]
     L.nmo_chain_set_position.argtypes = [C.c_void_p, _dp]
     L.nmo_chain_set_position.restype = C.c_int
@@ -207,15 +214,20 @@ def init_positions_uniform(seed, chain_offset, n_chains, dim):
 class Chain:
     """One oracle chain: the reference's `settings.new_chain(chain, math, rng)` + set_position + draw."""
 
-    def __init__(self, settings, kind, dim, params, cfg, chain_id=0, key=None):
+    def __init__(self, settings, kind, dim, params, cfg, chain_id=0, key=None, callback=None):
+        """callback: an oracle.HOST_LOGP_FN — the density is then LOGP_HOST_CALLBACK (`kind` / `params` unused)."""
         self.dim = dim
         self.cfg = cfg
         self.params = np.ascontiguousarray(params, dtype=np.float64)
         if key is None:
             key = chain_key(settings.seed, chain_id)
         self._key = (C.c_uint8 * 32).from_buffer_copy(key)
-        self._h = lib().nmo_chain_create(C.byref(settings), kind, dim, self.params, len(self.params),
-                                         C.byref(cfg), chain_id, self._key)
+        self._cb = callback
+        if callback is not None:
+            self._h = lib().nmo_chain_create_callback(C.byref(settings), dim, callback, None, C.byref(cfg), chain_id, self._key)
+        else:
+            self._h = lib().nmo_chain_create(C.byref(settings), kind, dim, self.params, len(self.params),
+                                             C.byref(cfg), chain_id, self._key)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,127 @@
+"""The slow path of the drop-in boundary (SURVEY §8(b) "user density"): NM_LOGP_HOST_CALLBACK — a host function with the
+reference's `CpuLogpFunc::logp(position, gradient) -> Result<f64, E>` shape (src/math/cpu_math.rs:885-891), evaluated
+once per leapfrog, with the reference's error taxonomy: recoverable error => divergence with energy_error None
+(src/dynamics/transformed_hamiltonian.rs:562-578), unrecoverable => the chain stops (NutsError::LogpFailure, src/nuts.rs:231).
+Parity against the oracle's LOGP_HOST_CALLBACK on the SAME Python function."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nuts_rs_amd as N
+from helpers import STAT_FIELDS_EXACT, oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+
+def banana(chain, x):
+    """a smooth non-Gaussian density with a plain Python gradient"""
+    a = x[0] * x[0]
+    r = x[1:] - a
+    lp = -0.5 * float(x[0] * x[0]) / 4.0 - 0.5 * float(np.dot(r, r))
+    g = np.empty_like(x)
+    g[1:] = -r
+    g[0] = -x[0] / 4.0 + 2.0 * x[0] * float(r.sum())
+    return lp, g
+
+
+def run_both(oracle, fn_engine, fn_oracle, dim, n, tune, draws, seed=3, low_rank=False):
+    s = (N.LowRankNutsSettings if low_rank else N.DiagNutsSettings)(num_chains=n, seed=seed, num_tune=tune, store_divergences=True)
+    logp = N.LogpSpec.host_callback(dim, fn_engine, threads=2)
+    b = N.ChainBatch(s, logp, n)
+    x0 = b.init_positions_uniform()
+    status = b.set_position(x0, raise_on_error=False)
+    pos, st = b.draw_many(draws, raise_on_error=False)
+    calls = b.host_logp_calls()
+    tpc = b.threads_per_chain()
+    b.close()
+
+    def tramp(ctx, d, px, pg, plogp):
+        try:
+            lp, g = fn_oracle(0, np.ctypeslib.as_array(px, shape=(d,)).copy())
+            np.ctypeslib.as_array(pg, shape=(d,))[:] = g
+            plogp[0] = lp
+            return 0
+        except N.RecoverableLogpError:
+            return 1
+        except BaseException:     # noqa: BLE001
+            return 2
+    cb = oracle.HOST_LOGP_FN(tramp)
+    so = oracle_settings(oracle, s)
+    res = []
+    for c in range(n):
+        ch = oracle.Chain(so, 0, dim, np.zeros(1), oracle.gpu_cfg(tpc), chain_id=c, callback=cb)
+        rc = ch.set_position(x0[c])
+        rows = []
+        if rc == 0:
+            for t in range(draws):
+                p, q, rc2 = ch.draw()
+                rows.append((p, q, rc2))
+                if rc2 != 0:
+                    break
+        res.append((rc, rows))
+    return status, pos, st, res, calls
+
+
+def compare(status, pos, st, res, allow_stop=False):
+    for c, (rc, rows) in enumerate(res):
+        assert int(status[c]) == rc
+        for t, (p, q, rc2) in enumerate(rows):
+            assert int(st["chain_status"][t, c]) == rc2, (c, t)
+            if rc2 != 0:
+                assert allow_stop
+                break
+            assert (p.view(np.uint64) == pos[t, c].view(np.uint64)).all(), (c, t)
+            for f in STAT_FIELDS_EXACT:
+                assert q[f] == st[f][t, c], (f, c, t)
+            assert q["step_size"] == st["step_size"][t, c] and q["energy"] == st["energy"][t, c]
+            a, b = q["divergence_energy_error"], st["divergence_energy_error"][t, c]
+            assert (np.isnan(a) and np.isnan(b)) or a == b
+
+
+def test_host_callback_matches_oracle(oracle):
+    status, pos, st, res, calls = run_both(oracle, banana, banana, 6, 5, 60, 90)
+    compare(status, pos, st, res)
+    # one call per leapfrog + the chosen point of every draw + set_position's (3 + the step-size search)
+    assert calls >= int(st["n_steps"].sum()) + 90 * 5
+
+
+def test_host_callback_low_rank_transformation(oracle):
+    """the same density behind LowRankNutsSettings (the engine's built-in estimator on both... no: on the engine only,
+    so statistics, not bits): the chains run, adapt a low-rank part and sample the banana's moments"""
+    s = N.LowRankNutsSettings(num_chains=8, seed=4, num_tune=200)
+    b = N.ChainBatch(s, N.LogpSpec.host_callback(6, banana, threads=4), 8)
+    b.init_with_retries()
+    pos, st = b.draw_many(400)
+    b.close()
+    sample = pos[200:].reshape(-1, 6)
+    assert (st["chain_status"] == 0).all() and abs(sample[:, 0].mean()) < 0.5 and 2.0 < sample[:, 0].var() < 7.0
+    assert abs((sample[:, 1] - sample[:, 0] ** 2).mean()) < 0.2
+
+
+def test_recoverable_errors_become_divergences(oracle):
+    def walled(chain, x):
+        if x[0] > 1.5:                       # outside the support: a recoverable error, like a failed ODE solve
+            raise N.RecoverableLogpError()
+        lp = -0.5 * float(np.dot(x, x))
+        return lp, -x
+    status, pos, st, res, _ = run_both(oracle, walled, walled, 4, 6, 40, 80, seed=11)
+    compare(status, pos, st, res)
+    div = st["diverging"] != 0
+    assert div.sum() > 5                                           # the wall is hit
+    assert np.isnan(st["divergence_energy_error"][div]).any()      # ... and those divergences carry no energy error
+    assert (pos[..., 0] <= 1.5).all()
+
+
+def test_unrecoverable_error_stops_the_chain(oracle):
+    def fatal_later(chain, x):
+        if abs(x[1]) > 2.2:
+            raise ValueError("not recoverable")
+        return -0.5 * float(np.dot(x, x)), -x
+    status, pos, st, res, _ = run_both(oracle, fatal_later, fatal_later, 3, 6, 30, 120, seed=2)
+    compare(status, pos, st, res, allow_stop=True)
+    stopped = [c for c, (rc, rows) in enumerate(res) if rows and rows[-1][2] != 0]
+    assert stopped, "no chain met the fatal region: pick another seed"
+    for c in stopped:
+        t = len(res[c][1]) - 1
+        assert st["chain_status"][t, c] == 2                       # NM_CHAIN_LOGP_FATAL, exactly where the oracle's chain stops
