@@ -671,6 +671,34 @@ static bool lr_stage_update(nm_engine* e, uint64_t c, ChainScalars& q, uint64_t 
     return true;
 }
 
+// One transformation for ALL chains: staged once on the device, then copied into every chain's slots by a kernel (per chain:
+// sigma, 1/sigma, mean -> P_SIG, P_ISIG, P_MU; mu_lr and the eigenvectors -> lrvec; lambda^(+-1/2) -> lrval; the scalars of the
+// pending LowRankMassMatrix::update -> ChainScalars).  stage: [4 + n_eig][dpad] rows (sigma, 1/sigma, mean, mu_lr, vecs...).
+__global__ __launch_bounds__(256) void lr_broadcast_kernel(const KParams P, const double* stage, const double* vals2, uint64_t n_eig,
+                                                          double logdet, int ok) {
+    const uint64_t dp = P.dpad;
+    for (uint64_t c = blockIdx.x; c < P.n_chains; c += gridDim.x) {
+        ChainScalars& q = P.sc[c];
+        if (ok) {
+            double* pv = P.pvec + (size_t)c * NUM_PSLOT * dp;
+            double* lv = P.lrvec + (size_t)c * (1 + P.lr_rmax) * dp;
+            double* lw = P.lrval + (size_t)c * 2 * P.lr_rmax;
+            for (uint64_t i = threadIdx.x; i < dp; i += blockDim.x) {
+                pv[(size_t)P_SIG * dp + i] = stage[i];
+                pv[(size_t)P_ISIG * dp + i] = stage[dp + i];
+                pv[(size_t)P_MU * dp + i] = stage[2 * dp + i];
+                lv[i] = stage[3 * dp + i];
+            }
+            for (uint64_t i = threadIdx.x; i < n_eig * dp; i += blockDim.x) lv[dp + i] = stage[4 * dp + i];
+            for (uint64_t i = threadIdx.x; i < n_eig; i += blockDim.x) { lw[i] = vals2[i]; lw[P.lr_rmax + i] = vals2[n_eig + i]; }
+        }
+        if (threadIdx.x == 0) {
+            q.lr_upd_ok = ok ? 1 : 0; q.lr_upd_rank = ok ? n_eig : 0; q.lr_upd_logdet = ok ? logdet : 0.0;
+            q.lr_pending = LR_SET_TRANSFORM;
+        }
+    }
+}
+
 extern "C" nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_estimator_fn fn, void* ctx, uint64_t n_threads) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
     if (!e->lr) return fail(NM_ERR_STATE, "the engine was not created with adaptation = NM_ADAPT_LOW_RANK");
@@ -693,8 +721,39 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
     const uint64_t dim = e->dim;
-    for (uint64_t c = 0; c < e->n_chains; ++c) {
+    for (uint64_t c = 0; c < e->n_chains; ++c)
         if (sc[c].lr_pending != LR_IDLE && sc[c].lr_pending != LR_SET_TRANSFORM) return fail(NM_ERR_STATE, "chain %llu is waiting for its estimator", (unsigned long long)c);
+    bool shared_ok = false;
+    if (!per_chain) {      // one upload + a broadcast kernel instead of several copies per chain
+        const uint64_t dp = e->P.dpad;
+        auto finite = [](const double* a, uint64_t n) { for (uint64_t i = 0; i < n; ++i) if (!std::isfinite(a[i])) return false; return true; };
+        shared_ok = finite(h_stds, dim) && finite(h_mean, dim) && (!n_eig || (finite(h_vals, n_eig) && finite(h_vecs, n_eig * dim)));
+        std::vector<double> stage((4 + n_eig) * dp, 0.0), vals2(2 * (n_eig ? n_eig : 1), 0.0);
+        double ld = -0.0;
+        if (shared_ok) {
+            for (uint64_t i = 0; i < dim; ++i) { stage[i] = h_stds[i]; stage[dp + i] = 1.0 / h_stds[i]; stage[2 * dp + i] = h_mean[i]; stage[3 * dp + i] = h_mu_lr[i]; }
+            for (uint64_t k = 0; k < n_eig; ++k) {
+                memcpy(&stage[(4 + k) * dp], h_vecs + k * dim, dim * 8);
+                ld += -0.5 * dlog(h_vals[k]);
+                vals2[k] = std::sqrt(h_vals[k]); vals2[n_eig + k] = 1.0 / vals2[k];
+            }
+        }
+        double *d_stage = nullptr, *d_vals2 = nullptr;
+        HIP_TRY(hipMalloc(&d_stage, stage.size() * 8));
+        HIP_TRY(hipMalloc(&d_vals2, vals2.size() * 8));
+        hipError_t er = hipMemcpyAsync(d_stage, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, e->stream);
+        if (er == hipSuccess) er = hipMemcpyAsync(d_vals2, vals2.data(), vals2.size() * 8, hipMemcpyHostToDevice, e->stream);
+        if (er == hipSuccess) {
+            hipLaunchKernelGGL(lr_broadcast_kernel, dim3((unsigned)std::min<uint64_t>(e->n_chains, 4096)), dim3(256), 0, e->stream, e->P, d_stage, d_vals2,
+                               n_eig, ld, shared_ok ? 1 : 0);
+            er = hipGetLastError();
+        }
+        if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+        (void)hipFree(d_stage); (void)hipFree(d_vals2);
+        if (er != hipSuccess) return fail(NM_ERR_HIP, "broadcast of the transformation: %s", hipGetErrorString(er));
+        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    }
+    for (uint64_t c = 0; per_chain && c < e->n_chains; ++c) {
         const uint64_t k = per_chain ? c : 0;
         hipError_t er;
         (void)lr_stage_update(e, c, sc[c], n_eig, h_stds + k * dim, h_mean + k * dim, h_vals ? h_vals + k * n_eig : nullptr,
@@ -702,7 +761,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
         if (er != hipSuccess) return fail(NM_ERR_HIP, "upload of the transformation: %s", hipGetErrorString(er));
         sc[c].lr_pending = LR_SET_TRANSFORM;            // committed by the next launch (LowRankMassMatrix::update)
     }
-    HIP_TRY(hipMemcpy(e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    if (per_chain) HIP_TRY(hipMemcpy(e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
     // One transformation for all chains, frozen, on the full-precision normal: the draws can run 16 chains per block with
     // U', U and P on the matrix cores (nuts_tile.hpp).  The matrices are packed in MFMA operand order once, here.
     e->tile_active = false;

@@ -3,10 +3,17 @@
 Parity mode needs no collective: chains are independent (reference src/sampler.rs:1105-1126) and the chain RNG
 depends only on (seed, global chain id), so a rank just owns a contiguous block of chain ids.
 
-`pooled_welford` is the merge an OPT-IN pooled-adaptation mode would use (north_star's "cross-chain Welford
-reduction").  It is NOT reference behaviour (every reference chain adapts alone, src/adapt_strategy.rs:24-39) and
-the engine does not use it; it is here with its test so the payload and the math are pinned: per rank
-(count, mean[D], M2[D]) gathered with all_gather and merged with Chan's parallel formula.
+OPT-IN pooled adaptation (north_star's "RCCL cross-chain Welford reduction").  It is NOT reference
+behaviour — every reference chain adapts alone (src/adapt_strategy.rs:24-39) — and it changes results, so it is a
+separate driver, `pooled_warmup`, never the default.  All chains of all ranks share ONE diagonal transformation:
+the engine runs with the transformation frozen (its own mass-matrix adaptation off, step size adapting per chain as
+usual), records draws and gradients of a window in device buffers, each rank reduces its chains' window to
+(count, mean[D], M2[D]) for draws and for gradients on the device, the ranks exchange those 2 (2 D + 1) doubles with
+ONE all_gather per window (torch.distributed: RCCL over xGMI with the nccl backend, issued on a side stream so the next
+window's kernel is already running; gloo in the tests), merge them in rank order with Chan's formula, and every rank
+sets sigma = (var_x / var_g)^(1/4), mean = x_bar + sigma^2 g_bar (the reference's diagonal estimate,
+src/transform/diagonal.rs:107-131) for all its chains with one broadcast upload (nm_engine_set_transform).
+`pooled_welford` is the merge with numpy arrays (pinned by tests/test_distributed_cpu.py).
 """
 import numpy as np
 
@@ -55,3 +62,90 @@ def pooled_welford(local, dist=None):
         t = (float(g[0]), g[1:1 + d].copy(), g[1 + d:].copy())
         out = t if out is None else chan_merge(out, t)
     return out
+
+
+def _partial_device(x):
+    """(count, mean[D], M2[D]) over the rows of a device tensor [n, D] (one pass, in f64, on the tensor's device)."""
+    import torch
+    n = x.shape[0]
+    mean = x.mean(dim=0)
+    m2 = ((x - mean) ** 2).sum(dim=0)
+    return torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=x.device), mean, m2])
+
+
+def _merge_payloads(payloads, d):
+    """Chan merge of gathered [count, mean[D], M2[D]] payloads in rank order (torch tensors on one device)."""
+    n, mean, m2 = payloads[0][0], payloads[0][1:1 + d], payloads[0][1 + d:]
+    for p in payloads[1:]:
+        nb, mb, sb = p[0], p[1:1 + d], p[1 + d:]
+        tot = n + nb
+        delta = mb - mean
+        mean = mean + delta * (nb / tot)
+        m2 = m2 + sb + delta * delta * (n * nb / tot)
+        n = tot
+    return n, mean, m2
+
+
+def pooled_warmup(batch, num_tune, dist=None, windows=None, collective_device=None, on_window=None):
+    """Warm up `batch` (a ChainBatch created from LowRankNutsSettings(freeze_transform=True, num_tune=num_tune)) with ONE
+    diagonal transformation pooled over all chains of all ranks.  Returns the list of (draw index, sigma, mean) updates.
+
+    windows: draw counts of the successive windows (default: the reference's schedule shape — 10-draw windows in the
+    first 30 %, then 80 growing by 1.5x, none in the last 15 % where only the step size adapts).
+    dist: an initialised torch.distributed module or None (single process).  With the nccl backend the payload stays on
+    the GPU (RCCL); with gloo (tests) it goes through the host (`collective_device="cpu"`)."""
+    import torch
+    dim, nc = batch.logp.dim, batch.n_chains
+    if windows is None:
+        early_end, final = int(0.3 * num_tune), num_tune - int(0.15 * num_tune)
+        windows, t, w = [], 0, 80
+        while t + 10 <= early_end:
+            windows.append(10); t += 10
+        while t + w <= final:
+            windows.append(w); t += w; w = max(w + 1, int(round(w * 1.5)))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    cdev = torch.device(collective_device) if collective_device else dev
+    side = torch.cuda.Stream(device=dev)
+    updates, done, pending = [], 0, None
+
+    def finish(p):
+        work, gathered, at = p
+        if work is not None:
+            work.wait()
+        with torch.cuda.stream(side):
+            parts = [g.to(dev) for g in gathered]
+            d2 = 2 * dim + 1
+            _, mx, vx = _merge_payloads([g[:d2] for g in parts], dim)
+            _, mg, vg = _merge_payloads([g[d2:] for g in parts], dim)
+            sigma = torch.sqrt(torch.sqrt(vx / vg))
+            ok = torch.isfinite(sigma) & (sigma > 0)
+            sigma = torch.where(ok, torch.clamp(sigma, 1e-10, 1e10), torch.ones_like(sigma))
+            mean = mx + sigma * sigma * mg
+        side.synchronize()
+        s_h, m_h = sigma.cpu().numpy(), mean.cpu().numpy()
+        batch.set_transform(s_h, m_h, np.zeros(0), np.zeros((0, dim)), np.zeros(dim))
+        updates.append((at, s_h, m_h))
+        if on_window:
+            on_window(at, s_h, m_h)
+
+    for w in windows:
+        pos = torch.empty((w, nc, dim), dtype=torch.float64, device=dev)
+        grad = torch.empty((w, nc, dim), dtype=torch.float64, device=dev)
+        batch.draw_device_ex(w, positions=pos.data_ptr(), gradient=grad.data_ptr())     # the window's kernel
+        if pending is not None:                # the previous window's exchange ran beside this kernel; apply it now
+            finish(pending)
+        done += w
+        with torch.cuda.stream(side):          # this window's partials + the collective, off the engine's stream
+            payload = torch.cat([_partial_device(pos.reshape(-1, dim)), _partial_device(grad.reshape(-1, dim))]).to(cdev)
+            gathered = [torch.empty_like(payload) for _ in range(world)]
+            if world > 1:
+                work = dist.all_gather(gathered, payload, async_op=True)
+            else:
+                gathered, work = [payload], None
+        pending = (work, gathered, done)
+    if pending is not None:
+        finish(pending)
+    if done < num_tune:
+        batch.draw_device(num_tune - done)     # the final window: step size only (reference adapt_strategy.rs:215-221)
+    return updates

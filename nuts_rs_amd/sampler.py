@@ -372,6 +372,17 @@ class ChainBatch:
         fn = L.nm_engine_draw if sync else L.nm_engine_draw_async
         check(fn(self._h, n_draws, C.c_void_p(d_positions or None), C.c_void_p(d_stats or None)))
 
+    def draw_device_ex(self, n_draws, positions=0, stats=0, **vectors):
+        """`expanded_draw` x n_draws with every result left in caller-provided DEVICE buffers (raw pointers): positions,
+        stats and any of VECTOR_STATS by name (e.g. gradient=tensor.data_ptr())."""
+        out = NmDrawOutputs()
+        out.d_positions, out.d_stats = positions or None, stats or None
+        for k, ptr in vectors.items():
+            if k not in VECTOR_STATS:
+                raise ValueError(f"unknown vector statistic {k}")
+            setattr(out, "d_" + k, ptr or None)
+        check(_lib.load().nm_engine_draw_ex(self._h, n_draws, C.byref(out)))
+
     def synchronize(self):
         check(_lib.load().nm_engine_synchronize(self._h))
 

@@ -1,0 +1,79 @@
+"""N > 1 on the GPU: two ranks sharing GPU 0 (gloo), launched like the driver launches bench.py.
+  * parity mode: the concatenated draws of the two ranks ARE the draws of one engine that owns all the chains, bit for bit
+    (chains are independent units; the RNG depends only on (seed, global chain id); no data-path collective)
+  * the opt-in pooled adaptation: both ranks end up with the same pooled transformation, equal to the one a single
+    process computes from the same two partial reductions
+  * bench.py --gpus 2 starts its own ranks and reports the whole job"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import nuts_rs_amd as N
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(mode, outdir, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), mode, str(outdir)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+
+
+def test_two_ranks_equal_one_engine(tmp_path):
+    launch("shard", tmp_path)
+    a, b = (np.load(tmp_path / f"shard_{r}.npz") for r in (0, 1))
+    dim, C_, tune, draws, seed = 24, 20, 60, 30, 77
+    s = N.DiagNutsSettings(num_chains=2 * C_, seed=seed, num_tune=tune)
+    e = N.ChainBatch(s, N.LogpSpec.diag_normal(np.exp(np.linspace(-2, 2, dim))), 2 * C_)
+    e.set_position(e.init_positions_uniform())
+    pos, st = e.draw_many(tune + draws)
+    e.close()
+    both = np.concatenate([a["pos"], b["pos"]], axis=1)
+    assert (both.view(np.uint64) == pos.view(np.uint64)).all()
+    assert (np.concatenate([a["n_steps"], b["n_steps"]], axis=1) == st["n_steps"]).all()
+    assert (np.concatenate([a["chain"], b["chain"]], axis=1) == st["chain"]).all()
+    assert (np.concatenate([a["step"], b["step"]], axis=1) == st["step_size"]).all()
+
+
+def test_pooled_adaptation_two_ranks(tmp_path):
+    launch("pooled", tmp_path)
+    a, b = (np.load(tmp_path / f"pooled_{r}.npz") for r in (0, 1))
+    assert a["sigma"].shape == (3, 24)
+    assert (a["sigma"] == b["sigma"]).all() and (a["mean"] == b["mean"]).all()       # one transformation for the whole job
+    # the target is N(0, diag(1/p)): the pooled sigma approaches its standard deviations, the pooled mean its centre
+    true_sd = np.exp(np.linspace(-2, 2, 24)) ** -0.5
+    assert np.abs(np.log(a["sigma"][-1] / true_sd)).max() < 0.25
+    assert np.abs(a["mean"][-1] / true_sd).max() < 0.5
+    sample = np.concatenate([a["pos"], b["pos"]], axis=1).reshape(-1, 24)
+    assert np.abs(sample.std(axis=0) / true_sd - 1).max() < 0.15
+
+
+def test_bench_starts_its_own_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "6", "--warmup", "2",
+                        "--repeats", "2", "--chains", "64", "--dim", "128", "--num-tune", "30", "--pmc", "off", "--master-port", str(free_port())],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains_per_gpu"] == 64 and d["value"] > 0
+    assert abs(d["leapfrogs_per_draw"] * 6 * 128 * 128 / (d["ms_per_step"] * 6e-3) / d["value"] - 1) < 1e-6   # whole-job aggregate
+    # asking for more ranks than GPUs over RCCL fails loudly instead of running fewer
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--pmc", "off"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"GPU(s) visible" in r.stderr
