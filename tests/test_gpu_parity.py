@@ -564,3 +564,55 @@ def test_init_retry_loop_matches_reference_semantics(oracle):
             assert rc == 0
             assert (p.view(np.uint64) == pos[t, c].view(np.uint64)).all(), (c, t)
             assert q["n_steps"] == st["n_steps"][t, c] and q["step_size"] == st["step_size"][t, c]
+
+
+@pytest.mark.parametrize("config", ["k2", "k3", "k4", "k5_diag"])
+def test_baseline_configs_first_chains_match_oracle(oracle, config):
+    """BASELINE.json's configurations AT THEIR OWN SIZE AND SETTINGS (4096 x 1024 iid normal; funnel 101 x 8192; 8 schools x
+    65536 chains on the several-chains-per-wavefront kernel; the full-precision normal 256 x 4096 with the diagonal
+    adaptation): DiagNutsSettings defaults (400 tuning draws) + 50 draws, and chains 0-3 of that very run compared with the
+    oracle draw for draw, bit for bit — positions, tree sizes, step sizes, energies."""
+    if config == "k2":
+        logp, C_ = N.LogpSpec.iid_normal(1024, 3.0), 4096
+    elif config == "k3":
+        logp, C_ = N.LogpSpec.funnel(101), 8192
+    elif config == "k4":
+        logp, C_ = N.LogpSpec.eight_schools(), 65536
+    else:
+        rng = np.random.default_rng(1)
+        u = np.linalg.qr(rng.normal(size=(256, 4)))[0]
+        sigma = np.eye(256) + u @ np.diag([30.0, 20.0, 10.0, 5.0]) @ u.T
+        p = np.linalg.inv(sigma)
+        logp, C_ = N.LogpSpec.mvn_precision((p + p.T) / 2), 4096
+    tune, draws = 400, 50
+    s = N.DiagNutsSettings(num_chains=C_, seed=20260928, num_tune=tune, num_draws=draws)
+    b = N.ChainBatch(s, logp, C_)
+    x0 = b.init_positions_uniform()
+    status, _ = b.init_with_retries(x0)
+    assert (status == 0).all()
+    # the first four chains' results only: [draws][4][dim] device buffers, the rest of the batch records nothing
+    import torch
+    total = tune + draws
+    pos = torch.empty((total, C_, logp.dim), dtype=torch.float64, device="cuda") if C_ * logp.dim * total * 8 < 4e9 else None
+    if pos is not None:
+        st = torch.zeros((total, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        b.draw_device(total, pos.data_ptr(), st.data_ptr())
+        pos_g = pos[:, :4].cpu().numpy()
+        st_g = np.frombuffer(st[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(total, 4)
+    else:       # K2 / K3 traces are tens of GB: chunks of 50 draws
+        parts = []
+        for lo in range(0, total, 50):
+            n = min(50, total - lo)
+            p_ = torch.empty((n, C_, logp.dim), dtype=torch.float64, device="cuda")
+            q_ = torch.zeros((n, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+            b.draw_device(n, p_.data_ptr(), q_.data_ptr())
+            parts.append((p_[:, :4].cpu().numpy(), np.frombuffer(q_[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(n, 4)))
+            del p_, q_
+        pos_g, st_g = np.concatenate([a for a, _ in parts]), np.concatenate([q for _, q in parts])
+    tpc = b.threads_per_chain()
+    if config == "k4":
+        assert b.group_launches() > 0                    # the 65536-chain job runs 8 chains per wavefront
+    b.close()
+    pos_o, st_o, _, failed = run_oracle(oracle, s, logp, 4, x0[:4], total, gpu_threads=tpc, n_threads=4)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)

