@@ -270,6 +270,7 @@ def main():
         d_pos = torch.empty((args.steps, C_, D), dtype=torch.float64, device=f"cuda:{device_index}")
         d_st = torch.zeros((args.steps, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device=f"cuda:{device_index}")
     p_pos, p_st = (d_pos.data_ptr(), d_st.data_ptr()) if record else (0, 0)
+    torch.cuda.synchronize()       # torch's fill kernels run on torch's stream, the engine on its own
     # ---- adaptation phase (untimed setup; reported)
     barrier()
     t0 = time.perf_counter()

@@ -311,6 +311,8 @@ nm_status nm_init_positions_uniform_at(uint64_t seed, uint64_t chain_id_offset, 
                                        uint64_t attempt, double* h_x0);
 
 /* Advance ALL chains by n_draws draws (`Chain::draw` x n_draws per chain, reference src/chain.rs:151-188).
+ * The engine launches on its OWN non-blocking stream (nm_engine_stream): output buffers must not have work pending on
+ * another stream (e.g. a framework's asynchronous zero-fill) when this is called.
  * The whole loop runs on the device; this call enqueues the launches and returns after they finish.
  *   d_positions : device buffer [n_draws][n_chains][dim] or NULL (positions not recorded)
  *   d_stats     : device buffer [n_draws][n_chains] of nm_draw_stats or NULL

@@ -596,6 +596,7 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
     pos = torch.empty((total, C_, logp.dim), dtype=torch.float64, device="cuda") if C_ * logp.dim * total * 8 < 4e9 else None
     if pos is not None:
         st = torch.zeros((total, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()        # the fill runs on torch's stream, the engine on its own: it must not overtake the draws
         b.draw_device(total, pos.data_ptr(), st.data_ptr())
         pos_g = pos[:, :4].cpu().numpy()
         st_g = np.frombuffer(st[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(total, 4)
@@ -605,6 +606,7 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
             n = min(50, total - lo)
             p_ = torch.empty((n, C_, logp.dim), dtype=torch.float64, device="cuda")
             q_ = torch.zeros((n, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
             b.draw_device(n, p_.data_ptr(), q_.data_ptr())
             parts.append((p_[:, :4].cpu().numpy(), np.frombuffer(q_[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(n, 4)))
             del p_, q_

@@ -59,7 +59,7 @@ def main():
     b.reset_counters()
     st_dev = torch.empty((a.draws, C, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
     pos_dev = torch.empty((a.draws, C, D), dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()       # (allocations / fills on torch's stream are done before the engine's stream writes)
     t = time.time()
     b.draw_device(a.draws, pos_dev.data_ptr(), st_dev.data_ptr())
     dt = time.time() - t
