@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 8
+#define NM_ABI_VERSION 9
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -440,6 +440,50 @@ nm_status nm_scalar_math_batch(uint64_t op, uint64_t n, const double* d_a, const
  * fills d_out[n][count] with the first `count` N(0,1) variates of ChaCha8(key=h_keys[i], stream 0). */
 nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const uint8_t* h_keys /*[n][32]*/,
                                    double* d_out, uint64_t* h_words_consumed /*[n] or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The per-vector seam: `trait Math` (reference src/math/math.rs:15-314) over device vectors, one function per hot-path
+ * method.  An nm_math is one `CpuMath<F>` (src/math/cpu_math.rs:19-41: a density, its dim, a
+ * stream), an nm_vec its `M::Vector` (device resident, opaque).  One chain per Math, one small launch per method: on a
+ * GPU this seam is launch-latency bound — it exists so that code written against `Math` has a target and so that the
+ * fused kernels' building blocks can be tested one by one; throughput lives in the batched engine above.  Every method
+ * runs the engine's arithmetic: FMAs where the reference writes mul_add, reductions in the engine's documented order
+ * (the oracle's gpu_cfg(nm_math_threads)).  Built-in densities only (their `LogpErr` cannot occur).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nm_math nm_math;
+typedef struct nm_vec nm_vec;
+nm_status nm_math_create(const nm_logp_spec* logp, nm_math** out);                    /* CpuMath::new (cpu_math.rs:32-41) */
+void      nm_math_destroy(nm_math* m);
+uint64_t  nm_math_dim(const nm_math* m);                                              /* Math::dim (math.rs:22) */
+uint64_t  nm_math_threads(const nm_math* m);                                          /* threads per vector: fixes the reduction order */
+const char* nm_math_last_error(void);
+nm_status nm_vec_new(nm_math* m, nm_vec** out);                                       /* M13 new_array: zeros (math.rs:24) */
+void      nm_vec_free(nm_vec* v);
+nm_status nm_vec_read_from_slice(nm_math* m, nm_vec* dest, const double* h_source);  /* M13 (math.rs:101) */
+nm_status nm_vec_write_to_slice(nm_math* m, const nm_vec* source, double* h_dest);   /* M13 (math.rs:103) */
+nm_status nm_vec_copy_into(nm_math* m, const nm_vec* source, nm_vec* dest);          /* M13 (math.rs:94) */
+nm_status nm_vec_fill_array(nm_math* m, nm_vec* dest, double value);                 /* M13 (math.rs:119) */
+nm_status nm_vec_array_recip(nm_math* m, const nm_vec* a, nm_vec* dest);             /* M13 (math.rs:125) */
+nm_status nm_vec_axpy_out(nm_math* m, const nm_vec* x, const nm_vec* y, double a, nm_vec* out);     /* M1 out = fma(a, x, y) (math.rs:98) */
+nm_status nm_vec_axpy(nm_math* m, const nm_vec* x, nm_vec* y, double a);             /* M2 y = fma(a, x, y) (math.rs:99) */
+nm_status nm_vec_array_mult(nm_math* m, const nm_vec* a, const nm_vec* b, nm_vec* dest);            /* M3 (math.rs:123-124; dest may be a) */
+nm_status nm_vec_array_vector_dot(nm_math* m, const nm_vec* a, const nm_vec* b, double* out);       /* M4 (math.rs:212) */
+nm_status nm_vec_scalar_prods3(nm_math* m, const nm_vec* positive1, const nm_vec* negative1, const nm_vec* positive2,
+                               const nm_vec* x, const nm_vec* y, double out[2]);     /* M5 (math.rs:75-82) */
+/* M6 array_gaussian (math.rs:213-218): dest_i = stds_i * N(0,1) from ChaCha8(key) at *stream_pos (u32 words), which is advanced */
+nm_status nm_vec_array_gaussian(nm_math* m, const uint8_t key[32], uint64_t* stream_pos, nm_vec* dest, const nm_vec* stds);
+nm_status nm_vec_array_update_variance(nm_math* m, nm_vec* mean, nm_vec* variance, const nm_vec* value, double diff_scale);   /* M7 (math.rs:227-233) */
+nm_status nm_vec_array_update_var_inv_std_draw_grad(nm_math* m, nm_vec* inv_std, nm_vec* std_, const nm_vec* draw_var, const nm_vec* grad_var,
+                                                    uint64_t has_fill_invalid, double fill_invalid, double clamp_lo, double clamp_hi);   /* M8 (math.rs:243-251) */
+nm_status nm_vec_array_update_var_inv_std_grad(nm_math* m, nm_vec* inv_std, nm_vec* std_, const nm_vec* gradient, double fill_invalid,
+                                               double clamp_lo, double clamp_hi);   /* M9 (math.rs:253-260) */
+nm_status nm_vec_array_update_var_inv_std_draw(nm_math* m, nm_vec* inv_std, nm_vec* std_, const nm_vec* draw_var, double scale,
+                                               uint64_t has_fill_invalid, double fill_invalid, double clamp_lo, double clamp_hi);   /* M10 (math.rs:234-242) */
+nm_status nm_vec_array_sum_ln(nm_math* m, const nm_vec* a, double* out);             /* M11 (math.rs:113-117) */
+nm_status nm_vec_array_all_finite(nm_math* m, const nm_vec* a, uint64_t and_nonzero, uint64_t* out);   /* M12 (math.rs:121-122) */
+/* M14 logp_array (math.rs:46-50): fills `gradient`, *logp; *status = 0 ok / 1 recoverable / 2 fatal (always 0 here) */
+nm_status nm_vec_logp_array(nm_math* m, const nm_vec* position, nm_vec* gradient, double* logp, uint64_t* status);
+nm_status nm_vec_sq_norm_sum(nm_math* m, const nm_vec* x, const nm_vec* y, double* out);             /* M15 (math.rs:92) */
 
 /* Chain RNG key derivation (host helper; reference src/sampler.rs:1105-1106, :761). */
 nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]);
