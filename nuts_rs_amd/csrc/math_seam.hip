@@ -209,7 +209,7 @@ hipError_t launch_dens(int dpl, int w, const VArgs& A, hipStream_t st) {
 #define NM_VL(D_, W_) hipLaunchKernelGGL((vec_op_kernel<D_, W_, Dens>), dim3(1), dim3(64 * W_), 0, st, A); return hipGetLastError();
     switch (w * 100 + dpl) {
     case 102: NM_VL(2, 1) case 104: NM_VL(4, 1) case 108: NM_VL(8, 1) case 116: NM_VL(16, 1)
-    case 208: NM_VL(8, 2) case 216: NM_VL(16, 2) case 404: NM_VL(4, 4)
+    case 208: NM_VL(8, 2) case 216: NM_VL(16, 2) case 404: NM_VL(4, 4) case 416: NM_VL(16, 4)
     }
 #undef NM_VL
     return hipErrorInvalidValue;
@@ -252,7 +252,7 @@ extern "C" nm_status nm_math_create(const nm_logp_spec* logp, nm_math** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return mfail(NM_ERR_NO_DEVICE, "no HIP device available; there is no CPU fallback");
     uint64_t dpl = 0, w = 0;
-    if (nm_pick_tiling(logp->dim, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : 0, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 1 : 0, &dpl, &w) != NM_OK || (w == 4 && dpl == 16))
+    if (nm_pick_tiling(logp->dim, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : 0, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 1 : 0, &dpl, &w) != NM_OK)
         return mfail(NM_ERR_UNSUPPORTED, "no tiling for this dim");
     nm_math* m = new (std::nothrow) nm_math();
     if (!m) return mfail(NM_ERR_HIP, "out of host memory");
