@@ -76,17 +76,14 @@ NM_DEV void get_col(const double* buf, int c, Tile<DPL>& t) {
 }
 
 // one 16-row stripe: acc += M[stripe rows][:] B, inner index ascending (an fma chain per output entry)
-template <bool SCALE>
-NM_DEV v4d gemm_stripe(const double* packed, int s, int kpairs, const double* b, v4d acc, const TileShared& T) {
+NM_DEV v4d gemm_stripe(const double* packed, int s, int kpairs, const double* b, v4d acc) {
     const int l = lane_id(), kk = l >> 4, c = l & 15;
     const double2* ap = reinterpret_cast<const double2*>(packed) + (size_t)s * (size_t)kpairs * 64 + l;
-    const double* scale = T.scale[SCALE ? (T.which[c] & 1) : 0];
 #pragma unroll 4
     for (int q = 0; q < kpairs; ++q) {
         const double2 a = ap[(size_t)q * 64];
-        const int r0 = 8 * q + kk, r1 = r0 + 4;
-        double b0 = b[taddr(r0, c)], b1 = b[taddr(r1, c)];
-        if (SCALE) { b0 = b0 * scale[r0]; b1 = b1 * scale[r1]; }      // S' = S (lambda^w - 1): the oracle's `sc[k] *= vals[k] - 1`
+        const int r0 = 8 * q + kk;
+        const double b0 = b[taddr(r0, c)], b1 = b[taddr(r0 + 4, c)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc, 0, 0, 0);
     }
@@ -97,6 +94,14 @@ NM_DEV void store_stripe(double* buf, int s, v4d acc) {
     const int l = lane_id(), g = l >> 4, c = l & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf[taddr(16 * s + g + 4 * r, c)] = acc[r];
+}
+// the same for S = U' z, scaled on the way out: S'[k][c] = S[k][c] (lambda_k^w - 1) with w the scale column c asked for —
+// the oracle's `sc[k] *= vals[k] - 1` (apply_lowrank_transform, cpu_math.rs:360-364)
+NM_DEV void store_stripe_scaled(double* buf, int s, v4d acc, const TileShared& T) {
+    const int l = lane_id(), g = l >> 4, c = l & 15;
+    const double* scale = T.scale[T.which[c] & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int k = 16 * s + g + 4 * r; buf[taddr(k, c)] = acc[r] * scale[k]; }
 }
 NM_DEV v4d load_stripe(const double* buf, int s) {
     const int l = lane_id(), g = l >> 4, c = l & 15;
@@ -131,13 +136,13 @@ NM_DEV bool apply_round(TileRef& X, int which, Tile<DPL>* v, bool may_exit) {
     }
     for (int s = w; s < X.M.rank_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gemm_stripe<false>(X.M.ut, s, X.M.dim_kp, T.zin, acc, T);
-        store_stripe(T.sbuf, s, acc);
+        acc = gemm_stripe(X.M.ut, s, X.M.dim_kp, T.zin, acc);
+        store_stripe_scaled(T.sbuf, s, acc, T);
     }
     tile_barrier();
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = load_stripe(T.zin, s);
-        acc = gemm_stripe<true>(X.M.u, s, X.M.rank_kp, T.sbuf, acc, T);
+        acc = gemm_stripe(X.M.u, s, X.M.rank_kp, T.sbuf, acc);
         store_stripe(T.zin, s, acc);
     }
     tile_barrier();
@@ -153,7 +158,7 @@ NM_DEV void density_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y) {
     tile_barrier();
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gemm_stripe<false>(X.M.p, s, X.M.dim_kp, T.zin, acc, T);
+        acc = gemm_stripe(X.M.p, s, X.M.dim_kp, T.zin, acc);
         store_stripe(T.sbuf, s, acc);
     }
     tile_barrier();

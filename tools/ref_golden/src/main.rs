@@ -7,8 +7,7 @@
 use std::collections::HashMap;
 
 use nuts_rs::{Chain, CpuLogpFunc, CpuMath, CpuMathError, DiagNutsSettings, HasDims, LogpError, Settings};
-use rand::SeedableRng;
-use rand_chacha::ChaCha8Rng;
+use rand::{SeedableRng, rngs::ChaCha8Rng};   // as the reference imports it (src/sampler.rs:6)
 use thiserror::Error;
 
 #[derive(Debug)]
