@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 9
+#define NM_ABI_VERSION 10
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -108,7 +108,18 @@ typedef struct nm_settings {
      * mass-matrix estimator steps of GlobalStrategy::adapt (update_estimators / switch / adapt) are skipped; the
      * step-size schedule runs as usual */
     uint64_t freeze_transform;               /* 0 */
+    /* trajectory_kind: KineticEnergyKind (src/sampler.rs:224-232, src/dynamics/transformed_hamiltonian.rs:27-50): which
+     * integrator the tree's leapfrog is.  NM_TRAJ_EXACT_NORMAL: the geodesic leapfrog that is exact for a standard-normal
+     * potential (std_norm_flow / std_norm_grad_flow, src/math/util.rs:507-741).  NM_TRAJ_MICROCANONICAL: the isokinetic ESH
+     * leapfrog (esh_momentum_update, src/math/cpu_math.rs:505-551; unit-sphere momentum, the point's kinetic energy is the
+     * accumulated change, a divergence is |energy error| >= max_energy_error; needs dim >= 2).  The non-Euclidean kinds run
+     * with the diagonal adaptation on the one-chain-per-block kernels (built-in densities and NM_LOGP_HOST_CALLBACK). */
+    uint64_t trajectory_kind;                /* NM_TRAJ_EUCLIDEAN */
 } nm_settings;
+
+#define NM_TRAJ_EUCLIDEAN 0
+#define NM_TRAJ_EXACT_NORMAL 1
+#define NM_TRAJ_MICROCANONICAL 2
 
 #define NM_ADAPT_DIAG 0
 #define NM_ADAPT_LOW_RANK 1   /* reference src/transform/low_rank.rs, src/transform/adapt/low_rank.rs */

@@ -63,6 +63,8 @@ struct EuclideanAdaptOptions {
     uint64_t mass_matrix_switch_freq = 80, early_mass_matrix_switch_freq = 10, mass_matrix_update_freq = 1;
     double mass_matrix_window_growth = 1.5;
 };
+enum class KineticEnergyKind : uint64_t {      // src/dynamics/transformed_hamiltonian.rs:27-50
+    Euclidean = NM_TRAJ_EUCLIDEAN, ExactNormal = NM_TRAJ_EXACT_NORMAL, Microcanonical = NM_TRAJ_MICROCANONICAL };
 struct DiagNutsSettings {
     uint64_t num_tune = 400, num_draws = 1000, maxdepth = 10, mindepth = 0;
     bool store_gradient = false, store_unconstrained = false, store_transformed = false;
@@ -71,6 +73,7 @@ struct DiagNutsSettings {
     EuclideanAdaptOptions adapt_options;
     bool check_turning = true;
     std::optional<double> target_integration_time;
+    KineticEnergyKind trajectory_kind = KineticEnergyKind::Euclidean;
     uint64_t num_chains = 6, seed = 0, extra_doublings = 0;
 
     nm_settings to_c() const {
@@ -78,7 +81,7 @@ struct DiagNutsSettings {
         nm_settings_default(&s);
         s.num_tune = num_tune; s.num_draws = num_draws; s.maxdepth = maxdepth; s.mindepth = mindepth;
         s.max_energy_error = max_energy_error; s.check_turning = check_turning; s.extra_doublings = extra_doublings;
-        s.seed = seed; s.num_chains = num_chains;
+        s.seed = seed; s.num_chains = num_chains; s.trajectory_kind = (uint64_t)trajectory_kind;
         s.store_gradient = store_gradient; s.store_unconstrained = store_unconstrained;
         s.store_transformed = store_transformed; s.store_divergences = store_divergences;
         s.has_target_integration_time = target_integration_time.has_value();

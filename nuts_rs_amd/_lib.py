@@ -53,7 +53,7 @@ class NmSettings(C.Structure):
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
         ("adam_learning_rate", C.c_double),
         ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
-        ("freeze_transform", C.c_uint64),
+        ("freeze_transform", C.c_uint64), ("trajectory_kind", C.c_uint64),
     ]
 
 

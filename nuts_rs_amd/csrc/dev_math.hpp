@@ -280,6 +280,37 @@ NM_DEV double logaddexp(double a, double b) {
     return diff;
 }
 
+// sin / cos of a step size (the ExactNormal trajectory kind; reference f64::sin / f64::cos, src/math/util.rs:580-581):
+// Cody-Waite reduction by pi/2 in two fma steps and the classic minimax kernels on [-pi/4, pi/4]; the same operation
+// sequence as oracle/nmo_math.hpp det_sincos (bit-identical), ~1 ulp from libm.
+static __host__ __device__ __noinline__ double2 dsincos(double x) {     // (sin x, cos x)
+    if (!(x == x) || __builtin_isinf(x)) return make_double2(__builtin_nan(""), __builtin_nan(""));
+    const double ax = __builtin_fabs(x);
+    const double nf = __builtin_rint(ax * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-nf, 1.57079632679489655800e+00, ax);
+    r = __builtin_fma(-nf, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const int q = (int)((long long)nf & 3);
+    double s_, c_;
+    if (q == 0) { s_ = sr; c_ = cr; }
+    else if (q == 1) { s_ = cr; c_ = -sr; }
+    else if (q == 2) { s_ = -sr; c_ = -cr; }
+    else { s_ = -cr; c_ = sr; }
+    return make_double2(x < 0.0 ? -s_ : s_, c_);
+}
+
 NM_DEV bool is_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 NM_DEV double clampd(double v, double lo, double hi) {   // f64::clamp: NaN stays NaN
     if (v < lo) return lo;

@@ -166,6 +166,7 @@ extern "C" void nm_settings_default(nm_settings* s) {
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;
     s->adaptation = NM_ADAPT_DIAG; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;
+    s->trajectory_kind = NM_TRAJ_EUCLIDEAN;                                  // sampler.rs:528
 }
 extern "C" void nm_settings_default_low_rank(nm_settings* s) {     // LowRankNutsSettings::default (src/sampler.rs:636-642)
     nm_settings_default(s);
@@ -184,8 +185,9 @@ typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blo
 typedef void (*module_info_fn)(uint64_t out[5]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
-                         module_launch_fn module = nullptr, bool lr = false) {
-    if (logp_kind == NM_LOGP_MODULE) return module && !lr ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
+                         module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds)
+    const bool lr = variant == 1;
+    if (logp_kind == NM_LOGP_MODULE) return module && variant == 0 ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
     if (lr) {      // the kernels that carry the low-rank transformation (LrWrap<Density>, kern_lr_*.hip)
         switch (logp_kind) {
         case NM_LOGP_IID_NORMAL: return launch_iid_normal_lr(dpl, w, kind, P, grid, stream, occ);
@@ -194,6 +196,17 @@ static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, co
         case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools_lr(dpl, w, kind, P, grid, stream, occ);
         case NM_LOGP_MVN_PREC: return launch_mvn_prec_lr(dpl, w, kind, P, grid, stream, occ);
         case NM_LOGP_HOST_CALLBACK: return launch_host_cb_lr(dpl, w, kind, P, grid, stream, occ);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (variant == 2) {      // the kernels that carry the non-Euclidean KineticEnergyKinds (KinWrap<Density>, kern_kin_*.hip)
+        switch (logp_kind) {
+        case NM_LOGP_IID_NORMAL: return launch_iid_normal_kin(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_DIAG_NORMAL: return launch_diag_normal_kin(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_FUNNEL: return launch_funnel_kin(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_EIGHT_SCHOOLS: return launch_eight_schools_kin(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_MVN_PREC: return launch_mvn_prec_kin(dpl, w, kind, P, grid, stream, occ);
+        case NM_LOGP_HOST_CALLBACK: return launch_host_cb_kin(dpl, w, kind, P, grid, stream, occ);
         }
         return hipErrorInvalidValue;
     }
@@ -313,6 +326,7 @@ struct nm_engine {
     bool pending_timing = false;
     // low-rank transformation (settings.adaptation == NM_ADAPT_LOW_RANK)
     bool lr = false;
+    int variant = 0;            // kernel family: 0 plain, 1 LrWrap, 2 KinWrap (see launch())
     uint64_t lr_rmax = 0, lr_cap = 0;
     double *d_lrvec = nullptr, *d_lrval = nullptr, *d_lrwin = nullptr;
     nm_lowrank_estimator_fn lr_estimator = nm_lowrank_compute_update;
@@ -388,6 +402,11 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     const bool lr = s.adaptation == NM_ADAPT_LOW_RANK;
     if (lr && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "NM_ADAPT_LOW_RANK with a density module: modules carry the diagonal kernels only");
     if (lr && !(s.lr_gamma > 0.0) ) return fail(NM_ERR_INVALID_ARG, "lr_gamma must be > 0");
+    if (s.trajectory_kind > NM_TRAJ_MICROCANONICAL) return fail(NM_ERR_INVALID_ARG, "trajectory_kind %llu is not one of NM_TRAJ_*", (unsigned long long)s.trajectory_kind);
+    const bool kin = s.trajectory_kind != NM_TRAJ_EUCLIDEAN;
+    if (kin && lr) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds run with the diagonal adaptation (NM_ADAPT_DIAG) only");
+    if (kin && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds with a density module: modules carry the Euclidean kernels only");
+    if (s.trajectory_kind == NM_TRAJ_MICROCANONICAL && logp->dim < 2) return fail(NM_ERR_INVALID_ARG, "ESH dynamics requires at least 2 dimensions (reference src/math/cpu_math.rs:514)");
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
     int dpl = 0, wv = 0;
@@ -402,6 +421,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (!e) return fail(NM_ERR_HIP, "out of host memory");
     e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl; e->wpc = wv;
     e->lr = lr;
+    e->variant = lr ? 1 : (kin ? 2 : 0);
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;
     const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
@@ -429,7 +449,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         int occ = 0, cus = 0;
         KParams dummy;
         memset(&dummy, 0, sizeof dummy);
-        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch, lr));
+        E_TRY(launch(logp->kind, dpl, wv, K_QUERY, dummy, 0, nullptr, &occ, e->module_launch, e->variant));
         E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
         uint64_t resident = (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(cus > 0 ? cus : 1);
         const uint64_t wave_slots = resident;                      // chains the wave-per-chain kernel runs at once
@@ -438,7 +458,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const int gs = grp::group_size(logp->dim);
         const bool group_density = (logp->kind != NM_LOGP_MODULE && logp->kind != NM_LOGP_HOST_CALLBACK) || (logp->kind == NM_LOGP_MODULE && gs && e->module_group_lanes == gs);   // every built-in density has a group form
-        if (!lr && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
+        if (!lr && !kin && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
@@ -617,7 +637,7 @@ extern "C" nm_status nm_engine_set_positions_masked(nm_engine* e, const double* 
         P.init_mask = e->d_init_mask;
     }
     e->cb_active.store(1, std::memory_order_release);
-    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->lr));
+    HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->variant));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->cb_active.store(0, std::memory_order_release);
     std::vector<ChainScalars> sc(e->n_chains);
@@ -922,7 +942,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, e->module_launch));
         e->group_launches += 1;
     } else
-        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch));
+        HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch, e->variant));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     e->pending_timing = true;
     e->kernel_launches += 1;

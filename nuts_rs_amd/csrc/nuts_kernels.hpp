@@ -505,6 +505,12 @@ template <class D>
 struct LrWrap : D {};
 template <class D> struct lr_trait { static constexpr bool value = false; };
 template <class D> struct lr_trait<LrWrap<D>> { static constexpr bool value = true; };
+// KinWrap<D>: the same density with the non-Euclidean KineticEnergyKinds compiled into the leapfrog (nm_settings.trajectory_kind,
+// reference src/dynamics/transformed_hamiltonian.rs:27-50); the plain kernels carry only the Euclidean integrator.
+template <class D>
+struct KinWrap : D {};
+template <class D> struct kin_trait { static constexpr bool value = false; };
+template <class D> struct kin_trait<KinWrap<D>> { static constexpr bool value = true; };
 // densities of the tile kernel (nuts_tile.hpp) set kTile: products with the SHARED matrices (U', U, P) are rendezvous
 // GEMMs of the block's 16 chains on the matrix cores
 template <class D, class = void> struct tile_trait { static constexpr bool value = false; };
@@ -787,11 +793,120 @@ NM_DEV void transform_to_z(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x, Tile<D
     }
 }
 
+// ---- the non-Euclidean KineticEnergyKinds (KinWrap kernels only) -----------------------------------------------------
+// `v.iter().map(|x| x * x).sum()` in the engine's reduction order (oracle Ctx::sum_sq, REDUCE_GPU)
+template <int DPL, int W>
+NM_DEV double sum_sq_tile(const Tile<DPL>& v, Reducer<W>& R) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc = acc + v.a[k] * v.a[k];
+    return R.sum(acc);
+}
+// array_normalize (reference src/math/cpu_math.rs:496-503)
+template <int DPL, int W>
+NM_DEV void normalize_tile(Tile<DPL>& v, Reducer<W>& R) {
+    const double inv = 1.0 / __builtin_sqrt(sum_sq_tile(v, R));
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) v.a[k] *= inv;
+}
+// esh_momentum_update (reference src/math/cpu_math.rs:505-551): the ESH momentum step on the unit sphere; returns the
+// change of the kinetic energy.  Padding elements hold 0 and stay 0.
+template <int DPL, int W, class Dens>
+NM_DEV double esh_update(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& g, Tile<DPL>& p, double step_size) {
+    const double grad_norm = __builtin_sqrt(sum_sq_tile(g, C.red));
+    const double inv_grad_norm = 1.0 / grad_norm;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc = acc + p.a[k] * g.a[k] * inv_grad_norm;
+    const double momentum_proj = C.red.sum(acc);
+    const double dims_m1 = (double)(C.dim - 1);
+    const double delta = step_size * grad_norm / dims_m1;
+    const double zeta = uexp(-delta);
+    const double coeff_g = (1.0 - zeta) * (1.0 + zeta + momentum_proj * (1.0 - zeta));
+    const double coeff_p = 2.0 * zeta;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) p.a[k] = coeff_g * (g.a[k] * inv_grad_norm) + coeff_p * p.a[k];
+    normalize_tile(p, C.red);
+    const double arg = momentum_proj + (1.0 - momentum_proj) * zeta * zeta;
+    return (delta - 6.93147180559945286227e-01 + ulog1p(arg)) * dims_m1;
+}
+// leapfrog's divergence criterion (transformed_hamiltonian.rs:583-590)
+template <int DPL, int W, class Dens>
+NM_DEV bool bad_energy(const ChainCtx<DPL, W, Dens>& C, double energy_error, double max_energy_error) {
+    if constexpr (kin_trait<Dens>::value) {
+        if (C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL)
+            return (__builtin_fabs(energy_error) >= max_energy_error) | !is_finite(energy_error);
+    }
+    return (energy_error > max_energy_error) | !is_finite(energy_error);
+}
+// The leapfrog of KineticEnergyKind::ExactNormal (std_norm_grad_flow / std_norm_flow, src/math/util.rs:507-741) and
+// ::Microcanonical (two ESH momentum half-steps around the position step, :186-226, :235-258) with the diagonal
+// transformation; `o.ke` of the microcanonical kind is the accumulated kinetic-energy change (s.ke + both half-steps).
+template <int DPL, int W, class Dens>
+NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
+    const bool micro = C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL;
+    const double half = epsilon / 2.;
+    const double sqrt_n = __builtin_sqrt((double)C.dim);
+    Tile<DPL> x, gx;
+    if (micro) {
+        o.v = s.v;
+        o.ke = s.ke + esh_update(C, s.g, o.v, sqrt_n * epsilon / 2.);
+        const double eps_n = epsilon * sqrt_n;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) o.z.a[k] = __builtin_fma(eps_n, o.v.a[k], s.z.a[k]);
+    } else {
+        const double2 sc2 = dsincos(epsilon);
+        const double es = uniform_f64(sc2.x), ec = uniform_f64(sc2.y);
+        const double nes = -es;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const double vh = __builtin_fma(half, s.z.a[k] + s.g.a[k], s.v.a[k]);
+            o.z.a[k] = __builtin_fma(s.z.a[k], ec, vh * es);
+            o.v.a[k] = __builtin_fma(s.z.a[k], nes, vh * ec);
+        }
+    }
+    const double2* sg2 = C.tptr(C.lsig);
+    const double2* mu2 = C.tptr(C.lmu);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64 * W], mm = mu2[m * 64 * W];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * m + j;
+            const double t = o.z.a[k] * (j ? sg.y : sg.x);
+            x.a[k] = __builtin_fma(1.0, (j ? mm.y : mm.x), t);
+        }
+    }
+    o.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 sg = sg2[m * 64 * W];
+        o.g.a[2 * m] = gx.a[2 * m] * sg.x;
+        o.g.a[2 * m + 1] = gx.a[2 * m + 1] * sg.y;
+    }
+    if (micro) {
+        o.ke = o.ke + esh_update(C, o.g, o.v, sqrt_n * epsilon / 2.);
+    } else {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            o.v.a[k] = __builtin_fma(half, o.z.a[k] + o.g.a[k], o.v.a[k]);
+            acc = __builtin_fma(o.v.a[k], o.v.a[k], acc);
+        }
+        o.ke = 0.5 * C.red.sum(acc);
+    }
+    if (x_out) *x_out = x;
+    if (gx_out) *gx_out = gx;
+}
+
 // One leapfrog, registers to registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
 //   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
 template <int DPL, int W, class Dens>
 NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
+    if constexpr (kin_trait<Dens>::value) {
+        if (C.P.s.trajectory_kind != NM_TRAJ_EUCLIDEAN) { leapfrog_kin(C, s, o, epsilon, x_out, gx_out); return; }
+    }
     const double half = epsilon / 2.;
     Tile<DPL> x, gx;
     if constexpr (lr_trait<Dens>::value) {
@@ -943,6 +1058,20 @@ NM_DEV double kinetic(const Tile<DPL>& v, Reducer<W>& R) {
     for (int k = 0; k < DPL; ++k) acc = __builtin_fma(v.a[k], v.a[k], acc);
     return 0.5 * R.sum(acc);
 }
+// the kinetic energy a trajectory starts with (initialize_trajectory, transformed_hamiltonian.rs:697-727): the
+// microcanonical kind first puts the fresh momentum on the unit sphere (and re-stages it: the initial point's v is an
+// edge operand) and starts its accumulated kinetic-energy change at 0
+template <int DPL, int W, class Dens>
+NM_DEV double initial_kinetic(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
+    if constexpr (kin_trait<Dens>::value) {
+        if (C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL) {
+            normalize_tile(v, C.red);
+            C.storeS(v, STAGE_V);
+            return 0.0;
+        }
+    }
+    return kinetic(v, C.red);
+}
 
 // Σ ln(t) over valid elements (array_sum_ln, cpu_math.rs:300-304)
 template <int DPL, int W, class Dens>
@@ -1030,7 +1159,8 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
     }
     const double logdet = C.sc.mm_logdet;
     sample_velocity(C, st.v);                    // initialize_trajectory(resample) :687-736
-    const double ke0 = kinetic(st.v, C.red);
+    const double ke0 = initial_kinetic(C, st.v);
+    st.ke = ke0;
     const double e0 = ke0 - (st.logp + logdet);
     AcceptCollector col;
     C.sc.step_size = s.initial_step;
@@ -1046,7 +1176,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
             if (it > 0) C.sc.step_size = s.initial_step;
             return NM_CHAIN_OK;
         }
-        if ((err > 1000.0) | !is_finite(err)) {                 // hard-coded 1000.0 (adapt.rs:118, :142)
+        if (bad_energy(C, err, 1000.0)) {                       // hard-coded 1000.0 (adapt.rs:118, :142)
             if (it > 0) C.sc.step_size = s.initial_step;
             return NM_CHAIN_OK;
         }
@@ -1488,7 +1618,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         C.loadP(E.g, P_GZ);
     }
     const double logdet = sc.logdet;
-    const double ke_init = kinetic(E.v, C.red);
+    const double ke_init = initial_kinetic(C, E.v);
+    E.ke = ke_init;
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
@@ -1499,6 +1630,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     uint64_t depth = 0;
     double log_size = 0.;
     int64_t left_idx = 0, right_idx = 0;
+    [[maybe_unused]] double left_ke = ke_init, right_ke = ke_init;   // the edges' kinetic_energy: an input of the microcanonical leapfrog only
     CandRef mc = {-1, sc.logp, ke_init, 0};
     uint32_t used = 0;   // candidate-pool occupancy bitmask
 
@@ -1558,7 +1690,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if (want_div) C.storeS((START).z, slot_F(0));                                             \
                 stop = STOP_DIVERGING;                                                                    \
             } else                                                                                        \
-            if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
+            if (bad_energy(C, err_, s.max_energy_error)) {                                                \
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
                 R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
@@ -1637,6 +1769,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
                 const int es = fwd ? right_slot : left_slot;
                 C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es)); C.loadRef(O.g, C.edge_g(es));
+                if constexpr (kin_trait<Dens>::value) O.ke = fwd ? right_ke : left_ke;
             }
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 // ---- even leaf n
@@ -1812,6 +1945,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         }
         NM_MARK(C, 28)
         if (fwd) right_idx = O.idx; else left_idx = O.idx;
+        if constexpr (kin_trait<Dens>::value) { if (fwd) right_ke = O.ke; else left_ke = O.ke; }
         depth += 1;
         log_size = total;
         if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }

@@ -83,6 +83,13 @@ hipError_t launch_diag_normal_lr(int dpl, int w, KernelKind kind, const KParams&
 hipError_t launch_funnel_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_eight_schools_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_mvn_prec_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+// the same kernels with the non-Euclidean KineticEnergyKinds compiled in (KinWrap<Density>), in kern_kin_<density>.hip
+hipError_t launch_iid_normal_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_diag_normal_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_funnel_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_eight_schools_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_mvn_prec_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+hipError_t launch_host_cb_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 // NM_LOGP_HOST_CALLBACK (kern_host_cb.hip)
 hipError_t launch_host_cb(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_host_cb_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);

@@ -57,6 +57,10 @@ class DiagAdaptExpSettings:        # src/transform/adapt/diagonal.rs:92-106
     use_grad_based_estimate: bool = True
 
 
+class KineticEnergyKind:           # src/dynamics/transformed_hamiltonian.rs:27-50
+    EUCLIDEAN, EXACT_NORMAL, MICROCANONICAL = 0, 1, 2
+
+
 @dataclass
 class LowRankSettings:             # src/transform/low_rank.rs:188-203
     store_mass_matrix: bool = False
@@ -94,6 +98,7 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
     seed: int = 0
     extra_doublings: int = 0
     freeze_transform: bool = False   # engine knob (not a reference setting): see nm_settings.freeze_transform
+    trajectory_kind: int = 0         # KineticEnergyKind (src/sampler.rs:224-232): KineticEnergyKind.EUCLIDEAN / EXACT_NORMAL / MICROCANONICAL
 
     def to_c(self) -> NmSettings:
         s = NmSettings()
@@ -121,6 +126,7 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
             s.adaptation = ADAPT_DIAG
             s.use_grad_based_estimate = int(mo.use_grad_based_estimate)
         s.freeze_transform = int(self.freeze_transform)
+        s.trajectory_kind = int(self.trajectory_kind)
         s.target_accept, s.initial_step = st.target_accept, st.initial_step
         s.has_jitter, s.jitter = int(st.jitter is not None), st.jitter or 0.0
         s.step_size_method, s.fixed_step_size = st.method, st.fixed_step_size

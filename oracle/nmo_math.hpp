@@ -121,6 +121,39 @@ static inline double det_log1p(double x) {
     return det_log_core(u, x - (u - 1.0));
 }
 
+// sin and cos of x (reference: f64::sin / f64::cos of the step size, src/math/util.rs:580-581).  Cody-Waite reduction by
+// pi/2 in two fma steps, then the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]; every step is one
+// binary64 operation, the engine runs the same sequence.  Odd / even symmetry is exact, like libm's.  Accuracy ~1 ulp for
+// |x| up to a few thousand (step sizes), deterministic everywhere.
+static inline void det_sincos(double x, double* sn, double* cs) {
+    if (!(x == x) || std::isinf(x)) { *sn = NAN; *cs = NAN; return; }
+    const double ax = std::fabs(x);
+    const double nf = std::nearbyint(ax * 6.36619772367581382433e-01);
+    double r = std::fma(-nf, 1.57079632679489655800e+00, ax);
+    r = std::fma(-nf, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = std::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = std::fma(z, ps, 2.75573137070700676789e-06);
+    ps = std::fma(z, ps, -1.98412698298579493134e-04);
+    ps = std::fma(z, ps, 8.33333333332248946124e-03);
+    ps = std::fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = std::fma(r * z, ps, r);
+    double pc = std::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = std::fma(z, pc, -2.75573143513906633035e-07);
+    pc = std::fma(z, pc, 2.48015872894767294178e-05);
+    pc = std::fma(z, pc, -1.38888888888741095749e-03);
+    pc = std::fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = std::fma(z * z, pc, std::fma(-0.5, z, 1.0));
+    const int q = (int)((long long)nf & 3);
+    double s_, c_;
+    if (q == 0) { s_ = sr; c_ = cr; }
+    else if (q == 1) { s_ = cr; c_ = -sr; }
+    else if (q == 2) { s_ = -sr; c_ = -cr; }
+    else { s_ = -cr; c_ = sr; }
+    *sn = x < 0.0 ? -s_ : s_;
+    *cs = c_;
+}
+
 struct Ctx {
     MathCfg cfg;
     double exp(double x) const { return cfg.detmath ? det_exp(x) : std::exp(x); }
@@ -128,6 +161,9 @@ struct Ctx {
     double ln_1p(double x) const { return cfg.detmath ? det_log1p(x) : std::log1p(x); }
     // count.powf(-k) of dual averaging (reference src/stepsize/dual_avg.rs:60)
     double powf(double a, double b) const { return cfg.detmath ? det_exp(b * det_log(a)) : std::pow(a, b); }
+
+    double sin(double x) const { if (!cfg.detmath) return std::sin(x); double s_, c_; det_sincos(x, &s_, &c_); return s_; }
+    double cos(double x) const { if (!cfg.detmath) return std::cos(x); double s_, c_; det_sincos(x, &s_, &c_); return c_; }
 
     // reference src/math/util.rs:6-19
     double logaddexp(double a, double b) const {
@@ -256,6 +292,74 @@ struct Ctx {
         double s = 0.0;
         for (size_t i = 0; i < n; ++i) s += (x[i] + y[i]) * (x[i] + y[i]);
         return s;
+    }
+
+    // `v.iter().map(|x| x * x).sum::<f64>()` (reference src/math/cpu_math.rs:498, :517, :541): a sequential scalar sum
+    double sum_sq(const double* a, size_t n) const {
+        if (cfg.reduce_mode == REDUCE_GPU)
+            return gpu_reduce(n, [&](double acc, size_t d) { return acc + a[d] * a[d]; });
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += a[i] * a[i];
+        return s;
+    }
+    // `p.zip(g).map(|(p, g)| p * g * inv).sum()` (reference src/math/cpu_math.rs:522-526)
+    double sum_prod_scaled(const double* p, const double* g, double inv, size_t n) const {
+        if (cfg.reduce_mode == REDUCE_GPU)
+            return gpu_reduce(n, [&](double acc, size_t d) { return acc + p[d] * g[d] * inv; });
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += p[i] * g[i] * inv;
+        return s;
+    }
+    // elements below this index go through the SIMD registers (fused multiply-adds); the remainder is the scalar tail loop of
+    // the reference's kernels, which is written WITHOUT mul_add (src/math/util.rs:561-565, :644-646, :713-715).  The engine's
+    // arithmetic (REDUCE_GPU) has no tail: every element is fused.
+    size_t simd_head(size_t n) const {
+        if (cfg.reduce_mode == REDUCE_GPU) return n;
+        return n - n % (size_t)cfg.simd_lanes;
+    }
+
+    // std_norm_flow (reference src/math/util.rs:507-589): pos_out = p cos e + v sin e ; vel = -p sin e + v cos e
+    void std_norm_flow(const double* pos, double* pos_out, double* vel, double epsilon, size_t n) const {
+        const double es = sin(epsilon), ec = cos(epsilon);
+        const size_t h = simd_head(n);
+        for (size_t i = 0; i < h; ++i) {
+            const double p = pos[i], v = vel[i];
+            pos_out[i] = std::fma(p, ec, v * es);
+            vel[i] = std::fma(p, -es, v * ec);
+        }
+        for (size_t i = h; i < n; ++i) {
+            const double p = pos[i], v = vel[i];
+            pos_out[i] = p * ec + v * es;
+            vel[i] = p * (-es) + v * ec;
+        }
+    }
+    // std_norm_grad_flow / _inplace (reference src/math/util.rs:591-741): vel_out = vel + e (pos + grad)
+    void std_norm_grad_flow(const double* pos, const double* grad, const double* vel, double* vel_out, double epsilon, size_t n) const {
+        const size_t h = simd_head(n);
+        for (size_t i = 0; i < h; ++i) vel_out[i] = std::fma(epsilon, pos[i] + grad[i], vel[i]);
+        for (size_t i = h; i < n; ++i) vel_out[i] = vel[i] + epsilon * (pos[i] + grad[i]);
+    }
+    // array_normalize (reference src/math/cpu_math.rs:496-503)
+    void array_normalize(double* v, size_t n) const {
+        const double inv = 1.0 / std::sqrt(sum_sq(v, n));
+        for (size_t i = 0; i < n; ++i) v[i] *= inv;
+    }
+    // esh_momentum_update (reference src/math/cpu_math.rs:505-551): the ESH momentum step on the unit sphere; returns the
+    // kinetic-energy change
+    double esh_momentum_update(const double* gradient, double* momentum, double step_size, size_t n) const {
+        const double grad_norm = std::sqrt(sum_sq(gradient, n));
+        const double inv_grad_norm = 1.0 / grad_norm;
+        const double momentum_proj = sum_prod_scaled(momentum, gradient, inv_grad_norm, n);
+        const double dims_m1 = (double)(n - 1);
+        const double delta = step_size * grad_norm / dims_m1;
+        const double zeta = exp(-delta);
+        const double coeff_g = (1.0 - zeta) * (1.0 + zeta + momentum_proj * (1.0 - zeta));
+        const double coeff_p = 2.0 * zeta;
+        for (size_t i = 0; i < n; ++i) momentum[i] = coeff_g * (gradient[i] * inv_grad_norm) + coeff_p * momentum[i];
+        const double inv = 1.0 / std::sqrt(sum_sq(momentum, n));
+        for (size_t i = 0; i < n; ++i) momentum[i] *= inv;
+        const double arg = momentum_proj + (1.0 - momentum_proj) * zeta * zeta;
+        return (delta - 6.93147180559945286227e-01 + ln_1p(arg)) * dims_m1;
     }
 
 private:

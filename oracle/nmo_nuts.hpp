@@ -46,7 +46,9 @@ struct Settings {
     uint64_t adaptation;
     double lr_gamma, lr_eigval_cutoff;          // LowRankSettings (src/transform/low_rank.rs:188-203)
     uint64_t freeze_transform;                  // engine knob (not a reference setting): the transformation is given, never adapted
+    uint64_t trajectory_kind;                   // KineticEnergyKind (src/dynamics/transformed_hamiltonian.rs:27-50, NutsSettings::trajectory_kind)
 };
+enum { TRAJ_EUCLIDEAN = 0, TRAJ_EXACT_NORMAL = 1, TRAJ_MICROCANONICAL = 2 };
 
 struct DrawStats {   // same field order as nm_draw_stats
     uint64_t draw, chain, depth, maxdepth_reached, diverging, tuning, n_steps;
@@ -401,7 +403,7 @@ enum LeapfrogKind { LF_OK, LF_DIVERGENCE, LF_ERR };
 struct LeapfrogResult { LeapfrogKind kind; State state; DivergenceInfo info; };
 
 // ---------------------------------------------------------------------------------------------
-// TransformedHamiltonian<DiagMassMatrix>, Euclidean kinetic energy
+// TransformedHamiltonian<DiagMassMatrix | LowRankMassMatrix>; the three KineticEnergyKinds (:27-50)
 // ---------------------------------------------------------------------------------------------
 struct Hamiltonian {
     const Ctx* m;
@@ -409,6 +411,7 @@ struct Hamiltonian {
     MassMatrix mm;
     double step_size = 0;
     size_t n;
+    int64_t kind = TRAJ_EUCLIDEAN;
     Hamiltonian(const Ctx* m_, const Density* d) : m(m_), dens(d), mm(d->dim), n(d->dim) {}
 
     // leapfrog :524-615.  `acc` may be null (no collector).
@@ -420,8 +423,18 @@ struct Hamiltonian {
         o.initial_energy = s.initial_energy;
         o.transform_id = s.transform_id;
         const double epsilon = (double)sign * step_size * step_size_factor;
-        axpy_out(s.gz.data(), s.v.data(), epsilon / 2., o.v.data(), n);          // first_velocity_halfstep :178-184
-        axpy_out(o.v.data(), s.z.data(), epsilon, o.z.data(), n);                // position_step :220-225
+        const double sqrt_n = std::sqrt((double)n);
+        if (kind == TRAJ_EXACT_NORMAL) {                                         // first_velocity_halfstep :169-177
+            m->std_norm_grad_flow(s.z.data(), s.gz.data(), s.v.data(), o.v.data(), epsilon / 2., n);
+            m->std_norm_flow(s.z.data(), o.z.data(), o.v.data(), epsilon, n);    // position_step :206-213
+        } else if (kind == TRAJ_MICROCANONICAL) {                                // :186-198
+            o.v = s.v;
+            o.kinetic_energy = s.kinetic_energy + m->esh_momentum_update(s.gz.data(), o.v.data(), sqrt_n * epsilon / 2., n);
+            axpy_out(o.v.data(), s.z.data(), epsilon * sqrt_n, o.z.data(), n);   // position_step :214-226
+        } else {
+            axpy_out(s.gz.data(), s.v.data(), epsilon / 2., o.v.data(), n);      // first_velocity_halfstep :178-184
+            axpy_out(o.v.data(), s.z.data(), epsilon, o.z.data(), n);            // position_step :220-225
+        }
         // init_from_transformed_position (diagonal.rs:196-209)
         mm.compute_untransformed_position(*m, o.z, o.x);
         double logp = 0;
@@ -437,11 +450,19 @@ struct Hamiltonian {
         o.logp = logp;
         o.logdet = mm.logdet;
         o.transform_id = mm.id;
-        axpy(o.gz.data(), o.v.data(), epsilon / 2., n);                          // second_velocity_halfstep :245-247
-        o.kinetic_energy = 0.5 * m->vector_dot(o.v.data(), o.v.data(), n);      // :260-262
+        if (kind == TRAJ_EXACT_NORMAL)                                           // second_velocity_halfstep :235-258
+            m->std_norm_grad_flow(o.z.data(), o.gz.data(), o.v.data(), o.v.data(), epsilon / 2., n);
+        else if (kind == TRAJ_MICROCANONICAL)
+            o.kinetic_energy = o.kinetic_energy + m->esh_momentum_update(o.gz.data(), o.v.data(), sqrt_n * epsilon / 2., n);
+        else
+            axpy(o.gz.data(), o.v.data(), epsilon / 2., n);
+        if (kind != TRAJ_MICROCANONICAL)
+            o.kinetic_energy = 0.5 * m->vector_dot(o.v.data(), o.v.data(), n);  // :260-262
         o.index_in_trajectory = s.index_in_trajectory + sign;
         const double energy_error = o.energy() - energy_baseline;
-        if ((energy_error > max_energy_error) | !std::isfinite(energy_error)) {  // :590-610
+        const bool bad_energy = kind == TRAJ_MICROCANONICAL ? std::fabs(energy_error) >= max_energy_error
+                                                            : energy_error > max_energy_error;   // :583-589
+        if (bad_energy | !std::isfinite(energy_error)) {                         // :590-610
             DivergenceInfo info; info.present = true; info.has_energy_error = true; info.energy_error = energy_error;
             info.start_location = s.x; info.start_gradient = s.gx; info.end_location = o.x; info.has_end = true;
             info.start_idx = s.index_in_trajectory; info.end_idx = o.index_in_trajectory;
@@ -503,13 +524,15 @@ struct Hamiltonian {
     // initialize_trajectory :687-736 (resample_velocity = true)
     void initialize_trajectory(Point& p, ChaCha8Rng& rng) {
         for (size_t i = 0; i < n; ++i) p.v[i] = 1.0 * standard_normal(rng, *m);  // array_gaussian cpu_math.rs:561-577
+        if (kind == TRAJ_MICROCANONICAL) m->array_normalize(p.v.data(), n);      // the momentum lives on the unit sphere :700-703
         if (mm.id != p.transform_id) {                                           // inv_transform_normalize diagonal.rs:210-221
             mm.compute_transformed_position(*m, p.x, p.z);
             mm.compute_transformed_gradient(*m, p.gx, p.gz);
             p.logdet = mm.logdet;
             p.transform_id = mm.id;
         }
-        p.kinetic_energy = 0.5 * m->vector_dot(p.v.data(), p.v.data(), n);
+        if (kind == TRAJ_MICROCANONICAL) p.kinetic_energy = 0.0;                 // accumulated change, none yet :722-727
+        else p.kinetic_energy = 0.5 * m->vector_dot(p.v.data(), p.v.data(), n);
         p.index_in_trajectory = 0;
         p.initial_energy = p.energy();
     }
@@ -741,7 +764,7 @@ struct Chain {
     Chain(const Settings& s_, const Density& d, const MathCfg& cfg, uint64_t chain, const uint8_t key[32])
         : m{cfg}, dens(d), s(s_), chain_id(chain), rng(ChaCha8Rng::from_seed(key)), h(&m, &dens), coll(d.dim),
           var_draw(d.dim), var_grad(d.dim), var_draw_bg(d.dim), var_grad_bg(d.dim), n(d.dim) {
-        h.m = &m; h.dens = &dens;
+        h.m = &m; h.dens = &dens; h.kind = (int64_t)s.trajectory_kind;
         options = {s.maxdepth, s.mindepth, s.check_turning != 0, s.extra_doublings, s.max_energy_error,
                    s.has_target_integration_time != 0, s.target_integration_time};
         // GlobalStrategy::new adapt_strategy.rs:77-98

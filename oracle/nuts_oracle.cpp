@@ -27,6 +27,7 @@ void nmo_settings_default(Settings* s) {
     s->da_k = 0.75; s->da_t0 = 10.; s->da_gamma = 0.05; s->da_max_step_size = 3.14159265358979323846;
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;   // adam.rs:25-33
     s->adaptation = 0; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;          // low_rank.rs:195-203
+    s->trajectory_kind = TRAJ_EUCLIDEAN;                                                                  // sampler.rs:528
 }
 // LowRankNutsSettings::default() (reference src/sampler.rs:636-642): num_tune 800, mass_matrix_update_freq 20
 void nmo_settings_default_low_rank(Settings* s) {
@@ -420,6 +421,51 @@ int nmo_leapfrog(const MathCfg* cfg, int64_t kind, uint64_t dim, const double* p
     for (uint64_t i = 0; i < dim; ++i) { s->z[i] = z[i]; s->v[i] = v[i]; s->gz[i] = gz[i]; }
     s->initial_energy = initial_energy; s->transform_id = 0;
     LeapfrogResult r = h.leapfrog(s, eps < 0 ? -1 : +1, 1.0, initial_energy, INFINITY, nullptr);
+    if (r.kind != LF_OK) return 1;
+    for (uint64_t i = 0; i < dim; ++i) {
+        z_out[i] = r.state->z[i]; v_out[i] = r.state->v[i]; gz_out[i] = r.state->gz[i];
+        x_out[i] = r.state->x[i]; gx_out[i] = r.state->gx[i];
+    }
+    *logp_out = r.state->logp; *kinetic_out = r.state->kinetic_energy;
+    *energy_error_out = r.state->energy() - initial_energy;
+    return 0;
+}
+
+// The per-vector primitives of the non-Euclidean trajectory kinds (reference src/math/util.rs:507-741,
+// src/math/cpu_math.rs:496-551), one call each: op 0 std_norm_flow(pos = a, vel = b) -> out1 = pos_out, out2 = vel;
+// 1 std_norm_grad_flow(pos = a, grad = b, vel = c) -> out1; 2 esh_momentum_update(gradient = a, momentum = b, step = eps)
+// -> out1 = momentum, *scalar = kinetic-energy change; 3 array_normalize(a) -> out1; 4 sin / cos of eps -> out1[0], out1[1].
+int nmo_traj_kat(const MathCfg* cfg, int64_t op, uint64_t n, const double* a, const double* b, const double* c, double eps,
+                 double* out1, double* out2, double* scalar) {
+    Ctx m{*cfg};
+    switch (op) {
+    case 0: { Vec v(b, b + n); m.std_norm_flow(a, out1, v.data(), eps, n); for (uint64_t i = 0; i < n; ++i) out2[i] = v[i]; return 0; }
+    case 1: m.std_norm_grad_flow(a, b, c, out1, eps, n); return 0;
+    case 2: { for (uint64_t i = 0; i < n; ++i) out1[i] = b[i]; *scalar = m.esh_momentum_update(a, out1, eps, n); return 0; }
+    case 3: { for (uint64_t i = 0; i < n; ++i) out1[i] = a[i]; m.array_normalize(out1, n); return 0; }
+    case 4: out1[0] = m.sin(eps); out1[1] = m.cos(eps); return 0;
+    }
+    return 1;
+}
+
+// nmo_leapfrog with a KineticEnergyKind: `kinetic_start` is the start point's kinetic_energy (the accumulated change for
+// the microcanonical kind); `max_energy_error` as in the leapfrog (returns 1 for a divergence).
+int nmo_leapfrog_traj(const MathCfg* cfg, int64_t traj_kind, int64_t kind, uint64_t dim, const double* params, uint64_t n_params,
+                      const double* z, const double* v, const double* gz, const double* sigma, const double* mu,
+                      double eps, double logdet, double initial_energy, double kinetic_start, double max_energy_error,
+                      double* z_out, double* v_out, double* gz_out, double* x_out, double* gx_out,
+                      double* logp_out, double* kinetic_out, double* energy_error_out) {
+    Ctx m{*cfg};
+    Density d = make_density(kind, dim, params, n_params);
+    Hamiltonian h(&m, &d);
+    h.kind = traj_kind;
+    for (uint64_t i = 0; i < dim; ++i) { h.mm.stds[i] = sigma[i]; h.mm.mean[i] = mu[i]; h.mm.inv_stds[i] = 1.0 / sigma[i]; }
+    h.mm.logdet = logdet; h.mm.id = 0;
+    h.step_size = std::fabs(eps);
+    State s = std::make_shared<Point>(dim);
+    for (uint64_t i = 0; i < dim; ++i) { s->z[i] = z[i]; s->v[i] = v[i]; s->gz[i] = gz[i]; }
+    s->initial_energy = initial_energy; s->transform_id = 0; s->kinetic_energy = kinetic_start;
+    LeapfrogResult r = h.leapfrog(s, eps < 0 ? -1 : +1, 1.0, initial_energy, max_energy_error, nullptr);
     if (r.kind != LF_OK) return 1;
     for (uint64_t i = 0; i < dim; ++i) {
         z_out[i] = r.state->z[i]; v_out[i] = r.state->v[i]; gz_out[i] = r.state->gz[i];

@@ -41,11 +41,12 @@ class Settings(C.Structure):
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_epsilon", C.c_double),
         ("adam_learning_rate", C.c_double),
         ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
-        ("freeze_transform", C.c_uint64),
+        ("freeze_transform", C.c_uint64), ("trajectory_kind", C.c_uint64),
     ]
 
 
 ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
+TRAJ_EUCLIDEAN, TRAJ_EXACT_NORMAL, TRAJ_MICROCANONICAL = 0, 1, 2
 
 STATS_DTYPE = np.dtype([
     ("draw", "<u8"), ("chain", "<u8"), ("depth", "<u8"), ("maxdepth_reached", "<u8"), ("diverging", "<u8"),
@@ -266,6 +267,28 @@ def lowrank_kat(cfg, precision_diag, stds, mean, vals, vecs, mu_lr, x, which=-1)
                                z, gz, C.byref(logp), C.byref(logdet), x_rt, C.byref(logp_rt), C.byref(logdet_rt))
     return dict(rc=rc, z=z, gz=gz, x_rt=x_rt, logp=logp.value, logdet=logdet.value, logp_rt=logp_rt.value,
                 logdet_rt=logdet_rt.value)
+
+
+def traj_kat(cfg, op, a=None, b=None, c=None, eps=0.0):
+    """The non-Euclidean trajectory kinds' vector primitives (nmo_traj_kat): op "flow" (pos, vel) -> (pos_out, vel),
+    "grad_flow" (pos, grad, vel) -> vel_out, "esh" (gradient, momentum) -> (momentum, dKE), "normalize" (v) -> v,
+    "sincos" -> (sin eps, cos eps)."""
+    f = lambda x: np.ascontiguousarray(x if x is not None else np.zeros(1), dtype=np.float64)
+    opn = {"flow": 0, "grad_flow": 1, "esh": 2, "normalize": 3, "sincos": 4}[op]
+    n = len(a) if a is not None else 2
+    o1, o2, sc = np.empty(max(n, 2)), np.empty(max(n, 2)), C.c_double()
+    P = C.POINTER(C.c_double)
+    rc = lib().nmo_traj_kat(C.byref(cfg), C.c_int64(opn), C.c_uint64(n if a is not None else 0), f(a).ctypes.data_as(P),
+                            f(b).ctypes.data_as(P), f(c).ctypes.data_as(P), C.c_double(eps), o1.ctypes.data_as(P),
+                            o2.ctypes.data_as(P), C.byref(sc))
+    assert rc == 0
+    if op == "flow":
+        return o1[:n], o2[:n]
+    if op == "esh":
+        return o1[:n], sc.value
+    if op == "sincos":
+        return o1[0], o1[1]
+    return o1[:n]
 
 
 def adam_sequence(initial_step, accept, target, beta1, beta2, epsilon, learning_rate, cfg=None):

@@ -25,8 +25,8 @@ def banana(chain, x):
     return lp, g
 
 
-def run_both(oracle, fn_engine, fn_oracle, dim, n, tune, draws, seed=3, low_rank=False):
-    s = (N.LowRankNutsSettings if low_rank else N.DiagNutsSettings)(num_chains=n, seed=seed, num_tune=tune, store_divergences=True)
+def run_both(oracle, fn_engine, fn_oracle, dim, n, tune, draws, seed=3, low_rank=False, **skw):
+    s = (N.LowRankNutsSettings if low_rank else N.DiagNutsSettings)(num_chains=n, seed=seed, num_tune=tune, store_divergences=True, **skw)
     logp = N.LogpSpec.host_callback(dim, fn_engine, threads=2)
     b = N.ChainBatch(s, logp, n)
     x0 = b.init_positions_uniform()
@@ -84,6 +84,18 @@ def test_host_callback_matches_oracle(oracle):
     compare(status, pos, st, res)
     # one call per leapfrog + the chosen point of every draw + set_position's (3 + the step-size search)
     assert calls >= int(st["n_steps"].sum()) + 90 * 5
+
+
+def test_host_callback_with_trajectory_kinds(oracle):
+    """the ExactNormal and Microcanonical integrators around a host density, recoverable errors included (KinWrap<HostCb>)"""
+    def walled(chain, x):
+        if x[1] > 2.5:
+            raise N.RecoverableLogpError("outside the support")
+        return banana(chain, x)
+    for kind in (N.KineticEnergyKind.EXACT_NORMAL, N.KineticEnergyKind.MICROCANONICAL):
+        status, pos, st, res, _ = run_both(oracle, walled, walled, 5, 4, 50, 80, seed=11 + kind, trajectory_kind=kind)
+        compare(status, pos, st, res)
+        assert st["diverging"].sum() > 0
 
 
 def test_host_callback_low_rank_transformation(oracle):

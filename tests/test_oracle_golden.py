@@ -539,3 +539,87 @@ def test_arithmetic_bridge_is_no_wider_than_the_references_own_simd_spread(oracl
             firsts["simd"] += list(f_simd)
         assert min(firsts["gpu"]) >= 10, (name, firsts)                                   # nothing departs in the first draws
         assert np.median(firsts["gpu"]) >= 0.6 * np.median(firsts["simd"]), (name, firsts)
+
+
+# ---- the non-Euclidean trajectory kinds (NutsSettings::trajectory_kind) ----------------------------------
+def test_trajectory_kind_primitives_reference_formulas(oracle):
+    """The reference's own tests of std_norm_flow / std_norm_grad_flow (src/math/util.rs:808-868) compare the SIMD kernels
+    with the scalar formulas; the same formulas pin the oracle here — exactly, head (fused) and scalar tail (unfused)
+    separately — plus esh_momentum_update / array_normalize (src/math/cpu_math.rs:496-551) against their published algebra."""
+    rng = np.random.default_rng(12)
+    ref = oracle.ref_cfg()
+    fma = math.fma if hasattr(math, "fma") else None
+    for n in (3, 4, 32, 35):
+        for eps in (-7.3, -0.4, 0.0, 0.25, 3.9):
+            p, v, g = rng.normal(size=n), rng.normal(size=n), rng.normal(size=n)
+            es, ec = math.sin(eps), math.cos(eps)
+            po, vo = oracle.traj_kat(ref, "flow", p, v, eps=eps)
+            gv = oracle.traj_kat(ref, "grad_flow", p, g, v, eps=eps)
+            head = n - n % 4
+            for i in range(n):
+                if i < head and fma:
+                    assert po[i] == fma(p[i], ec, v[i] * es) and vo[i] == fma(p[i], -es, v[i] * ec)
+                    assert gv[i] == fma(eps, p[i] + g[i], v[i])
+                elif i >= head:       # the scalar tail loops are written without mul_add (util.rs:561-565, :644-646)
+                    assert po[i] == p[i] * ec + v[i] * es and vo[i] == p[i] * (-es) + v[i] * ec
+                    assert gv[i] == v[i] + eps * (p[i] + g[i])
+                assert abs(po[i] - (p[i] * ec + v[i] * es)) <= 4e-16 * (abs(p[i]) + abs(v[i]))
+            # the flow is a rotation of every (q_i, v_i) plane
+            assert np.allclose(po ** 2 + vo ** 2, p ** 2 + v ** 2, rtol=1e-14)
+    for n in (2, 7, 64):
+        g, u = rng.normal(size=n) * 3, rng.normal(size=n)
+        un = oracle.traj_kat(ref, "normalize", u)
+        assert un.tolist() == (u * (1.0 / math.sqrt(sum(x * x for x in u)))).tolist()
+        for step in (0.3, -0.3, 2.0):
+            m, dke = oracle.traj_kat(ref, "esh", g, un, eps=step)
+            gn = np.linalg.norm(g)
+            e = g / gn
+            ue = float(un @ e)
+            delta = step * gn / (n - 1)
+            zeta = math.exp(-delta)
+            raw = e * (1 - zeta) * (1 + zeta + ue * (1 - zeta)) + 2 * zeta * un
+            assert np.allclose(m, raw / np.linalg.norm(raw), rtol=1e-12, atol=1e-15)
+            assert abs(np.linalg.norm(m) - 1) < 1e-15
+            assert abs(dke - (delta - math.log(2) + math.log1p(ue + (1 - ue) * zeta * zeta)) * (n - 1)) < 1e-12 * max(1, abs(dke))
+            # the engine's arithmetic differs from it by reduction order only
+            m2, dke2 = oracle.traj_kat(oracle.gpu_cfg(64), "esh", g, un, eps=step)
+            assert np.abs(m - m2).max() < 1e-14 and abs(dke - dke2) < 1e-12 * max(1, abs(dke))
+
+
+def test_det_sincos_within_an_ulp_of_libm(oracle):
+    gpu, ref = oracle.gpu_cfg(64), oracle.ref_cfg()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-10, 10, 4000), rng.uniform(-3000, 3000, 500),
+                         [0.0, -0.0, 1e-300, 5e-9, math.pi / 4, math.pi / 2, math.pi, 1.5707963267948966, 3.0, 100.0]])
+    for x in xs:
+        s_, c_ = oracle.traj_kat(gpu, "sincos", eps=float(x))
+        assert ulps(s_, math.sin(x)) <= 1 and ulps(c_, math.cos(x)) <= 1, x
+        sm, cm = oracle.traj_kat(gpu, "sincos", eps=float(-x))
+        assert sm == -s_ and cm == c_                     # exactly odd / even, like libm's
+        sr, cr = oracle.traj_kat(ref, "sincos", eps=float(x))      # the platform libm (this interpreter may carry another build of it)
+        assert ulps(sr, math.sin(x)) <= 1 and ulps(cr, math.cos(x)) <= 1
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        s_, c_ = oracle.traj_kat(gpu, "sincos", eps=bad)
+        assert math.isnan(s_) and math.isnan(c_)
+
+
+def test_trajectory_kinds_sample_the_right_posterior(oracle):
+    """Both kinds inside the NUTS tree reproduce the moments of an iid normal (the reference's envelope for the Euclidean
+    kind, src/adapt_strategy.rs:367-435); the exact-normal geodesic accepts (almost) everything; and the two arithmetic
+    modes of the oracle agree on the first draws."""
+    dim, n = 20, 4
+    x0 = oracle.init_positions_uniform(5, 0, n, dim)
+    for kind in (oracle.TRAJ_EXACT_NORMAL, oracle.TRAJ_MICROCANONICAL):
+        s = oracle.default_settings()
+        s.num_tune, s.num_draws, s.seed, s.trajectory_kind = 300, 300, 5, kind
+        pos, st, steps, failed = oracle.run(s, 0, dim, np.array([3.0]), oracle.ref_cfg(), n, x0, 600)
+        post = pos[300:]
+        assert failed == 0 and abs(post.mean() - 3.0) < 0.1 and abs(post.var() - 1.0) < 0.15
+        if kind == oracle.TRAJ_EXACT_NORMAL:
+            assert st["mean_tree_accept"][300:].mean() > 0.99
+        else:
+            assert st["diverging"].sum() <= 5
+        # (only the first draws: at step sizes near pi — the dual-averaging cap — two geodesic steps return to the start and the
+        # U-turn products are pure rounding noise, so trajectories of the two arithmetics part early for this kind)
+        pos2, st2, _, _ = oracle.run(s, 0, dim, np.array([3.0]), oracle.gpu_cfg(64), n, x0, 3)
+        assert np.allclose(pos2[:3], pos[:3], rtol=1e-9, atol=1e-12)
