@@ -495,6 +495,12 @@ nm_status nm_vec_array_all_finite(nm_math* m, const nm_vec* a, uint64_t and_nonz
 /* M14 logp_array (math.rs:46-50): fills `gradient`, *logp; *status = 0 ok / 1 recoverable / 2 fatal (always 0 here) */
 nm_status nm_vec_logp_array(nm_math* m, const nm_vec* position, nm_vec* gradient, double* logp, uint64_t* status);
 nm_status nm_vec_sq_norm_sum(nm_math* m, const nm_vec* x, const nm_vec* y, double* out);             /* M15 (math.rs:92) */
+/* the Math methods of the non-Euclidean KineticEnergyKinds (src/math/math.rs:155-200; src/math/util.rs:507-741,
+ * src/math/cpu_math.rs:496-551).  `vel_out` may be `vel` (std_norm_grad_flow_inplace). */
+nm_status nm_vec_std_norm_flow(nm_math* m, const nm_vec* pos, nm_vec* pos_out, nm_vec* vel, double epsilon);
+nm_status nm_vec_std_norm_grad_flow(nm_math* m, const nm_vec* pos, const nm_vec* grad, const nm_vec* vel, nm_vec* vel_out, double epsilon);
+nm_status nm_vec_esh_momentum_update(nm_math* m, const nm_vec* gradient, nm_vec* momentum, double step_size, double* kinetic_energy_change);
+nm_status nm_vec_array_normalize(nm_math* m, nm_vec* v);
 
 /* Chain RNG key derivation (host helper; reference src/sampler.rs:1105-1106, :761). */
 nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]);

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
     "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_host_logp_calls",
     # the per-vector `Math` seam
-    "nm_math_create", "nm_math_destroy", "nm_math_dim", "nm_math_threads", "nm_math_last_error", "nm_vec_new", "nm_vec_free", "nm_vec_read_from_slice", "nm_vec_write_to_slice", "nm_vec_copy_into", "nm_vec_fill_array", "nm_vec_array_recip", "nm_vec_axpy_out", "nm_vec_axpy", "nm_vec_array_mult", "nm_vec_array_vector_dot", "nm_vec_scalar_prods3", "nm_vec_array_gaussian", "nm_vec_array_update_variance", "nm_vec_array_update_var_inv_std_draw_grad", "nm_vec_array_update_var_inv_std_grad", "nm_vec_array_update_var_inv_std_draw", "nm_vec_array_sum_ln", "nm_vec_array_all_finite", "nm_vec_logp_array", "nm_vec_sq_norm_sum",
+    "nm_math_create", "nm_math_destroy", "nm_math_dim", "nm_math_threads", "nm_math_last_error", "nm_vec_new", "nm_vec_free", "nm_vec_read_from_slice", "nm_vec_write_to_slice", "nm_vec_copy_into", "nm_vec_fill_array", "nm_vec_array_recip", "nm_vec_axpy_out", "nm_vec_axpy", "nm_vec_array_mult", "nm_vec_array_vector_dot", "nm_vec_scalar_prods3", "nm_vec_array_gaussian", "nm_vec_array_update_variance", "nm_vec_array_update_var_inv_std_draw_grad", "nm_vec_array_update_var_inv_std_grad", "nm_vec_array_update_var_inv_std_draw", "nm_vec_array_sum_ln", "nm_vec_array_all_finite", "nm_vec_logp_array", "nm_vec_sq_norm_sum", "nm_vec_std_norm_flow", "nm_vec_std_norm_grad_flow", "nm_vec_esh_momentum_update", "nm_vec_array_normalize",
 ]
 
 
@@ -204,6 +204,10 @@ def load():
     L.nm_vec_array_all_finite.argtypes = [vp, vp, u64, pu]
     L.nm_vec_logp_array.argtypes = [vp, vp, vp, pd, pu]
     L.nm_vec_sq_norm_sum.argtypes = [vp, vp, vp, pd]
+    L.nm_vec_std_norm_flow.argtypes = [vp, vp, vp, vp, dbl]
+    L.nm_vec_std_norm_grad_flow.argtypes = [vp, vp, vp, vp, vp, dbl]
+    L.nm_vec_esh_momentum_update.argtypes = [vp, vp, vp, dbl, pd]
+    L.nm_vec_array_normalize.argtypes = [vp, vp]
     L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_last_error.restype = C.c_char_p

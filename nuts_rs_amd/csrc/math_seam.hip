@@ -26,7 +26,8 @@ struct nm_math {
 
 namespace {
 enum Op : int { OP_AXPY_OUT, OP_AXPY, OP_MULT, OP_DOT, OP_PRODS3, OP_GAUSSIAN, OP_UPD_VAR, OP_STD_DRAW_GRAD, OP_STD_GRAD, OP_STD_DRAW,
-                OP_SUM_LN, OP_ALL_FINITE, OP_ALL_FINITE_NONZERO, OP_LOGP, OP_SQ_NORM_SUM, OP_FILL, OP_RECIP, OP_COPY };
+                OP_SUM_LN, OP_ALL_FINITE, OP_ALL_FINITE_NONZERO, OP_LOGP, OP_SQ_NORM_SUM, OP_FILL, OP_RECIP, OP_COPY,
+                OP_STD_NORM_FLOW, OP_STD_NORM_GRAD_FLOW, OP_ESH, OP_NORMALIZE };
 struct VArgs {
     int op;
     uint64_t dim;
@@ -200,6 +201,36 @@ __global__ __launch_bounds__(64 * W) void vec_op_kernel(const VArgs A) {
     case OP_COPY:          // M13 copy_into
         load_tile<DPL, W>(a, A.a);
         store_tile<DPL, W>(a, A.b);
+        break;
+    case OP_STD_NORM_FLOW: {   // std_norm_flow (util.rs:507-589): pos_out = p cos e + v sin e ; vel = -p sin e + v cos e
+        load_tile<DPL, W>(a, A.a); load_tile<DPL, W>(c, A.c);
+        const double2 sc = dsincos(A.s0);
+        const double es = sc.x, ec = sc.y, nes = -sc.x;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            b.a[k] = valid(k) ? __builtin_fma(a.a[k], ec, c.a[k] * es) : 0.0;
+            d.a[k] = valid(k) ? __builtin_fma(a.a[k], nes, c.a[k] * ec) : 0.0;
+        }
+        store_tile<DPL, W>(b, A.b); store_tile<DPL, W>(d, A.c);
+        break;
+    }
+    case OP_STD_NORM_GRAD_FLOW:   // std_norm_grad_flow / _inplace (util.rs:591-741): vel_out = fma(e, pos + grad, vel)
+        load_tile<DPL, W>(a, A.a); load_tile<DPL, W>(b, A.b); load_tile<DPL, W>(c, A.c);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) d.a[k] = valid(k) ? __builtin_fma(A.s0, a.a[k] + b.a[k], c.a[k]) : 0.0;
+        store_tile<DPL, W>(d, A.d);
+        break;
+    case OP_ESH: {         // esh_momentum_update (cpu_math.rs:505-551)
+        load_tile<DPL, W>(a, A.a); load_tile<DPL, W>(b, A.b);
+        const double dke = esh_update_core<DPL, W>(a, b, A.s0, dim, R);
+        store_tile<DPL, W>(b, A.b);
+        if (tid() == 0) A.out[0] = dke;
+        break;
+    }
+    case OP_NORMALIZE:     // array_normalize (cpu_math.rs:496-503)
+        load_tile<DPL, W>(a, A.a);
+        normalize_tile<DPL, W>(a, R);
+        store_tile<DPL, W>(a, A.a);
         break;
     }
 }
@@ -382,4 +413,21 @@ extern "C" nm_status nm_vec_logp_array(nm_math* m, const nm_vec* position, nm_ve
 }
 extern "C" nm_status nm_vec_sq_norm_sum(nm_math* m, const nm_vec* x, const nm_vec* y, double* out) {
     NM_CHECK(m, x, y, out); VArgs A{}; A.op = OP_SQ_NORM_SUM; A.a = x->d; A.b = y->d; return run(m, A, out, 1);
+}
+
+// the Math methods of the non-Euclidean KineticEnergyKinds (math.rs:155-200)
+extern "C" nm_status nm_vec_std_norm_flow(nm_math* m, const nm_vec* pos, nm_vec* pos_out, nm_vec* vel, double epsilon) {
+    NM_CHECK(m, pos, pos_out, vel); VArgs A{}; A.op = OP_STD_NORM_FLOW; A.a = pos->d; A.b = pos_out->d; A.c = vel->d; A.s0 = epsilon; return run(m, A);
+}
+extern "C" nm_status nm_vec_std_norm_grad_flow(nm_math* m, const nm_vec* pos, const nm_vec* grad, const nm_vec* vel, nm_vec* vel_out, double epsilon) {
+    NM_CHECK(m, pos, grad, vel, vel_out);
+    VArgs A{}; A.op = OP_STD_NORM_GRAD_FLOW; A.a = pos->d; A.b = grad->d; A.c = vel->d; A.d = vel_out->d; A.s0 = epsilon; return run(m, A);
+}
+extern "C" nm_status nm_vec_esh_momentum_update(nm_math* m, const nm_vec* gradient, nm_vec* momentum, double step_size, double* kinetic_energy_change) {
+    NM_CHECK(m, gradient, momentum, kinetic_energy_change);
+    if (m->dim < 2) return mfail(NM_ERR_INVALID_ARG, "ESH dynamics requires at least 2 dimensions");
+    VArgs A{}; A.op = OP_ESH; A.a = gradient->d; A.b = momentum->d; A.s0 = step_size; return run(m, A, kinetic_energy_change, 1);
+}
+extern "C" nm_status nm_vec_array_normalize(nm_math* m, nm_vec* v) {
+    NM_CHECK(m, v); VArgs A{}; A.op = OP_NORMALIZE; A.a = v->d; return run(m, A);
 }

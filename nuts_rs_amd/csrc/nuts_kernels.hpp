@@ -811,24 +811,28 @@ NM_DEV void normalize_tile(Tile<DPL>& v, Reducer<W>& R) {
 }
 // esh_momentum_update (reference src/math/cpu_math.rs:505-551): the ESH momentum step on the unit sphere; returns the
 // change of the kinetic energy.  Padding elements hold 0 and stay 0.
-template <int DPL, int W, class Dens>
-NM_DEV double esh_update(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& g, Tile<DPL>& p, double step_size) {
-    const double grad_norm = __builtin_sqrt(sum_sq_tile(g, C.red));
+template <int DPL, int W>
+NM_DEV double esh_update_core(const Tile<DPL>& g, Tile<DPL>& p, double step_size, int dim, Reducer<W>& R) {
+    const double grad_norm = __builtin_sqrt(sum_sq_tile(g, R));
     const double inv_grad_norm = 1.0 / grad_norm;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) acc = acc + p.a[k] * g.a[k] * inv_grad_norm;
-    const double momentum_proj = C.red.sum(acc);
-    const double dims_m1 = (double)(C.dim - 1);
+    const double momentum_proj = R.sum(acc);
+    const double dims_m1 = (double)(dim - 1);
     const double delta = step_size * grad_norm / dims_m1;
     const double zeta = uexp(-delta);
     const double coeff_g = (1.0 - zeta) * (1.0 + zeta + momentum_proj * (1.0 - zeta));
     const double coeff_p = 2.0 * zeta;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) p.a[k] = coeff_g * (g.a[k] * inv_grad_norm) + coeff_p * p.a[k];
-    normalize_tile(p, C.red);
+    normalize_tile(p, R);
     const double arg = momentum_proj + (1.0 - momentum_proj) * zeta * zeta;
     return (delta - 6.93147180559945286227e-01 + ulog1p(arg)) * dims_m1;
+}
+template <int DPL, int W, class Dens>
+NM_DEV double esh_update(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& g, Tile<DPL>& p, double step_size) {
+    return esh_update_core<DPL, W>(g, p, step_size, C.dim, C.red);
 }
 // leapfrog's divergence criterion (transformed_hamiltonian.rs:583-590)
 template <int DPL, int W, class Dens>

@@ -155,3 +155,34 @@ def oracle_sum(oracle, cfg, terms):
     use vector_dot with exact products: t_i * 1.0 accumulates as fma(t_i, 1.0, acc) = acc + t_i exactly."""
     t = np.ascontiguousarray(terms, dtype=np.float64)
     return oracle.lib().nmo_vector_dot(C.byref(cfg), t, np.ones(len(t)), len(t))
+
+
+@pytest.mark.parametrize("dim", [2, 10, 101, 300, 1024, 4000])
+def test_trajectory_kind_methods_bit_exact(oracle, dim):
+    """std_norm_flow / std_norm_grad_flow(_inplace) / esh_momentum_update / array_normalize (src/math/math.rs:155-200) against
+    the oracle's primitives in the engine's arithmetic."""
+    rng = np.random.default_rng(100 + dim)
+    M = DevMath(N.LogpSpec.iid_normal(dim, 0.0))
+    L, h = M.L, M.h
+    cfg = oracle.gpu_cfg(M.threads)
+    p, v, g = rng.normal(size=dim), rng.normal(size=dim), rng.normal(size=dim) * 2
+    for eps in (0.37, -1.9, 3.0):
+        vp_, vv, vo = M.vec(p), M.vec(v), M.vec()
+        assert L.nm_vec_std_norm_flow(h, vp_, vo, vv, eps) == 0
+        po, vn = oracle.traj_kat(cfg, "flow", p, v, eps=eps)
+        assert same(M.get(vo), po) and same(M.get(vv), vn)
+        vg, vv2, vout = M.vec(g), M.vec(v), M.vec()
+        assert L.nm_vec_std_norm_grad_flow(h, vp_, vg, vv2, vout, eps) == 0
+        want = oracle.traj_kat(cfg, "grad_flow", p, g, v, eps=eps)
+        assert same(M.get(vout), want)
+        assert L.nm_vec_std_norm_grad_flow(h, vp_, vg, vv2, vv2, eps) == 0 and same(M.get(vv2), want)     # _inplace
+    vu = M.vec(v)
+    assert L.nm_vec_array_normalize(h, vu) == 0
+    un = oracle.traj_kat(cfg, "normalize", v)
+    assert same(M.get(vu), un)
+    for step in (0.2, -0.45, 1.7):
+        vm, dke = M.vec(un), C.c_double()
+        assert L.nm_vec_esh_momentum_update(h, M.vec(g), vm, step, C.byref(dke)) == 0
+        m_o, dke_o = oracle.traj_kat(cfg, "esh", g, un, eps=step)
+        assert same(M.get(vm), m_o) and same([dke.value], [dke_o])
+    M.close()
