@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 10
+#define NM_ABI_VERSION 11
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -115,7 +115,28 @@ typedef struct nm_settings {
      * accumulated change, a divergence is |energy error| >= max_energy_error; needs dim >= 2).  The non-Euclidean kinds run
      * with the diagonal adaptation on the one-chain-per-block kernels (built-in densities and NM_LOGP_HOST_CALLBACK). */
     uint64_t trajectory_kind;                /* NM_TRAJ_EUCLIDEAN */
+    /* `MclmcSettings` (src/sampler.rs:266-317; experimental upstream): sampler = NM_SAMPLER_MCLMC replaces the NUTS tree by
+     * `MclmcChain` (src/mclmc.rs:212-409): per draw round(subsample_frequency L / eps) leapfrogs of the current kinetic kind,
+     * a partial momentum refresh (isokinetic Langevin / Ornstein-Uhlenbeck, transformed_hamiltonian.rs:770-825) on both sides
+     * of each, and with dynamic_step_size the halve-and-retry ladder on a divergence (at most 10 halvings).  The step size is
+     * the constant mclmc_step_size (the engine sets step_size_method = NM_STEP_FIXED, fixed_step_size = mclmc_step_size, as
+     * DiagMclmcSettings::new_chain does, sampler.rs:421-423); geometry adapts as usual.  NM_ADAPT_DIAG, built-in densities and
+     * NM_LOGP_HOST_CALLBACK, dim >= 2.  nm_draw_stats: depth = leapfrogs taken, energy_change, average_step_size. */
+    uint64_t sampler;                        /* NM_SAMPLER_NUTS */
+    double   mclmc_step_size;                /* 0.5 */
+    double   momentum_decoherence_length;    /* 3.0 */
+    double   subsample_frequency;            /* 1.0 */
+    uint64_t dynamic_step_size;              /* 1 */
+    uint64_t mclmc_trajectory_kind;          /* NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL */
+    double   trajectory_switch_fraction;     /* 0.3 */
 } nm_settings;
+
+#define NM_SAMPLER_NUTS 0
+#define NM_SAMPLER_MCLMC 1
+/* MclmcTrajectoryKind (src/mclmc.rs:44-70) */
+#define NM_MCLMC_MICROCANONICAL 0
+#define NM_MCLMC_EUCLIDEAN 1
+#define NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL 2
 
 #define NM_TRAJ_EUCLIDEAN 0
 #define NM_TRAJ_EXACT_NORMAL 1
@@ -132,6 +153,8 @@ typedef struct nm_settings {
 void nm_settings_default(nm_settings* s);
 /* Fill `s` with `LowRankNutsSettings::default()` (reference src/sampler.rs:636-642: num_tune 800, mass_matrix_update_freq 20). */
 void nm_settings_default_low_rank(nm_settings* s);
+/* Fill `s` with `DiagMclmcSettings::default()` (reference src/sampler.rs:342-374: step size 0.5, L 3, num_tune 400, 6 chains). */
+void nm_settings_default_mclmc(nm_settings* s);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-density registry.  The reference takes an arbitrary `CpuLogpFunc::logp(&[f64], &mut [f64])
@@ -232,6 +255,8 @@ typedef struct nm_draw_stats {
                                       statistics (first draw: compared with -1, src/sampler.rs:795), else -1 (= None) */
     uint64_t num_eigenvalues;      /* MatrixStats.num_eigenvalues (src/transform/low_rank.rs:205-229) on the draws where
                                       transformation_update_id >= 0 (0 while the transformation has no low-rank part), else 0 */
+    double   energy_change;        /* MclmcStats.energy_change (= log_weight, src/mclmc.rs:91-124, :438-439); NaN for NUTS draws */
+    double   average_step_size;    /* MclmcStats.average_step_size: trajectory time / leapfrogs taken; NaN for NUTS draws */
 } nm_draw_stats;
 /* Notes on reference naming.  `NutsStats.draw` (src/chain.rs:215-232) is read AFTER `draw_count += 1`
  * (src/chain.rs:184, :195) and therefore equals nm_draw_stats.draw + 1; `divergence_draw` likewise.
@@ -443,7 +468,7 @@ nm_status nm_turning_batch(uint64_t n, uint64_t dim, uint64_t dims_per_lane,
                            double* d_out_t, void* stream);
 
 /* Scalar special functions used on the device (deterministic restatements):
- * op 0 exp, 1 ln, 2 ln_1p, 3 logaddexp(a,b), 4 sqrt, 5 a/b.  d_a, d_b, d_out are device arrays [n]. */
+ * op 0 exp, 1 ln, 2 ln_1p, 3 logaddexp(a,b), 4 sqrt, 5 a/b, 7 exp_m1, 8 sin, 9 cos.  d_a, d_b, d_out are device arrays [n]. */
 nm_status nm_scalar_math_batch(uint64_t op, uint64_t n, const double* d_a, const double* d_b,
                                double* d_out, void* stream);
 

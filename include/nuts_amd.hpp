@@ -105,6 +105,40 @@ struct DiagNutsSettings {
     }
 };
 
+// `DiagMclmcSettings` = MclmcSettings<EuclideanAdaptOptions<DiagAdaptExpSettings>> (src/sampler.rs:266-374; experimental upstream)
+enum class MclmcTrajectoryKind : uint64_t {    // src/mclmc.rs:44-70
+    Microcanonical = NM_MCLMC_MICROCANONICAL, Euclidean = NM_MCLMC_EUCLIDEAN,
+    EuclideanEarlyThenMicrocanonical = NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL };
+struct DiagMclmcSettings {
+    double step_size = 0.5, momentum_decoherence_length = 3.0;
+    uint64_t num_tune = 400, num_draws = 1000, num_chains = 6, seed = 0;
+    double max_energy_error = 1000.0;
+    bool store_unconstrained = false, store_gradient = false, store_transformed = false, store_divergences = false;
+    EuclideanAdaptOptions adapt_options;
+    double subsample_frequency = 1.0;
+    bool dynamic_step_size = true;
+    MclmcTrajectoryKind trajectory_kind = MclmcTrajectoryKind::EuclideanEarlyThenMicrocanonical;
+    double trajectory_switch_fraction = 0.3;
+
+    // the NutsSettings-shaped part (seed, counts, adaptation, store_* flags), as new_chain builds its GlobalStrategy from it
+    DiagNutsSettings base() const {
+        DiagNutsSettings n;
+        n.num_tune = num_tune; n.num_draws = num_draws; n.num_chains = num_chains; n.seed = seed;
+        n.max_energy_error = max_energy_error; n.store_unconstrained = store_unconstrained; n.store_gradient = store_gradient;
+        n.store_transformed = store_transformed; n.store_divergences = store_divergences; n.adapt_options = adapt_options;
+        return n;
+    }
+    nm_settings to_c() const {
+        nm_settings s = base().to_c();
+        s.sampler = NM_SAMPLER_MCLMC;
+        s.mclmc_step_size = step_size; s.momentum_decoherence_length = momentum_decoherence_length;
+        s.subsample_frequency = subsample_frequency; s.dynamic_step_size = dynamic_step_size;
+        s.mclmc_trajectory_kind = (uint64_t)trajectory_kind; s.trajectory_switch_fraction = trajectory_switch_fraction;
+        s.step_size_method = NM_STEP_FIXED; s.fixed_step_size = step_size;      // Fixed(self.step_size) (sampler.rs:421-423)
+        return s;
+    }
+};
+
 // A registered device density (the device-side stand-in for a `CpuLogpFunc`, src/math/cpu_math.rs:885-891)
 struct LogpSpec {
     uint64_t kind = NM_LOGP_IID_NORMAL, dim = 0;
@@ -158,6 +192,17 @@ public:
     ChainBatch(const DiagNutsSettings& settings, const LogpSpec& logp, uint64_t n_chains, uint64_t chain_id_offset = 0,
                int64_t device = -1)
         : settings_(settings), n_(n_chains), dim_(logp.dim), offset_(chain_id_offset) {
+        nm_settings s = settings.to_c();
+        nm_logp_spec l = logp.to_c();
+        nm_engine_config cfg;
+        nm_engine_config_default(&cfg);
+        cfg.device = device; cfg.chain_id_offset = chain_id_offset;
+        check(nm_engine_create(&s, &l, n_chains, &cfg, &h_));
+    }
+    // `DiagMclmcSettings::new_chain` for every chain: the MCLMC sampler instead of the NUTS tree
+    ChainBatch(const DiagMclmcSettings& settings, const LogpSpec& logp, uint64_t n_chains, uint64_t chain_id_offset = 0,
+               int64_t device = -1)
+        : settings_(settings.base()), n_(n_chains), dim_(logp.dim), offset_(chain_id_offset) {
         nm_settings s = settings.to_c();
         nm_logp_spec l = logp.to_c();
         nm_engine_config cfg;

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
-    "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_engine_set_lowrank_estimator",
+    "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
     "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_host_logp_calls",
@@ -54,6 +54,9 @@ class NmSettings(C.Structure):
         ("adam_learning_rate", C.c_double),
         ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
         ("freeze_transform", C.c_uint64), ("trajectory_kind", C.c_uint64),
+        ("sampler", C.c_uint64), ("mclmc_step_size", C.c_double), ("momentum_decoherence_length", C.c_double),
+        ("subsample_frequency", C.c_double), ("dynamic_step_size", C.c_uint64), ("mclmc_trajectory_kind", C.c_uint64),
+        ("trajectory_switch_fraction", C.c_double),
     ]
 
 
@@ -79,7 +82,7 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
-    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"),
+    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"), ("energy_change", "<f8"), ("average_step_size", "<f8"),
 ])
 
 # nm_draw_outputs: the draws, the scalar statistics and the vector-valued statistics (reference stat names)
@@ -163,6 +166,8 @@ def load():
     L.nm_pick_tiling.argtypes = [u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.nm_settings_default_low_rank.argtypes = [C.POINTER(NmSettings)]
     L.nm_settings_default_low_rank.restype = None
+    L.nm_settings_default_mclmc.argtypes = [C.POINTER(NmSettings)]
+    L.nm_settings_default_mclmc.restype = None
     L.nm_engine_set_lowrank_estimator.argtypes = [vp, vp, vp, u64]
     L.nm_lowrank_compute_update.argtypes = [vp, u64, u64, vp, vp, dbl, dbl, vp, vp, C.POINTER(u64), vp, vp, vp]
     L.nm_engine_set_transform.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]

@@ -280,6 +280,26 @@ NM_DEV double logaddexp(double a, double b) {
     return diff;
 }
 
+// exp(x) - 1 for the isokinetic momentum refresh (reference f64::exp_m1, transformed_hamiltonian.rs:800-801): the same
+// operation sequence as oracle/nmo_math.hpp det_expm1 (Taylor series to x^14 for |x| <= 0.35, else exp(x) - 1)
+static __host__ __device__ __noinline__ double dexpm1(double x) {
+    if (!(__builtin_fabs(x) <= 0.35)) return dexp(x) - 1.0;
+    double p = 1.1470745597729725e-11;                                 // 1/14!
+    p = __builtin_fma(x, p, 1.6059043836821613e-10);    // 1/13!
+    p = __builtin_fma(x, p, 2.08767569878681e-09);    // 1/12!
+    p = __builtin_fma(x, p, 2.505210838544172e-08);    // 1/11!
+    p = __builtin_fma(x, p, 2.755731922398589e-07);    // 1/10!
+    p = __builtin_fma(x, p, 2.7557319223985893e-06);    // 1/9!
+    p = __builtin_fma(x, p, 2.48015873015873e-05);    // 1/8!
+    p = __builtin_fma(x, p, 0.0001984126984126984);    // 1/7!
+    p = __builtin_fma(x, p, 0.001388888888888889);    // 1/6!
+    p = __builtin_fma(x, p, 0.008333333333333333);    // 1/5!
+    p = __builtin_fma(x, p, 0.041666666666666664);    // 1/4!
+    p = __builtin_fma(x, p, 0.16666666666666666);    // 1/3!
+    p = __builtin_fma(x, p, 0.5);
+    return __builtin_fma(x * x, p, x);
+}
+
 // sin / cos of a step size (the ExactNormal trajectory kind; reference f64::sin / f64::cos, src/math/util.rs:580-581):
 // Cody-Waite reduction by pi/2 in two fma steps and the classic minimax kernels on [-pi/4, pi/4]; the same operation
 // sequence as oracle/nmo_math.hpp det_sincos (bit-identical), ~1 ulp from libm.

@@ -167,6 +167,13 @@ extern "C" void nm_settings_default(nm_settings* s) {
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;
     s->adaptation = NM_ADAPT_DIAG; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;
     s->trajectory_kind = NM_TRAJ_EUCLIDEAN;                                  // sampler.rs:528
+    // default_mclmc_settings (sampler.rs:342-366); inert while sampler == NM_SAMPLER_NUTS
+    s->sampler = NM_SAMPLER_NUTS; s->mclmc_step_size = 0.5; s->momentum_decoherence_length = 3.0; s->subsample_frequency = 1.0;
+    s->dynamic_step_size = 1; s->mclmc_trajectory_kind = NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL; s->trajectory_switch_fraction = 0.3;
+}
+extern "C" void nm_settings_default_mclmc(nm_settings* s) {        // DiagMclmcSettings::default (src/sampler.rs:368-374)
+    nm_settings_default(s);
+    s->sampler = NM_SAMPLER_MCLMC; s->step_size_method = NM_STEP_FIXED; s->fixed_step_size = s->mclmc_step_size;
 }
 extern "C" void nm_settings_default_low_rank(nm_settings* s) {     // LowRankNutsSettings::default (src/sampler.rs:636-642)
     nm_settings_default(s);
@@ -388,7 +395,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     nm_status st = check_logp(logp);
     if (st != NM_OK) return st;
     if (n_chains == 0) return fail(NM_ERR_INVALID_ARG, "n_chains must be > 0");
-    const nm_settings& s = *settings;
+    nm_settings s = *settings;
     if (s.maxdepth > (uint64_t)MAX_MAXDEPTH) return fail(NM_ERR_UNSUPPORTED, "maxdepth %llu > %d", (unsigned long long)s.maxdepth, MAX_MAXDEPTH);
     if (s.step_size_method > NM_STEP_FIXED) return fail(NM_ERR_INVALID_ARG, "step_size_method %llu is not one of NM_STEP_*", (unsigned long long)s.step_size_method);
     // GlobalStrategy::new asserts (adapt_strategy.rs:83-84)
@@ -403,9 +410,19 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (lr && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "NM_ADAPT_LOW_RANK with a density module: modules carry the diagonal kernels only");
     if (lr && !(s.lr_gamma > 0.0) ) return fail(NM_ERR_INVALID_ARG, "lr_gamma must be > 0");
     if (s.trajectory_kind > NM_TRAJ_MICROCANONICAL) return fail(NM_ERR_INVALID_ARG, "trajectory_kind %llu is not one of NM_TRAJ_*", (unsigned long long)s.trajectory_kind);
-    const bool kin = s.trajectory_kind != NM_TRAJ_EUCLIDEAN;
-    if (kin && lr) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds run with the diagonal adaptation (NM_ADAPT_DIAG) only");
-    if (kin && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds with a density module: modules carry the Euclidean kernels only");
+    if (s.sampler > NM_SAMPLER_MCLMC) return fail(NM_ERR_INVALID_ARG, "sampler %llu is not one of NM_SAMPLER_*", (unsigned long long)s.sampler);
+    const bool mclmc = s.sampler == NM_SAMPLER_MCLMC;
+    if (mclmc) {
+        if (s.mclmc_trajectory_kind > NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL) return fail(NM_ERR_INVALID_ARG, "mclmc_trajectory_kind %llu is not one of NM_MCLMC_*", (unsigned long long)s.mclmc_trajectory_kind);
+        if (!(s.mclmc_step_size > 0.0) || !(s.momentum_decoherence_length > 0.0)) return fail(NM_ERR_INVALID_ARG, "mclmc_step_size and momentum_decoherence_length must be > 0");
+        if (logp->dim < 2) return fail(NM_ERR_INVALID_ARG, "ESH dynamics requires at least 2 dimensions (reference src/math/cpu_math.rs:514)");
+        // DiagMclmcSettings::new_chain: adapt_options.step_size_settings.adapt_options.method = Fixed(self.step_size) (sampler.rs:421-423)
+        s.step_size_method = NM_STEP_FIXED; s.fixed_step_size = s.mclmc_step_size;
+        s.trajectory_kind = NM_TRAJ_EUCLIDEAN;      // (a NutsSettings field; MclmcChain's kind lives in the chain state)
+    }
+    const bool kin = mclmc || s.trajectory_kind != NM_TRAJ_EUCLIDEAN;
+    if (kin && lr) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds and NM_SAMPLER_MCLMC run with the diagonal adaptation (NM_ADAPT_DIAG) only");
+    if (kin && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds / NM_SAMPLER_MCLMC with a density module: modules carry the Euclidean NUTS kernels only");
     if (s.trajectory_kind == NM_TRAJ_MICROCANONICAL && logp->dim < 2) return fail(NM_ERR_INVALID_ARG, "ESH dynamics requires at least 2 dimensions (reference src/math/cpu_math.rs:514)");
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
@@ -531,6 +548,10 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nsslot = nsslot;
     P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.prof = e->d_prof; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
     P.early_end = early_end;
+    {   // MclmcChain's switch_draw = (trajectory_switch_fraction * num_tune) as u64 (sampler.rs:441; `as` saturates, NaN -> 0)
+        const double q = s.trajectory_switch_fraction * num_tune_f;
+        P.mclmc_switch_draw = q >= 18446744073709551616.0 ? ~0ull : (q > 0.0 ? (uint64_t)q : 0ull);
+    }
     P.final_step_size_window = s.num_tune >= step_size_window ? s.num_tune - step_size_window : 0;   // saturating_sub
     P.ln_max_step = dlog(s.da_max_step_size);
     if (s.has_jitter) {   // Uniform::new(1 - j, 1 + j)
@@ -1233,6 +1254,9 @@ __global__ void scalar_math_kernel(uint64_t op, uint64_t n, const double* a, con
     case 3: r = logaddexp_lane(x, y); break;
     case 4: r = __builtin_sqrt(x); break;
     case 5: r = x / y; break;
+    case 7: r = dexpm1(x); break;
+    case 8: r = dsincos(x).x; break;
+    case 9: r = dsincos(x).y; break;
     default: r = __builtin_nan("");
     }
     out[i] = r;
@@ -1372,7 +1396,7 @@ extern "C" nm_status nm_turning_batch(uint64_t n, uint64_t dim, uint64_t dims_pe
 extern "C" nm_status nm_scalar_math_batch(uint64_t op, uint64_t n, const double* d_a, const double* d_b, double* d_out, void* stream) {
     nm_status st = ensure_device(-1);
     if (st != NM_OK) return st;
-    if (op > 5) return fail(NM_ERR_INVALID_ARG, "unknown op");
+    if (op > 9 || op == 6) return fail(NM_ERR_INVALID_ARG, "unknown op");
     if (n == 0) return NM_OK;
     hipLaunchKernelGGL(scalar_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, n, d_a, d_b, d_out);
     HIP_TRY(hipGetLastError());

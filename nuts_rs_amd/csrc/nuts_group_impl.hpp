@@ -1033,6 +1033,7 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     out.chain_status = ast;
     out.transformation_update_id = -1;
     out.num_eigenvalues = 0;
+    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
     if (sc.mm_id != sc.stats_last_id) {                         // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70)
         out.transformation_update_id = sc.mm_id;
         g_write_row(C, P.out_mm_inv, row, C.sig);

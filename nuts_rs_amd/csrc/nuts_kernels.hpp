@@ -53,6 +53,7 @@ enum PSlot : int {
     P_SIG, P_ISIG, P_MU,               // DiagMassMatrix stds / inv_stds / mean (transform/diagonal.rs:9-17)
     E_DM, E_DV, E_GM, E_GV,            // foreground RunningVariance of draws / grads (adapt/diagonal.rs:108-115)
     B_DM, B_DV, B_GM, B_GV,            // background
+    P_V,                               // MclmcChain: the momentum survives from draw to draw (src/mclmc.rs:551)
     NUM_PSLOT
 };
 // main-tree edges: `left` and `right` are edge ids 0/1 (both start as the initial point's id 0; a successful doubling
@@ -108,6 +109,8 @@ struct ChainScalars {
     double lr_upd_logdet;              // its -1/2 sum ln lambda (InnerMatrix::new, low_rank.rs:57)
     uint64_t lr_is_late;               // is_late of the paused adapt call
     uint64_t lr_row;                   // output row of the paused draw
+    // KinWrap kernels: the Hamiltonian's current KineticEnergyKind (NutsSettings::trajectory_kind; MclmcChain switches it)
+    uint64_t kin;
 };
 enum { LR_IDLE = 0, LR_WAIT_HOST = 1, LR_ANSWERED = 2, LR_SET_TRANSFORM = 3 };
 
@@ -122,6 +125,7 @@ struct KParams {
     const double* logp_params;
     // derived schedule constants (GlobalStrategy::new, adapt_strategy.rs:77-98)
     uint64_t early_end, final_step_size_window;
+    uint64_t mclmc_switch_draw;        // MclmcChain::switch_draw (sampler.rs:441)
     double ln_max_step;                // ln(da_max_step_size), dual_avg.rs:59
     double jitter_low, jitter_scale;   // Uniform::new(1-j, 1+j) (stepsize/adapt.rs:259-261)
     // outputs of the draw kernel
@@ -838,7 +842,7 @@ NM_DEV double esh_update(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& g, Tile<DPL
 template <int DPL, int W, class Dens>
 NM_DEV bool bad_energy(const ChainCtx<DPL, W, Dens>& C, double energy_error, double max_energy_error) {
     if constexpr (kin_trait<Dens>::value) {
-        if (C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL)
+        if (C.sc.kin == NM_TRAJ_MICROCANONICAL)
             return (__builtin_fabs(energy_error) >= max_energy_error) | !is_finite(energy_error);
     }
     return (energy_error > max_energy_error) | !is_finite(energy_error);
@@ -848,7 +852,7 @@ NM_DEV bool bad_energy(const ChainCtx<DPL, W, Dens>& C, double energy_error, dou
 // transformation; `o.ke` of the microcanonical kind is the accumulated kinetic-energy change (s.ke + both half-steps).
 template <int DPL, int W, class Dens>
 NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
-    const bool micro = C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL;
+    const bool micro = C.sc.kin == NM_TRAJ_MICROCANONICAL;
     const double half = epsilon / 2.;
     const double sqrt_n = __builtin_sqrt((double)C.dim);
     Tile<DPL> x, gx;
@@ -909,7 +913,7 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
 template <int DPL, int W, class Dens>
 NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     if constexpr (kin_trait<Dens>::value) {
-        if (C.P.s.trajectory_kind != NM_TRAJ_EUCLIDEAN) { leapfrog_kin(C, s, o, epsilon, x_out, gx_out); return; }
+        if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { leapfrog_kin(C, s, o, epsilon, x_out, gx_out); return; }
     }
     const double half = epsilon / 2.;
     Tile<DPL> x, gx;
@@ -1068,7 +1072,7 @@ NM_DEV double kinetic(const Tile<DPL>& v, Reducer<W>& R) {
 template <int DPL, int W, class Dens>
 NM_DEV double initial_kinetic(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
     if constexpr (kin_trait<Dens>::value) {
-        if (C.P.s.trajectory_kind == NM_TRAJ_MICROCANONICAL) {
+        if (C.sc.kin == NM_TRAJ_MICROCANONICAL) {
             normalize_tile(v, C.red);
             C.storeS(v, STAGE_V);
             return 0.0;
@@ -2009,10 +2013,228 @@ NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx
     write_row(C, P.out_div_end, row, x);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MclmcChain::draw (reference src/mclmc.rs:488-556) with mclmc_kernel (:212-409): KinWrap kernels, nm_settings.sampler =
+// NM_SAMPLER_MCLMC.  The chain's point is (P_X, P_GX, P_Z, P_GZ, P_V); the momentum noise of the partial refresh stays in the
+// LDS staging area of the normal sampler (C.l1z: no tree uses it here) from its draw to its two uses.
+// ---------------------------------------------------------------------------------------------
+template <int DPL, int W, class Dens>
+NM_DEV void mclmc_sample_noise(ChainCtx<DPL, W, Dens>& C) {           // array_gaussian(noise, ones) (mclmc.rs:250, :304, :313)
+    block_sync(W == 1);
+    if (DPL == 2 && C.dim <= 48) fill_standard_normals(C.rng, C.l1z, C.dim, C.zig);
+    else fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, C.dim, C.zig, 64 * W, C.P.prof, C.prof_t);
+    block_sync(W == 1);
+}
+// partial_momentum_refresh (transformed_hamiltonian.rs:770-825)
+template <int DPL, int W, class Dens>
+NM_DEV void mclmc_partial_refresh(ChainCtx<DPL, W, Dens>& C, Pt<DPL>& p, double factor) {
+    const double half_step = C.sc.step_size * factor / 2.0;
+    const double L = C.P.s.momentum_decoherence_length;
+    Tile<DPL> nz;
+    const double2* s2 = C.tptr(C.l1z);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) {
+        const double2 q = s2[m * 64 * W];
+        nz.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+        nz.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+    }
+    if (C.sc.kin == NM_TRAJ_MICROCANONICAL) {       // isokinetic Langevin on the unit sphere
+        const double nu = __builtin_sqrt(uniform_f64(dexpm1(2.0 * half_step / L)) / (double)C.dim);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) p.v.a[k] = __builtin_fma(nu, nz.a[k], p.v.a[k]);
+        normalize_tile(p.v, C.red);
+    } else {                                        // Ornstein-Uhlenbeck: alpha p + sqrt(1 - alpha^2) z
+        const double alpha = uexp(-half_step / L);
+        const double beta = __builtin_sqrt(1.0 - alpha * alpha);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const double nv = __builtin_fma(alpha, p.v.a[k], 0.0);
+            p.v.a[k] = __builtin_fma(beta, nz.a[k], nv);
+        }
+        p.ke = kinetic(p.v, C.red);
+    }
+}
+
+template <int DPL, int W, class Dens>
+NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
+    const KParams& P = C.P;
+    const nm_settings& s = P.s;
+    ChainScalars& sc = C.sc;
+    nm_draw_stats out;
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    // ---- Euclidean -> Microcanonical switch (mclmc.rs:490-504)
+    bool resample_velocity = false;
+    if (s.mclmc_trajectory_kind == NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL && sc.draw_count == P.mclmc_switch_draw &&
+        sc.kin != NM_TRAJ_MICROCANONICAL) {
+        sc.kin = NM_TRAJ_MICROCANONICAL;
+        resample_velocity = true;
+    }
+    const double base_step_size = sc.step_size;
+    uint64_t num_base_steps;
+    {   // (subsample_frequency * L / eps).round().max(1.0).min(1e6) as u64 (mclmc.rs:219-232): round half away from zero
+        const double q = s.subsample_frequency * s.momentum_decoherence_length / base_step_size;
+        double r = __builtin_round(q);
+        r = r != r ? 1.0 : (r > 1.0 ? r : 1.0);
+        r = r < 1e6 ? r : 1e6;
+        num_base_steps = (uint64_t)r;
+    }
+    const int max_halvings = s.dynamic_step_size ? 10 : 0;
+    // ---- current = copy(state); initialize_trajectory(current, resample_velocity) (transformed_hamiltonian.rs:687-736)
+    Pt<DPL> cur, nxt;
+    Tile<DPL> x, gx;
+    C.loadP(x, P_X); C.loadP(gx, P_GX);
+    if (resample_velocity) sample_velocity(C, cur.v); else C.loadP(cur.v, P_V);
+    if (sc.mm_id != sc.transform_id) {                              // inv_transform_normalize (diagonal.rs:210-221)
+        Tile<DPL> isig, sig, mu;
+        C.loadP(isig, P_ISIG); C.load(sig, C.lsig); C.load(mu, C.lmu);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
+            cur.z.a[k] = isig.a[k] * t;
+            cur.g.a[k] = gx.a[k] * sig.a[k];
+        }
+        C.storeP(cur.z, P_Z); C.storeP(cur.g, P_GZ);
+        sc.logdet = sc.mm_logdet;
+        sc.transform_id = sc.mm_id;
+    } else {
+        C.loadP(cur.z, P_Z); C.loadP(cur.g, P_GZ);
+    }
+    const double logdet = sc.logdet;
+    cur.ke = resample_velocity ? initial_kinetic(C, cur.v) : (sc.kin == NM_TRAJ_MICROCANONICAL ? 0.0 : kinetic(cur.v, C.red));
+    cur.logp = sc.logp; cur.idx = 0;
+    const double initial_energy = cur.ke - (cur.logp + logdet);
+    mclmc_sample_noise(C);
+    const double draw_start_energy = initial_energy;
+    AcceptCollector col;
+    col.register_init(0.0);                         // adapt.new_collector(): never register_init'ed, the base energy is 0 (dual_avg.rs:119-127)
+    bool diverged = false, div_has_energy = false, div_has_end = false;
+    double div_energy_error = 0.0;
+    uint64_t steps_taken = 0, remaining = num_base_steps, stack0 = 0;
+    uint32_t stack_bits = 0;                        // remaining_stack: the entries above the first are 1 or 2
+    int stack_len = 0;
+    double factor = 1.0, time = 0.0;
+    uint64_t fatal = NM_CHAIN_OK;
+    Tile<DPL> xn, gxn;
+    const int tmp_slot = slot_F(0);                 // tmp_velocity (mclmc.rs:272-274): a scratch slot no tree uses here
+    while (remaining > 0) {
+        C.storeS(cur.v, tmp_slot);
+        mclmc_partial_refresh(C, cur, factor);
+        const double step_baseline = cur.ke - (cur.logp + logdet);
+        leapfrog(C, cur, nxt, base_step_size * factor, &xn, &gxn);
+        nxt.idx = cur.idx + 1;
+        const double energy = nxt.ke - (nxt.logp + logdet);
+        const double err = energy - step_baseline;
+        const int dst = dens_status(C);
+        bool div_now = false;
+        if (dst == 2) { fatal = NM_CHAIN_LOGP_FATAL; break; }
+        if (dst == 1) { col.register_divergent(); div_now = true; div_has_energy = false; div_has_end = false; }
+        else if (bad_energy(C, err, s.max_energy_error * factor / (double)num_base_steps)) {
+            col.register_divergent(); div_now = true; div_has_energy = true; div_has_end = true; div_energy_error = err;
+        } else col.register_ok(energy);
+        if (!div_now) {
+            mclmc_sample_noise(C);
+            mclmc_partial_refresh(C, nxt, factor);
+            mclmc_sample_noise(C);
+            cur = nxt; x = xn; gx = gxn;
+            steps_taken += 1;
+            remaining -= 1;
+            time += factor * base_step_size;
+            while (remaining == 0) {
+                if (stack_len == 0) break;
+                stack_len -= 1;
+                remaining = (stack_len == 0 ? stack0 : (((stack_bits >> stack_len) & 1u) ? 2ull : 1ull)) - 1;
+                factor *= 2.0;
+            }
+        } else {
+            if (stack_len >= max_halvings) { diverged = true; break; }
+            factor *= 0.5;
+            if (stack_len == 0) stack0 = remaining;
+            else stack_bits = (stack_bits & ~(1u << stack_len)) | ((remaining == 2 ? 1u : 0u) << stack_len);
+            stack_len += 1;
+            remaining = 2;
+            C.loadR(cur.v, C.rs, tmp_slot);
+        }
+    }
+    if (fatal != NM_CHAIN_OK) {
+        sc.status = fatal;
+        if (P.out_stats && tid() == 0) {
+            nm_draw_stats zz = {};
+            zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = fatal;
+            P.out_stats[t_out * P.n_chains + chain] = zz;
+        }
+        return;
+    }
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    // DrawGradCollector::register_draw(current) (adapt/diagonal.rs:73-83)
+    const bool is_good = diverged ? (cur.idx > 4) : (cur.idx != 0);
+    const double cur_energy = cur.ke - (cur.logp + logdet);
+    double energy_change, state_energy, state_energy_error, state_logp;
+    int64_t state_idx;
+    Tile<DPL> sx, sgx, sz, sgz;                     // the state the draw returns
+    if (diverged) {                                 // stay at the pre-trajectory position with a fresh momentum (mclmc.rs:361-388)
+        if (P.out_div_start) write_row(C, P.out_div_start, row, x);
+        if (P.out_div_start_grad) write_row(C, P.out_div_start_grad, row, gx);
+        if (P.out_div_end && div_has_end) write_row(C, P.out_div_end, row, xn);
+        Tile<DPL> v;
+        sample_velocity(C, v);
+        const double ke_new = initial_kinetic(C, v);
+        C.storeP(v, P_V);
+        C.loadP(sx, P_X); C.loadP(sgx, P_GX); C.loadP(sz, P_Z); C.loadP(sgz, P_GZ);
+        energy_change = cur_energy - draw_start_energy;
+        state_logp = sc.logp;
+        state_energy = ke_new - (state_logp + logdet);
+        state_energy_error = state_energy - state_energy;       // energy() - initial_energy of a freshly initialised point
+        state_idx = 0;
+    } else {
+        C.storeP(x, P_X); C.storeP(gx, P_GX); C.storeP(cur.z, P_Z); C.storeP(cur.g, P_GZ); C.storeP(cur.v, P_V);
+        sc.logp = cur.logp;
+        sx = x; sgx = gx; sz = cur.z; sgz = cur.g;
+        energy_change = cur_energy - initial_energy;             // current.energy_error()
+        state_logp = cur.logp; state_energy = cur_energy; state_energy_error = energy_change; state_idx = cur.idx;
+    }
+    sc.px_stale = 0;
+    write_row(C, P.out_positions, row, sx);
+    write_row(C, P.out_gradient, row, sgx);
+    write_row(C, P.out_tpos, row, sz);
+    write_row(C, P.out_tgrad, row, sgz);
+    double fd = 0.0;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) fd = fd + (sz.a[k] + sgz.a[k]) * (sz.a[k] + sgz.a[k]);
+    fd = C.red.sum(fd);
+    const int64_t trans_id = sc.transform_id;
+    sc.total_steps += col.count;
+    uint64_t ast = adapt(C, col, is_good, x, gx);    // the collector saw `current`; Fixed step size: the state's position is not used
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    out.depth = steps_taken; out.maxdepth_reached = 0; out.diverging = diverged;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.index_in_trajectory = state_idx; out.transformation_index = trans_id;
+    out.step_size = sc.step_size; out.step_size_bar = s.fixed_step_size;
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.logp = state_logp; out.energy = state_energy; out.energy_error = state_energy_error;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (diverged && div_has_energy) ? div_energy_error : __builtin_nan("");
+    out.chain_status = ast;
+    out.transformation_update_id = -1;
+    out.num_eigenvalues = 0;
+    out.energy_change = energy_change; out.average_step_size = time / (double)steps_taken;
+    if (sc.mm_id != sc.stats_last_id) {
+        out.transformation_update_id = sc.mm_id;
+        if (P.out_mm_inv) { C.load(sx, C.lsig); write_row(C, P.out_mm_inv, row, sx); }
+        if (P.out_mm_mu) { C.load(sx, C.lmu); write_row(C, P.out_mm_mu, row, sx); }
+    }
+    sc.stats_last_id = sc.mm_id;
+    if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
 template <int DPL, int W, class Dens>
 NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
+    if constexpr (kin_trait<Dens>::value) {
+        if (P.s.sampler == NM_SAMPLER_MCLMC) { chain_draw_mclmc(C, chain, t_out); return; }
+    }
     AcceptCollector col;
     DrawResult R;
     Tile<DPL> x, gx, z, gz;
@@ -2091,6 +2313,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70): an event when the version moved since the last draw
     out.transformation_update_id = -1;
     out.num_eigenvalues = 0;
+    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
     if (sc.mm_id != sc.stats_last_id) {
         out.transformation_update_id = sc.mm_id;
         if (P.out_mm_inv) { C.load(x, C.lsig); write_row(C, P.out_mm_inv, row, x); }
@@ -2122,6 +2345,7 @@ NM_DEV void finish_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain, nm_draw_st
     out.chain_status = ast;
     out.transformation_update_id = -1;                            // LowRankMassMatrix::extract_stats (low_rank.rs:218-262)
     out.num_eigenvalues = 0;
+    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
     if (sc.mm_id != sc.stats_last_id) {
         out.transformation_update_id = sc.mm_id;
         out.num_eigenvalues = sc.lr_has_inner ? sc.lr_rank : 0;
@@ -2291,7 +2515,13 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         ChainScalars& sc = C.sc;
         // stepsize::Strategy::new (stepsize/adapt.rs:67-72) belongs to the chain's construction: only the first
         // set_position of a chain does it (mm_id is still -1); a retry after BadInitGrad keeps the adaptation state
-        if (sc.mm_id < 0) stepsize_adapt_reset(sc, P.s, P.s.initial_step);
+        if (sc.mm_id < 0) {
+            stepsize_adapt_reset(sc, P.s, P.s.initial_step);
+            // TransformedHamiltonian::new(.., kind): NutsSettings::trajectory_kind, or MclmcChain's initial_kind (sampler.rs:433-438)
+            sc.kin = P.s.sampler == NM_SAMPLER_MCLMC
+                   ? (P.s.mclmc_trajectory_kind == NM_MCLMC_MICROCANONICAL ? NM_TRAJ_MICROCANONICAL : NM_TRAJ_EUCLIDEAN)
+                   : P.s.trajectory_kind;
+        }
         Tile<DPL> x, gx;
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
@@ -2333,6 +2563,13 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
                 C.storeP(x, P_X); C.storeP(g2, P_GX);
                 C.storeP(st.z, P_Z); C.storeP(st.g, P_GZ);
                 sc.logp = st.logp; sc.logdet = sc.mm_logdet; sc.transform_id = sc.mm_id;
+                if constexpr (kin_trait<Dens>::value) {
+                    if (P.s.sampler == NM_SAMPLER_MCLMC) {            // MclmcChain::set_position: initialize_trajectory(resample) (mclmc.rs:482-485)
+                        sample_velocity(C, st.v);
+                        (void)initial_kinetic(C, st.v);
+                        C.storeP(st.v, P_V);
+                    }
+                }
             }
         }
         sc.status = status;

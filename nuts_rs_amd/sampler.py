@@ -22,6 +22,7 @@ from ._lib import (NmDrawOutputs, NmEngineConfig, NmLogpSpec, NmSettings, NutsAm
 LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE, LOGP_HOST_CALLBACK = 0, 1, 2, 3, 4, 5, 6
 STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED = 0, 1, 2
 ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
+SAMPLER_NUTS, SAMPLER_MCLMC = 0, 1
 
 
 @dataclass
@@ -134,6 +135,49 @@ class DiagNutsSettings:            # src/sampler.rs:199-239; Default: :630-634
         s.da_max_step_size = st.dual_average.max_step_size
         s.adam_beta1, s.adam_beta2 = st.adam.beta1, st.adam.beta2
         s.adam_epsilon, s.adam_learning_rate = st.adam.epsilon, st.adam.learning_rate
+        return s
+
+
+class MclmcTrajectoryKind:         # src/mclmc.rs:44-70
+    MICROCANONICAL, EUCLIDEAN, EUCLIDEAN_EARLY_THEN_MICROCANONICAL = 0, 1, 2
+
+
+def _fixed_step_adapt_options():
+    a = EuclideanAdaptOptions()
+    a.step_size_settings.method, a.step_size_settings.fixed_step_size = STEP_FIXED, 0.5   # sampler.rs:371
+    return a
+
+
+@dataclass
+class DiagMclmcSettings:           # MclmcSettings<EuclideanAdaptOptions<DiagAdaptExpSettings>> (src/sampler.rs:266-374; experimental upstream)
+    step_size: float = 0.5
+    momentum_decoherence_length: float = 3.0
+    num_tune: int = 400
+    num_draws: int = 1000
+    num_chains: int = 6
+    seed: int = 0
+    max_energy_error: float = 1000.0
+    store_unconstrained: bool = False
+    store_gradient: bool = False
+    store_transformed: bool = False
+    store_divergences: bool = False
+    adapt_options: EuclideanAdaptOptions = field(default_factory=_fixed_step_adapt_options)
+    subsample_frequency: float = 1.0
+    dynamic_step_size: bool = True
+    trajectory_kind: int = MclmcTrajectoryKind.EUCLIDEAN_EARLY_THEN_MICROCANONICAL
+    trajectory_switch_fraction: float = 0.3
+
+    def to_c(self) -> NmSettings:
+        n = DiagNutsSettings(num_tune=self.num_tune, num_draws=self.num_draws, num_chains=self.num_chains, seed=self.seed,
+                             max_energy_error=self.max_energy_error, store_unconstrained=self.store_unconstrained,
+                             store_gradient=self.store_gradient, store_transformed=self.store_transformed,
+                             store_divergences=self.store_divergences, adapt_options=self.adapt_options)
+        s = n.to_c()
+        s.sampler = SAMPLER_MCLMC
+        s.mclmc_step_size, s.momentum_decoherence_length = self.step_size, self.momentum_decoherence_length
+        s.subsample_frequency, s.dynamic_step_size = self.subsample_frequency, int(self.dynamic_step_size)
+        s.mclmc_trajectory_kind, s.trajectory_switch_fraction = int(self.trajectory_kind), self.trajectory_switch_fraction
+        s.step_size_method, s.fixed_step_size = STEP_FIXED, self.step_size          # new_chain: Fixed(self.step_size) (sampler.rs:421-423)
         return s
 
 

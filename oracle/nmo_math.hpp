@@ -121,6 +121,26 @@ static inline double det_log1p(double x) {
     return det_log_core(u, x - (u - 1.0));
 }
 
+// exp(x) - 1 (reference: f64::exp_m1 in the isokinetic momentum refresh, src/dynamics/transformed_hamiltonian.rs:800-801).
+// |x| <= 0.35: the Taylor series to x^14 in Horner form (one fma per term); beyond: det_exp(x) - 1.  ~1-2 ulp.
+static inline double det_expm1(double x) {
+    if (!(std::fabs(x) <= 0.35)) return det_exp(x) - 1.0;
+    double p = 1.1470745597729725e-11;                                 // 1/14!
+    p = std::fma(x, p, 1.6059043836821613e-10);    // 1/13!
+    p = std::fma(x, p, 2.08767569878681e-09);    // 1/12!
+    p = std::fma(x, p, 2.505210838544172e-08);    // 1/11!
+    p = std::fma(x, p, 2.755731922398589e-07);    // 1/10!
+    p = std::fma(x, p, 2.7557319223985893e-06);    // 1/9!
+    p = std::fma(x, p, 2.48015873015873e-05);    // 1/8!
+    p = std::fma(x, p, 0.0001984126984126984);    // 1/7!
+    p = std::fma(x, p, 0.001388888888888889);    // 1/6!
+    p = std::fma(x, p, 0.008333333333333333);    // 1/5!
+    p = std::fma(x, p, 0.041666666666666664);    // 1/4!
+    p = std::fma(x, p, 0.16666666666666666);    // 1/3!
+    p = std::fma(x, p, 0.5);
+    return std::fma(x * x, p, x);
+}
+
 // sin and cos of x (reference: f64::sin / f64::cos of the step size, src/math/util.rs:580-581).  Cody-Waite reduction by
 // pi/2 in two fma steps, then the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]; every step is one
 // binary64 operation, the engine runs the same sequence.  Odd / even symmetry is exact, like libm's.  Accuracy ~1 ulp for
@@ -162,6 +182,7 @@ struct Ctx {
     // count.powf(-k) of dual averaging (reference src/stepsize/dual_avg.rs:60)
     double powf(double a, double b) const { return cfg.detmath ? det_exp(b * det_log(a)) : std::pow(a, b); }
 
+    double exp_m1(double x) const { return cfg.detmath ? det_expm1(x) : std::expm1(x); }
     double sin(double x) const { if (!cfg.detmath) return std::sin(x); double s_, c_; det_sincos(x, &s_, &c_); return s_; }
     double cos(double x) const { if (!cfg.detmath) return std::cos(x); double s_, c_; det_sincos(x, &s_, &c_); return c_; }
 

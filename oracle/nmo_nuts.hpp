@@ -47,8 +47,15 @@ struct Settings {
     double lr_gamma, lr_eigval_cutoff;          // LowRankSettings (src/transform/low_rank.rs:188-203)
     uint64_t freeze_transform;                  // engine knob (not a reference setting): the transformation is given, never adapted
     uint64_t trajectory_kind;                   // KineticEnergyKind (src/dynamics/transformed_hamiltonian.rs:27-50, NutsSettings::trajectory_kind)
+    // MclmcSettings (src/sampler.rs:266-317): sampler = 1 runs MclmcChain (src/mclmc.rs) instead of the NUTS tree
+    uint64_t sampler;
+    double mclmc_step_size, momentum_decoherence_length, subsample_frequency;
+    uint64_t dynamic_step_size, mclmc_trajectory_kind;
+    double trajectory_switch_fraction;
 };
 enum { TRAJ_EUCLIDEAN = 0, TRAJ_EXACT_NORMAL = 1, TRAJ_MICROCANONICAL = 2 };
+enum { SAMPLER_NUTS = 0, SAMPLER_MCLMC = 1 };
+enum { MCLMC_MICROCANONICAL = 0, MCLMC_EUCLIDEAN = 1, MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL = 2 };   // MclmcTrajectoryKind (src/mclmc.rs:44-70)
 
 struct DrawStats {   // same field order as nm_draw_stats
     uint64_t draw, chain, depth, maxdepth_reached, diverging, tuning, n_steps;
@@ -58,6 +65,7 @@ struct DrawStats {   // same field order as nm_draw_stats
     uint64_t chain_status;
     int64_t transformation_update_id;   // DiagMassMatrixStats.transformation_update_id, -1 = None
     uint64_t num_eigenvalues;           // MatrixStats.num_eigenvalues (low_rank.rs:205-216) on update draws, else 0
+    double energy_change, average_step_size;   // MclmcStats (src/mclmc.rs:91-124); NaN for NUTS draws
 };
 
 // Optional vector-valued statistics of one draw (rows of length dim; nullptr = not wanted).  The reference's
@@ -412,6 +420,7 @@ struct Hamiltonian {
     double step_size = 0;
     size_t n;
     int64_t kind = TRAJ_EUCLIDEAN;
+    double decoherence_length = INFINITY;       // momentum_decoherence_length: Some(L) for MCLMC (:441-443)
     Hamiltonian(const Ctx* m_, const Density* d) : m(m_), dens(d), mm(d->dim), n(d->dim) {}
 
     // leapfrog :524-615.  `acc` may be null (no collector).
@@ -522,9 +531,11 @@ struct Hamiltonian {
     }
 
     // initialize_trajectory :687-736 (resample_velocity = true)
-    void initialize_trajectory(Point& p, ChaCha8Rng& rng) {
-        for (size_t i = 0; i < n; ++i) p.v[i] = 1.0 * standard_normal(rng, *m);  // array_gaussian cpu_math.rs:561-577
-        if (kind == TRAJ_MICROCANONICAL) m->array_normalize(p.v.data(), n);      // the momentum lives on the unit sphere :700-703
+    void initialize_trajectory(Point& p, ChaCha8Rng& rng, bool resample_velocity = true) {
+        if (resample_velocity) {
+            for (size_t i = 0; i < n; ++i) p.v[i] = 1.0 * standard_normal(rng, *m);  // array_gaussian cpu_math.rs:561-577
+            if (kind == TRAJ_MICROCANONICAL) m->array_normalize(p.v.data(), n);  // the momentum lives on the unit sphere :700-703
+        }
         if (mm.id != p.transform_id) {                                           // inv_transform_normalize diagonal.rs:210-221
             mm.compute_transformed_position(*m, p.x, p.z);
             mm.compute_transformed_gradient(*m, p.gx, p.gz);
@@ -535,6 +546,25 @@ struct Hamiltonian {
         else p.kinetic_energy = 0.5 * m->vector_dot(p.v.data(), p.v.data(), n);
         p.index_in_trajectory = 0;
         p.initial_energy = p.energy();
+    }
+
+    // partial_momentum_refresh :770-825 (MCLMC only: momentum_decoherence_length is Some(L))
+    void partial_momentum_refresh(Point& p, const Vec& noise, double factor) {
+        const double half_step = step_size * factor / 2.0;
+        if (kind == TRAJ_MICROCANONICAL) {       // isokinetic Langevin: p <- (p + nu z) / |p + nu z|
+            const double nn = (double)n;
+            const double nu = std::sqrt(m->exp_m1(2.0 * half_step / decoherence_length) / nn);
+            axpy(noise.data(), p.v.data(), nu, n);
+            m->array_normalize(p.v.data(), n);
+        } else {                                 // Ornstein-Uhlenbeck: p <- alpha p + sqrt(1 - alpha^2) z
+            const double alpha = m->exp(-half_step / decoherence_length);
+            const double beta = std::sqrt(1.0 - alpha * alpha);
+            Vec zeros(n, 0.0), nv(n);
+            axpy_out(p.v.data(), zeros.data(), alpha, nv.data(), n);
+            axpy(noise.data(), nv.data(), beta, n);
+            p.v = nv;
+            p.kinetic_energy = 0.5 * m->vector_dot(p.v.data(), p.v.data(), n);
+        }
     }
 };
 
@@ -742,6 +772,7 @@ struct Chain {
     NutsOptions options;
     State state;
     SampleInfo last_info;
+    uint64_t mclmc_switch_draw = 0;
     uint64_t draw_count = 0;
     // GlobalStrategy (adapt_strategy.rs:24-39)
     uint64_t num_tune, early_end, final_step_size_window, last_update = 0, current_window_size;
@@ -765,6 +796,12 @@ struct Chain {
         : m{cfg}, dens(d), s(s_), chain_id(chain), rng(ChaCha8Rng::from_seed(key)), h(&m, &dens), coll(d.dim),
           var_draw(d.dim), var_grad(d.dim), var_draw_bg(d.dim), var_grad_bg(d.dim), n(d.dim) {
         h.m = &m; h.dens = &dens; h.kind = (int64_t)s.trajectory_kind;
+        if (s.sampler == SAMPLER_MCLMC) {                                       // DiagMclmcSettings::new_chain sampler.rs:405-457
+            h.kind = s.mclmc_trajectory_kind == MCLMC_MICROCANONICAL ? TRAJ_MICROCANONICAL : TRAJ_EUCLIDEAN;
+            h.decoherence_length = s.momentum_decoherence_length;
+            mclmc_switch_draw = (uint64_t)(s.trajectory_switch_fraction * (double)s.num_tune);
+            s.step_size_method = 2; s.fixed_step_size = s.mclmc_step_size;      // StepSizeAdaptMethod::Fixed(self.step_size)
+        }
         options = {s.maxdepth, s.mindepth, s.check_turning != 0, s.extra_doublings, s.max_energy_error,
                    s.has_target_integration_time != 0, s.target_integration_time};
         // GlobalStrategy::new adapt_strategy.rs:77-98
@@ -878,6 +915,7 @@ struct Chain {
         rc = stepsize_init(position);
         if (rc != ST_OK) return rc;
         rc = h.init_state(position, &state);
+        if (rc == ST_OK && s.sampler == SAMPLER_MCLMC) h.initialize_trajectory(*state, rng, true);   // MclmcChain::set_position mclmc.rs:472-486
         return rc;
     }
 
@@ -954,6 +992,7 @@ struct Chain {
 
     // NutsChain::draw chain.rs:151-188 (+ the stats of expanded_draw :190-232)
     int draw(double* out_position, DrawStats* stats, const DrawVectors* vec = nullptr) {
+        if (s.sampler == SAMPLER_MCLMC) return mclmc_draw(out_position, stats, vec);
         State chosen;
         SampleInfo info;
         int rc = nuts_draw(m, state, rng, h, options, coll, &chosen, &info);
@@ -978,6 +1017,7 @@ struct Chain {
             // extraction (chain.rs:195-200; starts at -1, sampler.rs:795)
             o.transformation_update_id = h.mm.id != stats_last_id ? h.mm.id : -1;
             o.num_eigenvalues = (h.mm.id != stats_last_id && h.mm.has_inner) ? h.mm.rank : 0;   // MatrixStats low_rank.rs:222-229
+            o.energy_change = NAN; o.average_step_size = NAN;
         }
         if (vec) {
             auto put = [&](double* dst, const Vec& v) { if (dst) for (size_t i = 0; i < n; ++i) dst[i] = v[i]; };
@@ -999,6 +1039,114 @@ struct Chain {
         draw_count += 1;
         state = chosen;
         last_info = info;
+        return arc;
+    }
+
+    // MclmcChain::draw + mclmc_kernel (reference src/mclmc.rs:212-409, :488-556): `num_steps` ESH / Euclidean leapfrogs with a
+    // partial momentum refresh on both sides of each, halving the step size factor on a divergence (dynamic_step_size)
+    int mclmc_draw(double* out_position, DrawStats* stats, const DrawVectors* vec) {
+        bool resample_velocity = false;                                          // Euclidean -> Microcanonical switch :490-504
+        if (s.mclmc_trajectory_kind == MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL && draw_count == mclmc_switch_draw &&
+            h.kind != TRAJ_MICROCANONICAL) {
+            h.kind = TRAJ_MICROCANONICAL;
+            resample_velocity = true;
+        }
+        const double base_step_size = h.step_size;
+        double ns = std::round(s.subsample_frequency * h.decoherence_length / base_step_size);   // f64::round: half away from zero
+        ns = ns != ns ? 1.0 : std::fmax(ns, 1.0);                                // f64::max ignores a NaN
+        ns = std::fmin(ns, 1e6);
+        const uint64_t num_base_steps = (uint64_t)ns;
+        const uint64_t max_halvings = s.dynamic_step_size ? 10 : 0;
+        State current = std::make_shared<Point>(*state);
+        h.initialize_trajectory(*current, rng, resample_velocity);
+        Vec noise(n);
+        auto gaussian = [&]() { for (size_t i = 0; i < n; ++i) noise[i] = 1.0 * standard_normal(rng, m); };
+        gaussian();
+        const double draw_start_energy = current->energy();
+        coll.acc = AcceptanceRateCollector();                                    // adapt.new_collector: never register_init'ed (base energy 0)
+        bool diverged = false;
+        DivergenceInfo div;
+        uint64_t steps_taken = 0;
+        double factor = 1.0;
+        std::vector<uint64_t> remaining_stack;
+        uint64_t remaining = num_base_steps;
+        double time = 0.0;
+        while (remaining > 0) {
+            Vec tmp_velocity = current->v;
+            h.partial_momentum_refresh(*current, noise, factor);
+            const double step_baseline = current->energy();
+            LeapfrogResult r = h.leapfrog(current, +1, factor, step_baseline,
+                                          s.max_energy_error * factor / (double)num_base_steps, &coll.acc);
+            if (r.kind == LF_OK) {
+                gaussian();
+                h.partial_momentum_refresh(*r.state, noise, factor);
+                gaussian();
+                current = r.state;
+                steps_taken += 1;
+                remaining -= 1;
+                time += factor * base_step_size;
+                while (remaining == 0) {
+                    if (remaining_stack.empty()) break;
+                    remaining = remaining_stack.back() - 1;
+                    remaining_stack.pop_back();
+                    factor *= 2.0;
+                }
+            } else if (r.kind == LF_DIVERGENCE) {
+                if (remaining_stack.size() >= max_halvings) { diverged = true; div = r.info; break; }
+                factor *= 0.5;
+                remaining_stack.push_back(remaining);
+                remaining = 2;
+                current->v = tmp_velocity;
+            } else {
+                if (stats) stats->chain_status = ST_LOGP_FATAL;
+                return ST_LOGP_FATAL;
+            }
+        }
+        State next;
+        double energy_change;
+        if (diverged) {      // stay at the pre-trajectory position with a fresh momentum :361-388
+            next = std::make_shared<Point>(*state);
+            h.initialize_trajectory(*next, rng, true);
+            energy_change = current->energy() - draw_start_energy;
+        } else {
+            next = current;
+            energy_change = current->energy_error();
+        }
+        coll.dg.register_draw(*current, diverged);
+        const double average_step_size = time / (double)steps_taken;
+        if (out_position) for (size_t i = 0; i < n; ++i) out_position[i] = next->x[i];
+        int arc = adapt(draw_count, next);
+        if (stats) {
+            DrawStats& o = *stats;
+            o.draw = draw_count; o.chain = chain_id; o.depth = steps_taken; o.maxdepth_reached = 0;
+            o.diverging = diverged; o.tuning = tuning; o.n_steps = last_n_steps;
+            o.index_in_trajectory = next->index_in_trajectory; o.transformation_index = next->transform_id;
+            o.step_size = h.step_size; o.step_size_bar = s.fixed_step_size;
+            o.mean_tree_accept = last_mean_tree_accept; o.mean_tree_accept_sym = last_sym_mean_tree_accept;
+            o.max_energy_error = last_max_energy_error;
+            o.logp = next->logp; o.energy = next->energy(); o.energy_error = next->energy_error();
+            o.fisher_distance = m.sq_norm_sum(next->z.data(), next->gz.data(), n);
+            o.divergence_energy_error = (diverged && div.has_energy_error) ? div.energy_error : NAN;
+            o.chain_status = arc;
+            o.transformation_update_id = h.mm.id != stats_last_id ? h.mm.id : -1;
+            o.num_eigenvalues = 0;
+            o.energy_change = energy_change; o.average_step_size = average_step_size;
+        }
+        if (vec) {
+            auto put = [&](double* dst, const Vec& v) { if (dst) for (size_t i = 0; i < n; ++i) dst[i] = v[i]; };
+            put(vec->gradient, next->gx);
+            put(vec->transformed_position, next->z);
+            put(vec->transformed_gradient, next->gz);
+            if (h.mm.id != stats_last_id) { put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean); }
+            if (diverged) {
+                put(vec->divergence_start, div.start_location);
+                put(vec->divergence_start_gradient, div.start_gradient);
+                if (div.has_end) put(vec->divergence_end, div.end_location);
+            }
+        }
+        stats_last_id = h.mm.id;
+        draw_count += 1;
+        state = next;
         return arc;
     }
 };

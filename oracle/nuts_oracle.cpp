@@ -28,6 +28,14 @@ void nmo_settings_default(Settings* s) {
     s->adam_beta1 = 0.9; s->adam_beta2 = 0.999; s->adam_epsilon = 1e-8; s->adam_learning_rate = 0.05;   // adam.rs:25-33
     s->adaptation = 0; s->lr_gamma = 1e-5; s->lr_eigval_cutoff = 2.0; s->freeze_transform = 0;          // low_rank.rs:195-203
     s->trajectory_kind = TRAJ_EUCLIDEAN;                                                                  // sampler.rs:528
+    // default_mclmc_settings (sampler.rs:342-366), inert while sampler == SAMPLER_NUTS
+    s->sampler = SAMPLER_NUTS; s->mclmc_step_size = 0.5; s->momentum_decoherence_length = 3.0; s->subsample_frequency = 1.0;
+    s->dynamic_step_size = 1; s->mclmc_trajectory_kind = MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL; s->trajectory_switch_fraction = 0.3;
+}
+// DiagMclmcSettings::default() (reference src/sampler.rs:368-374): num_tune 400, 6 chains, max_energy_error 1000, Fixed(0.5)
+void nmo_settings_default_mclmc(Settings* s) {
+    nmo_settings_default(s);
+    s->sampler = SAMPLER_MCLMC; s->step_size_method = 2; s->fixed_step_size = 0.5;
 }
 // LowRankNutsSettings::default() (reference src/sampler.rs:636-642): num_tune 800, mass_matrix_update_freq 20
 void nmo_settings_default_low_rank(Settings* s) {
@@ -292,6 +300,9 @@ double nmo_scalar_fn(const MathCfg* cfg, int64_t op, double a, double b) {
     case 4: return std::sqrt(a);
     case 5: return a / b;
     case 6: return m.powf(a, b);
+    case 7: return m.exp_m1(a);
+    case 8: return m.sin(a);
+    case 9: return m.cos(a);
     }
     return NAN;
 }

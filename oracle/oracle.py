@@ -42,11 +42,16 @@ class Settings(C.Structure):
         ("adam_learning_rate", C.c_double),
         ("adaptation", C.c_uint64), ("lr_gamma", C.c_double), ("lr_eigval_cutoff", C.c_double),
         ("freeze_transform", C.c_uint64), ("trajectory_kind", C.c_uint64),
+        ("sampler", C.c_uint64), ("mclmc_step_size", C.c_double), ("momentum_decoherence_length", C.c_double),
+        ("subsample_frequency", C.c_double), ("dynamic_step_size", C.c_uint64), ("mclmc_trajectory_kind", C.c_uint64),
+        ("trajectory_switch_fraction", C.c_double),
     ]
 
 
 ADAPT_DIAG, ADAPT_LOW_RANK = 0, 1
 TRAJ_EUCLIDEAN, TRAJ_EXACT_NORMAL, TRAJ_MICROCANONICAL = 0, 1, 2
+SAMPLER_NUTS, SAMPLER_MCLMC = 0, 1
+MCLMC_MICROCANONICAL, MCLMC_EUCLIDEAN, MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL = 0, 1, 2
 
 STATS_DTYPE = np.dtype([
     ("draw", "<u8"), ("chain", "<u8"), ("depth", "<u8"), ("maxdepth_reached", "<u8"), ("diverging", "<u8"),
@@ -54,7 +59,7 @@ STATS_DTYPE = np.dtype([
     ("step_size", "<f8"), ("step_size_bar", "<f8"), ("mean_tree_accept", "<f8"), ("mean_tree_accept_sym", "<f8"),
     ("max_energy_error", "<f8"), ("logp", "<f8"), ("energy", "<f8"), ("energy_error", "<f8"),
     ("fisher_distance", "<f8"), ("divergence_energy_error", "<f8"), ("chain_status", "<u8"),
-    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"),
+    ("transformation_update_id", "<i8"), ("num_eigenvalues", "<u8"), ("energy_change", "<f8"), ("average_step_size", "<f8"),
 ])
 
 VECTOR_STATS = ("gradient", "transformed_position", "transformed_gradient", "mass_matrix_inv", "transformation_mu",
@@ -135,6 +140,7 @@ def lib():
     L.nmo_run_ex.restype = C.c_int
     L.nmo_run_ex.argtypes = L.nmo_run.argtypes + [C.POINTER(RunExtras)]
     L.nmo_settings_default_low_rank.argtypes = [C.POINTER(Settings)]
+    L.nmo_settings_default_mclmc.argtypes = [C.POINTER(Settings)]
     L.nmo_chain_set_estimator.argtypes = [C.c_void_p, ESTIMATOR_FN, C.c_void_p]
     L.nmo_chain_set_transform.restype = C.c_int
     L.nmo_chain_set_transform.argtypes = [C.c_void_p, _dp, _dp, C.c_uint64, _dp, _dp, _dp]
@@ -186,10 +192,12 @@ def lib():
     return L
 
 
-def default_settings(low_rank=False, **overrides):
-    """DiagNutsSettings::default() or, with low_rank=True, LowRankNutsSettings::default() (src/sampler.rs:630-642)."""
+def default_settings(low_rank=False, mclmc=False, **overrides):
+    """DiagNutsSettings::default(), with low_rank=True LowRankNutsSettings::default() (src/sampler.rs:630-642), with mclmc=True
+    DiagMclmcSettings::default() (src/sampler.rs:368-374)."""
     s = Settings()
-    (lib().nmo_settings_default_low_rank if low_rank else lib().nmo_settings_default)(C.byref(s))
+    L = lib()
+    (L.nmo_settings_default_mclmc if mclmc else L.nmo_settings_default_low_rank if low_rank else L.nmo_settings_default)(C.byref(s))
     for k, v in overrides.items():
         if not hasattr(s, k):
             raise AttributeError(k)

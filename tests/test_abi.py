@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # every field is 8 bytes wide (header contract)
-    assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 42
-    assert _lib.STATS_DTYPE.itemsize == 8 * 22
+    assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 49
+    assert _lib.STATS_DTYPE.itemsize == 8 * 24
     assert C.sizeof(_lib.NmDrawOutputs) == 8 * 16
     assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 64
 

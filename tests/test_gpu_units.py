@@ -38,6 +38,10 @@ def test_scalar_math_bit_exact(oracle):
         3: (rng.uniform(-50, 50, n), rng.uniform(-50, 50, n)),
         4: (np.concatenate([np.exp(rng.uniform(-700, 700, n)), [0.0, 1.0, 2.0]]), None),
         5: (rng.normal(size=n) * np.exp(rng.uniform(-300, 300, n)), rng.normal(size=n) * np.exp(rng.uniform(-300, 300, n))),
+        # exp_m1 (the isokinetic momentum refresh) and sin / cos (the exact-normal geodesic step)
+        7: (np.concatenate([rng.uniform(-0.36, 0.36, n), rng.uniform(-40, 40, 20000), [0.0, -0.0, 0.35, -0.35, np.inf, -np.inf, np.nan, 1e-300]]), None),
+        8: (np.concatenate([rng.uniform(-10, 10, n), rng.uniform(-1e4, 1e4, 20000), [0.0, -0.0, np.pi / 2, np.inf, np.nan, 1e-300]]), None),
+        9: (np.concatenate([rng.uniform(-10, 10, n), rng.uniform(-1e4, 1e4, 20000), [0.0, -0.0, np.pi / 2, np.inf, np.nan, 1e-300]]), None),
     }
     for op, (a, b) in cases.items():
         da, db = dev(a), dev(b) if b is not None else None

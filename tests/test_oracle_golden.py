@@ -623,3 +623,59 @@ def test_trajectory_kinds_sample_the_right_posterior(oracle):
         # U-turn products are pure rounding noise, so trajectories of the two arithmetics part early for this kind)
         pos2, st2, _, _ = oracle.run(s, 0, dim, np.array([3.0]), oracle.gpu_cfg(64), n, x0, 3)
         assert np.allclose(pos2[:3], pos[:3], rtol=1e-9, atol=1e-12)
+
+
+# ---- MclmcChain (src/mclmc.rs; experimental upstream) ----------------------------------------------------
+def test_mclmc_reference_tests(oracle):
+    """The reference's own MCLMC tests (src/mclmc.rs:566-680): DiagMclmcSettings on a 10-dim N(3, 1) from x0 = 0, the three
+    trajectory kinds, 500 draws without a divergence and the last position near the mean; plus the default settings
+    (src/sampler.rs:342-374) and what the draw statistics must satisfy by construction."""
+    d = oracle.default_settings(mclmc=True)
+    assert (d.sampler, d.mclmc_step_size, d.momentum_decoherence_length, d.num_tune, d.num_draws, d.num_chains) == (1, 0.5, 3.0, 400, 1000, 6)
+    assert (d.subsample_frequency, d.dynamic_step_size, d.mclmc_trajectory_kind, d.trajectory_switch_fraction) == (1.0, 1, 2, 0.3)
+    assert d.max_energy_error == 1000.0 and d.step_size_method == 2 and d.fixed_step_size == 0.5
+    dim = 10
+    for kind, step in ((oracle.MCLMC_MICROCANONICAL, 0.5), (oracle.MCLMC_EUCLIDEAN, 0.3), (oracle.MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL, 0.5)):
+        s = oracle.default_settings(mclmc=True, num_tune=200, num_draws=500, mclmc_step_size=step, mclmc_trajectory_kind=kind, seed=kind)
+        pos, st, steps, failed = oracle.run(s, 0, dim, np.array([3.0]), oracle.ref_cfg(), 4, np.zeros((4, dim)), 500)
+        assert failed == 0 and st["diverging"].sum() == 0
+        assert (np.abs(pos[-1].mean(axis=1) - 3.0) < 3.0).all()
+        assert abs(pos[200:].mean() - 3.0) < 0.2
+        # num_steps = round(L / eps) leapfrogs per draw at factor 1: average_step_size is the (jittered) step size of the draw
+        assert (st["depth"] == st["n_steps"]).all() and (st["index_in_trajectory"] == st["depth"]).all()
+        assert np.allclose(st["average_step_size"][1:], st["step_size"][:-1], rtol=1e-12)
+        assert (st["energy_change"] == st["energy_error"]).all()
+
+
+def test_mclmc_ladder_and_divergences(oracle):
+    """dynamic_step_size: a divergent step halves the factor and asks for two steps (at most 10 halvings); without it the
+    draw is a divergence, the chain stays where it was (src/mclmc.rs:236-388)."""
+    dim, n = 11, 6
+    x0 = oracle.init_positions_uniform(8, 0, n, dim)
+    common = dict(num_tune=100, seed=8, mclmc_step_size=0.8, fixed_step_size=0.8, max_energy_error=2.0)
+    s = oracle.default_settings(mclmc=True, **common)
+    pos, st, _, failed = oracle.run(s, 2, dim, np.zeros(0), oracle.ref_cfg(), n, x0, 150)
+    assert failed == 0
+    laddered = st["average_step_size"] < st["step_size"].max() * 0.7
+    assert laddered.sum() > 0 and (st["depth"][laddered] > 4).all()
+    s2 = oracle.default_settings(mclmc=True, dynamic_step_size=0, **common)
+    pos2, st2, _, _ = oracle.run(s2, 2, dim, np.zeros(0), oracle.ref_cfg(), n, x0, 150)
+    div = st2["diverging"] != 0
+    assert div.sum() > 0
+    t, c = np.argwhere(div & (np.arange(150)[:, None] > 0))[0]
+    assert (pos2[t, c] == pos2[t - 1, c]).all()                 # the draw repeats the previous position
+    assert st2["index_in_trajectory"][t, c] == 0 and st2["energy_error"][t, c] == 0.0
+
+
+def test_det_expm1_within_ulps_of_libm(oracle):
+    """exp_m1 of the isokinetic refresh (transformed_hamiltonian.rs:800-801) in the engine's arithmetic."""
+    import ctypes as C
+    L = oracle.lib()
+    if not hasattr(L, "nmo_scalar_fn"):
+        pytest.skip("no scalar entry point")
+    cfg = oracle.gpu_cfg(64)
+    rng = np.random.default_rng(4)
+    L.nmo_scalar_fn.restype = C.c_double
+    for x in np.concatenate([rng.uniform(-0.35, 0.35, 3000), rng.uniform(-5, 5, 500), [0.0, 1e-300, -1e-20, 0.35, -0.35, 0.3500001]]):
+        got = L.nmo_scalar_fn(C.byref(cfg), 7, C.c_double(float(x)), C.c_double(0.0))
+        assert ulps(got, math.expm1(x)) <= 3, x
