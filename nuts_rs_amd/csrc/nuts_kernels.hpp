@@ -1948,6 +1948,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             const int other_side = fwd ? left_slot : right_slot;
             if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
             C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); C.storeRef(O.g, C.edge_g(ns));
+#ifdef NM_EXTRA_TRAFFIC   // development: is the kernel bound by the bytes it moves? (two more tile stores per doubling)
+            C.storeS(O.g, slot_F(MD)); C.storeS(O.z, slot_F(MD) + 1);
+#endif
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;
         }
