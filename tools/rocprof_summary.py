@@ -95,8 +95,10 @@ def k5(d, out, sub, logdir):
         pass
     g = res.get
     if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE"):
-        # MfmaUtil of rocprofv3's derived metrics: busy cycles summed over SIMDs / (GPU active cycles x SIMDs); 256 CUs x 4
-        res["mfma_util"] = res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 1024.0)
+        # MfmaUtil of rocprofv3's derived metrics: busy cycles summed over SIMDs / (kernel cycles x SIMDs); 256 CUs x 4 SIMDs.
+        # GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs, so kernel cycles = GRBM_GUI_ACTIVE / 8.
+        res["mfma_util"] = res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        res["mfma_util_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs"
     if g("SQ_INSTS_VALU_MFMA_MOPS_F64") and res["timed_launch_duration_ns"]:
         res["mfma_f64_TFLOPs"] = res["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / res["timed_launch_duration_ns"] / 1e3
         res["mfma_f64_frac_of_78.6TF"] = res["mfma_f64_TFLOPs"] / 78.6
