@@ -430,6 +430,11 @@ uint64_t  nm_engine_num_chains(const nm_engine* e);
  * the oracle reproduces it with gpu_cfg(threads_per_chain). */
 uint64_t  nm_engine_threads_per_chain(const nm_engine* e);
 uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
+/* dim > 4096: a chain is spread over ceil(dim / 4096) co-resident blocks of 256 threads that each own a 4096-element slice
+ * and exchange their block sums (1 for dim <= 4096).  Sums are then slice totals added in slice order; the oracle reproduces
+ * it with gpu_cfg(threads_per_chain, slice = 4096).  Element-wise densities (iid / diagonal normal), Euclidean NUTS with the
+ * diagonal adaptation, dim <= 65536. */
+uint64_t  nm_engine_blocks_per_chain(const nm_engine* e);
 /* draw launches served by the several-chains-per-wavefront kernels so far (nm_engine_config.lane_groups) */
 uint64_t  nm_engine_group_launches(const nm_engine* e);
 /* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
     "nm_engine_draw_ex_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
-    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
+    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_blocks_per_chain", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
@@ -152,6 +152,8 @@ def load():
     L.nm_engine_num_chains.restype = u64
     L.nm_engine_threads_per_chain.argtypes = [vp]
     L.nm_engine_threads_per_chain.restype = u64
+    L.nm_engine_blocks_per_chain.argtypes = [vp]
+    L.nm_engine_blocks_per_chain.restype = u64
     L.nm_engine_dims_per_lane.argtypes = [vp]
     L.nm_engine_dims_per_lane.restype = u64
     L.nm_engine_group_launches.argtypes = [vp]

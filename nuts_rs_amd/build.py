@@ -18,7 +18,7 @@ UNITS = ["nuts_engine.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern
          "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_eight_schools.hip", "kern_lr_mvn_prec.hip",
          "kern_tile_mvn_prec.hip", "kern_host_cb.hip", "kern_lr_host_cb.hip", "math_seam.hip",
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_eight_schools.hip", "kern_kin_mvn_prec.hip",
-         "kern_kin_host_cb.hip"]
+         "kern_kin_host_cb.hip", "kern_cluster.hip"]
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)

@@ -85,11 +85,59 @@ NM_DEV void wave_sum2(double& a, double& b) {
 // total in LDS, one barrier, then every thread adds the W totals in wave order (w = 0 first) — the documented
 // cross-wave order (oracle gpu_reduce).  Two LDS buffers alternate so one barrier per reduction is enough.
 constexpr int RED_MAX_VALUES = 6;
+
+// ---- chains wider than one block (dim > 4096): NM_CLUSTER_MODE translation units (kern_cluster.hip) -------------------------
+// `k` co-resident blocks ("members") own consecutive 4096-element slices of ONE chain and run the same instruction stream:
+// every scalar decision is a function of block sums, random words and per-chain scalars, so it is enough that every sum is
+// the same in all members.  A block's Reducer result is therefore followed by an exchange: each member publishes its
+// partial sums in the chain's mailbox, all meet at a counter, and every member adds the k partials in member order
+// (oracle gpu_reduce with gpu_slice: slice totals added in slice order).  Agent-scope release / acquire atomics carry the
+// data between compute units (and XCDs); the grid never exceeds the resident capacity, so the spin cannot deadlock.
+#ifndef NM_CLUSTER_MODE
+#define NM_CLUSTER_MODE 0
+#endif
+struct ClusterLink {
+    unsigned long long* box;     // [2][k][RED_MAX_VALUES] bit patterns of the members' partial sums (two epochs alternate)
+    unsigned long long* cnt;     // arrivals since the launch began
+    unsigned long long epoch;    // exchanges this member has completed since the launch began
+    int k, member;
+};
+
 template <int W>
 struct Reducer {
-    double* buf;   // LDS [2][RED_MAX_VALUES][W]
+    double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES in cluster mode)
     int par;
+#if NM_CLUSTER_MODE
+    ClusterLink* cl;
+    NM_DEV void init(double* lds) { buf = lds; par = 0; cl = nullptr; }
+    template <int N>
+    NM_DEV void cluster_combine(double (&v)[N]) {
+        ClusterLink& L = *cl;
+        double* lds_out = buf + 2 * RED_MAX_VALUES * W;
+        if (threadIdx.x == 0) {
+            unsigned long long* mine = L.box + ((L.epoch & 1ull) * (unsigned long long)L.k + (unsigned long long)L.member) * RED_MAX_VALUES;
+#pragma unroll
+            for (int i = 0; i < N; ++i) __hip_atomic_store(&mine[i], (unsigned long long)d2u(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long want = (L.epoch + 1ull) * (unsigned long long)L.k;
+            while (__hip_atomic_load(L.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            const unsigned long long* all = L.box + (L.epoch & 1ull) * (unsigned long long)L.k * RED_MAX_VALUES;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double t = u2d(__hip_atomic_load(&all[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                for (int m = 1; m < L.k; ++m) t = t + u2d(__hip_atomic_load(&all[m * RED_MAX_VALUES + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                lds_out[i] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = lds_out[i];
+        __syncthreads();
+        L.epoch += 1ull;
+    }
+#else
     NM_DEV void init(double* lds) { buf = lds; par = 0; }
+#endif
     template <int N>
     NM_DEV void sum_n(double (&v)[N]) {
         static_assert(N <= RED_MAX_VALUES, "too many values");
@@ -99,28 +147,32 @@ struct Reducer {
             for (int i = 0; i + 1 < N; i += 2) wave_sum2(v[i], v[i + 1]);
             if (N & 1) v[N - 1] = wave_sum(v[N - 1]);
         }
-        if (W == 1) return;
-        double* b = buf + par * (RED_MAX_VALUES * W);
-        if (lane_id() == 0) {
+        if (W != 1) {
+            double* b = buf + par * (RED_MAX_VALUES * W);
+            if (lane_id() == 0) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) b[i * W + wave_id()] = v[i];
+                for (int i = 0; i < N; ++i) b[i * W + wave_id()] = v[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double t = b[i * W];
+#pragma unroll
+                for (int w = 1; w < W; ++w) t = t + b[i * W + w];
+                v[i] = t;
+            }
+            par ^= 1;
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double t = b[i * W];
-#pragma unroll
-            for (int w = 1; w < W; ++w) t = t + b[i * W + w];
-            v[i] = t;
-        }
-        par ^= 1;
+#if NM_CLUSTER_MODE
+        if (cl && cl->k > 1) cluster_combine<N>(v);
+#endif
     }
     NM_DEV double sum(double x) { double v[1] = {x}; sum_n(v); return v[0]; }
     NM_DEV void sum2(double& a, double& b) { double v[2] = {a, b}; sum_n(v); a = v[0]; b = v[1]; }
     // true iff `ok` holds in every thread of the block
     NM_DEV bool all(bool ok) {
         const bool wave_ok = __ballot(!ok) == 0ull;
-        if (W == 1) return wave_ok;
+        if (W == 1 && !NM_CLUSTER_MODE) return wave_ok;
         return sum(wave_ok ? 0.0 : 1.0) == 0.0;
     }
 };

@@ -192,8 +192,9 @@ typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blo
 typedef void (*module_info_fn)(uint64_t out[5]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
-                         module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds)
+                         module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds), 3 cluster (dim > 4096)
     const bool lr = variant == 1;
+    if (variant == 3) return launch_cluster(logp_kind, kind, P, grid, stream, occ);   // chains wider than one block (kern_cluster.hip)
     if (logp_kind == NM_LOGP_MODULE) return module && variant == 0 ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
     if (lr) {      // the kernels that carry the low-rank transformation (LrWrap<Density>, kern_lr_*.hip)
         switch (logp_kind) {
@@ -334,6 +335,10 @@ struct nm_engine {
     // low-rank transformation (settings.adaptation == NM_ADAPT_LOW_RANK)
     bool lr = false;
     int variant = 0;            // kernel family: 0 plain, 1 LrWrap, 2 KinWrap (see launch())
+    // chains wider than one block (dim > 4096): cl_k blocks per chain, each with its own persistent vectors and copy of the scalars
+    uint64_t cl_k = 1;
+    unsigned long long *d_cl_box = nullptr, *d_cl_cnt = nullptr;
+    uint64_t n_clusters = 0;
     uint64_t lr_rmax = 0, lr_cap = 0;
     double *d_lrvec = nullptr, *d_lrval = nullptr, *d_lrwin = nullptr;
     nm_lowrank_estimator_fn lr_estimator = nm_lowrank_compute_update;
@@ -369,6 +374,8 @@ static void engine_free(nm_engine* e) {
     if (e->d_pvec) (void)hipFree(e->d_pvec);
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
+    if (e->d_cl_box) (void)hipFree(e->d_cl_box);
+    if (e->d_cl_cnt) (void)hipFree(e->d_cl_cnt);
     if (e->d_prof) (void)hipFree(e->d_prof);
     if (e->d_zig) (void)hipFree(e->d_zig);
     if (e->d_params) (void)hipFree(e->d_params);
@@ -384,6 +391,11 @@ static void engine_free(nm_engine* e) {
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+// the chains' scalars (cluster mode: the copy of every chain's first member)
+static hipError_t read_scalars(nm_engine* e, ChainScalars* out) {
+    if (e->cl_k == 1) return hipMemcpy(out, e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost);
+    return hipMemcpy2D(out, sizeof(ChainScalars), e->d_sc, e->cl_k * sizeof(ChainScalars), sizeof(ChainScalars), e->n_chains, hipMemcpyDeviceToHost);
 }
 
 extern "C" void nm_engine_destroy(nm_engine* e) { engine_free(e); }
@@ -427,6 +439,18 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     nm_engine_config cfg;
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
     int dpl = 0, wv = 0;
+    uint64_t cl_k = 1;
+    constexpr uint64_t CL_SLICE = 4096, CL_MAX_K = 16;
+    if (logp->dim > CL_SLICE) {     // wider than one block: ceil(dim / 4096) blocks per chain (kern_cluster.hip)
+        cl_k = (logp->dim + CL_SLICE - 1) / CL_SLICE;
+        if (cl_k > CL_MAX_K) return fail(NM_ERR_UNSUPPORTED, "dim %llu > %llu", (unsigned long long)logp->dim, (unsigned long long)(CL_SLICE * CL_MAX_K));
+        if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL)
+            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal) only", (unsigned long long)logp->dim);
+        if (lr || kin) return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: Euclidean NUTS with the diagonal adaptation only", (unsigned long long)logp->dim);
+        if ((cfg.dims_per_lane && cfg.dims_per_lane != 16) || (cfg.waves_per_chain && cfg.waves_per_chain != 4))
+            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096 runs on the (16 doubles, 4 waves) tiling", (unsigned long long)logp->dim);
+        dpl = 16; wv = 4;
+    } else
     if (!pick_tiling(logp->dim, logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 2 : cfg.dims_per_lane,
                      logp->kind == NM_LOGP_EIGHT_SCHOOLS ? 1 : cfg.waves_per_chain, &dpl, &wv))
         return fail(NM_ERR_UNSUPPORTED, "no tiling for dim %llu with dims_per_lane %llu / waves_per_chain %llu (max dim 4096 = 16 doubles x 64 lanes x 4 waves)",
@@ -438,7 +462,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (!e) return fail(NM_ERR_HIP, "out of host memory");
     e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl; e->wpc = wv;
     e->lr = lr;
-    e->variant = lr ? 1 : (kin ? 2 : 0);
+    e->variant = cl_k > 1 ? 3 : lr ? 1 : (kin ? 2 : 0);
+    e->cl_k = cl_k;
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;
     const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
@@ -472,10 +497,19 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         const uint64_t wave_slots = resident;                      // chains the wave-per-chain kernel runs at once
         if (cfg.grid_blocks) resident = cfg.grid_blocks;            // tuning override: blocks in the grid
         e->n_waves = (unsigned)(n_chains < resident ? n_chains : resident);
+        if (cl_k > 1) {     // whole clusters only, 8 x cl_k blocks at a time (block -> (cluster, member) map of the kernels); never
+            const uint64_t unit = 8 * cl_k;                                  // more blocks than the chip holds at once (the members spin)
+            uint64_t units = resident / unit;
+            if (units == 0) { engine_free(e); return fail(NM_ERR_UNSUPPORTED, "dim %llu needs %llu co-resident blocks, the device holds %llu", (unsigned long long)logp->dim, (unsigned long long)unit, (unsigned long long)resident); }
+            const uint64_t need = (n_chains + 7) / 8;
+            if (units > need) units = need;
+            e->n_waves = (unsigned)(units * unit);
+            e->n_clusters = units * 8;
+        }
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const int gs = grp::group_size(logp->dim);
         const bool group_density = (logp->kind != NM_LOGP_MODULE && logp->kind != NM_LOGP_HOST_CALLBACK) || (logp->kind == NM_LOGP_MODULE && gs && e->module_group_lanes == gs);   // every built-in density has a group form
-        if (!lr && !kin && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
+        if (cl_k == 1 && !lr && !kin && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
@@ -486,7 +520,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
             e->group_grid = (unsigned)(need < gres ? need : gres);
         }
     }
-    const size_t pvec_bytes = (size_t)n_chains * NUM_PSLOT * dpad * sizeof(double);
+    const size_t pvec_bytes = (size_t)n_chains * cl_k * NUM_PSLOT * dpad * sizeof(double);   // cluster mode: one set per member
     {   // the matrix-core kernel's grid: 16-chain tiles on resident blocks (one 16-wave block fills a CU's wave slots)
         int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
@@ -500,7 +534,12 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_svec, svec_bytes));
     E_TRY(hipMemsetAsync(e->d_svec, 0, svec_bytes, e->stream));
-    E_TRY(hipMalloc(&e->d_sc, n_chains * sizeof(ChainScalars)));
+    E_TRY(hipMalloc(&e->d_sc, n_chains * cl_k * sizeof(ChainScalars)));
+    if (cl_k > 1) {
+        E_TRY(hipMalloc(&e->d_cl_box, e->n_clusters * 2 * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
+        E_TRY(hipMalloc(&e->d_cl_cnt, e->n_clusters * sizeof(unsigned long long)));
+        E_TRY(hipMemset(e->d_cl_box, 0, e->n_clusters * 2 * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
+    }
     E_TRY(hipMalloc(&e->d_prof, 32 * sizeof(unsigned long long)));
     E_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
     E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
@@ -527,12 +566,12 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMemcpy(e->d_zig, kZigTables, sizeof kZigTables, hipMemcpyHostToDevice));
     // per-chain scalars: NutsChain::new / GlobalStrategy::new state (the DualAverage is reset on the device)
     {
-        std::vector<ChainScalars> sc(n_chains);
-        for (uint64_t c = 0; c < n_chains; ++c) {
+        std::vector<ChainScalars> sc(n_chains * cl_k);       // cluster mode: every member keeps an identical copy
+        for (uint64_t c = 0; c < n_chains * cl_k; ++c) {
             ChainScalars& q = sc[c];
             memset(&q, 0, sizeof q);
             uint8_t key[32];
-            nm_chain_rng_key(s.seed, cfg.chain_id_offset + c, key);
+            nm_chain_rng_key(s.seed, cfg.chain_id_offset + c / cl_k, key);
             for (int i = 0; i < 8; ++i)
                 q.key[i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) | ((uint32_t)key[4 * i + 3] << 24);
             q.transform_id = -1; q.mm_id = -1; q.stats_last_id = -1;
@@ -540,7 +579,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
             q.current_window_size = s.mass_matrix_switch_freq;
             q.status = NM_CHAIN_OK;
         }
-        E_TRY(hipMemcpy(e->d_sc, sc.data(), n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+        E_TRY(hipMemcpy(e->d_sc, sc.data(), n_chains * cl_k * sizeof(ChainScalars), hipMemcpyHostToDevice));
     }
     KParams& P = e->P;
     memset(&P, 0, sizeof P);
@@ -548,6 +587,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     P.n_chains = n_chains; P.dim = logp->dim; P.dpad = dpad; P.chain_id_offset = cfg.chain_id_offset; P.nsslot = nsslot;
     P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.prof = e->d_prof; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
     P.early_end = early_end;
+    P.cl_k = cl_k; P.cl_slice = CL_SLICE; P.cl_box = e->d_cl_box; P.cl_cnt = e->d_cl_cnt;
     {   // MclmcChain's switch_draw = (trajectory_switch_fraction * num_tune) as u64 (sampler.rs:441; `as` saturates, NaN -> 0)
         const double q = s.trajectory_switch_fraction * num_tune_f;
         P.mclmc_switch_draw = q >= 18446744073709551616.0 ? ~0ull : (q > 0.0 ? (uint64_t)q : 0ull);
@@ -658,11 +698,12 @@ extern "C" nm_status nm_engine_set_positions_masked(nm_engine* e, const double* 
         P.init_mask = e->d_init_mask;
     }
     e->cb_active.store(1, std::memory_order_release);
+    if (e->cl_k > 1) HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));   // the clusters' arrival counters
     HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->variant));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->cb_active.store(0, std::memory_order_release);
     std::vector<ChainScalars> sc(e->n_chains);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(read_scalars(e, sc.data()));
     uint64_t bad = 0, fatal = 0, min_draws = ~0ull;
     for (uint64_t c = 0; c < e->n_chains; ++c) {
         if (h_chain_status) h_chain_status[c] = sc[c].status;
@@ -760,7 +801,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
     nm_status st = nm_engine_synchronize(e);
     if (st != NM_OK) return st;
     std::vector<ChainScalars> sc(e->n_chains);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(read_scalars(e, sc.data()));
     const uint64_t dim = e->dim;
     for (uint64_t c = 0; c < e->n_chains; ++c)
         if (sc[c].lr_pending != LR_IDLE && sc[c].lr_pending != LR_SET_TRANSFORM) return fail(NM_ERR_STATE, "chain %llu is waiting for its estimator", (unsigned long long)c);
@@ -792,7 +833,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
         if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
         (void)hipFree(d_stage); (void)hipFree(d_vals2);
         if (er != hipSuccess) return fail(NM_ERR_HIP, "broadcast of the transformation: %s", hipGetErrorString(er));
-        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(read_scalars(e, sc.data()));
     }
     for (uint64_t c = 0; per_chain && c < e->n_chains; ++c) {
         const uint64_t k = per_chain ? c : 0;
@@ -847,7 +888,7 @@ extern "C" nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, doub
     nm_status st = nm_engine_synchronize(e);
     if (st != NM_OK) return st;
     std::vector<ChainScalars> sc(e->n_chains);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(read_scalars(e, sc.data()));
     const uint64_t dim = e->dim, dpad = e->P.dpad, R = e->lr_rmax;
     for (uint64_t c = 0; c < e->n_chains; ++c) {
         if (h_n_eig) h_n_eig[c] = sc[c].lr_has_inner ? sc[c].lr_rank : 0;
@@ -956,6 +997,7 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_mm_eigvals = out->d_mass_matrix_eigvals;
     e->cb_active.store(1, std::memory_order_release);   // NM_LOGP_HOST_CALLBACK: the service threads answer until the next synchronize
     if (e->lr) return lr_draw(e, n_draws, P);           // synchronous: the estimator rounds need the host between launches
+    if (e->cl_k > 1) HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     // small chains, many of them: the several-chains-per-wavefront kernels compute the same draws and statistics
     if (e->group_grid) {
@@ -1042,7 +1084,7 @@ extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, c
     if (st != NM_OK) return st;
     // surface chain failures the way Chain::draw's Result does
     std::vector<ChainScalars> sc(e->n_chains);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(read_scalars(e, sc.data()));
     uint64_t failed = 0;
     for (auto& q : sc) if (q.status != NM_CHAIN_OK) failed++;
     if (failed) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s) stopped with an error status", (unsigned long long)failed);
@@ -1070,10 +1112,19 @@ static nm_status read_slot(nm_engine* e, int slot, double* h_out) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     const KParams& P = e->P;
     // strided copy: row c = vec[c][slot][0..dim)
+    if (e->cl_k > 1) {      // a chain's vector is the concatenation of its members' slices
+        for (uint64_t m = 0; m < e->cl_k; ++m) {
+            const uint64_t off = m * P.cl_slice, len = std::min<uint64_t>(P.cl_slice, e->dim - off);
+            HIP_TRY(hipMemcpy2D(h_out + off, e->dim * sizeof(double), e->d_pvec + (m * NUM_PSLOT + (size_t)slot) * P.dpad,
+                                (size_t)e->cl_k * NUM_PSLOT * P.dpad * sizeof(double), len * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
+        }
+        return NM_OK;
+    }
     HIP_TRY(hipMemcpy2D(h_out, e->dim * sizeof(double), e->d_pvec + (size_t)slot * P.dpad,
                         (size_t)NUM_PSLOT * P.dpad * sizeof(double), e->dim * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
     return NM_OK;
 }
+extern "C" uint64_t nm_engine_blocks_per_chain(const nm_engine* e) { return e ? e->cl_k : 0; }
 extern "C" nm_status nm_engine_get_positions(nm_engine* e, double* h_x) { return read_slot(e, P_X, h_x); }
 extern "C" nm_status nm_engine_get_gradients(nm_engine* e, double* h_gx) { return read_slot(e, P_GX, h_gx); }
 extern "C" nm_status nm_engine_get_mass_matrix(nm_engine* e, double* h_stds, double* h_mean) {
@@ -1087,7 +1138,7 @@ extern "C" nm_status nm_engine_get_step_sizes(nm_engine* e, double* h_step_size)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<ChainScalars> sc(e->n_chains);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(read_scalars(e, sc.data()));
     for (uint64_t c = 0; c < e->n_chains; ++c) h_step_size[c] = sc[c].step_size;
     return NM_OK;
 }
@@ -1098,7 +1149,7 @@ extern "C" nm_status nm_engine_get_counters(nm_engine* e, uint64_t* total_leapfr
     if (st != NM_OK) return st;
     if (total_leapfrogs) {
         std::vector<ChainScalars> sc(e->n_chains);
-        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(read_scalars(e, sc.data()));
         uint64_t tot = 0;
         for (auto& q : sc) tot += q.total_steps;
         *total_leapfrogs = tot - e->steps_base;

@@ -126,6 +126,10 @@ struct KParams {
     // derived schedule constants (GlobalStrategy::new, adapt_strategy.rs:77-98)
     uint64_t early_end, final_step_size_window;
     uint64_t mclmc_switch_draw;        // MclmcChain::switch_draw (sampler.rs:441)
+    // chains wider than one block (NM_CLUSTER_MODE kernels): cl_k members of cl_slice elements each per chain, their mailboxes
+    uint64_t cl_k, cl_slice;
+    unsigned long long* cl_box;        // [clusters][2][cl_k][RED_MAX_VALUES]
+    unsigned long long* cl_cnt;        // [clusters], zeroed before every launch
     double ln_max_step;                // ln(da_max_step_size), dual_avg.rs:59
     double jitter_low, jitter_scale;   // Uniform::new(1-j, 1+j) (stepsize/adapt.rs:259-261)
     // outputs of the draw kernel
@@ -257,6 +261,8 @@ struct IidNormal {
     double mu;
     template <int W>
     NM_DEV void init(const double* params, int, Reducer<W>&) { mu = params[0]; }
+    template <int W>
+    NM_DEV void init_slice(const double* params, int, int, int, Reducer<W>&) { mu = params[0]; }   // cluster mode: this block holds one slice
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
         double acc = 0.0;
@@ -288,6 +294,19 @@ struct DiagNormal {
             }
         double log_det_p = R.sum(acc);
         norm = -0.5 * ((double)dim * ulog(6.283185307179586) - log_det_p);
+    }
+    // cluster mode: this block holds elements [goff, goff + dim) of a chain of gdim elements (R.sum spans the whole chain)
+    template <int W>
+    NM_DEV void init_slice(const double* params, int dim, int gdim, int goff, Reducer<W>& R) {
+        prec = params + goff;
+        double acc = 0.0;
+        for (int m = 0; m < (dim + 128 * W - 1) / (128 * W); ++m)
+            for (int j = 0; j < 2; ++j) {
+                int d = 2 * (m * 64 * W + tid()) + j;
+                acc = acc + (d < dim ? dlog(prec[d < dim ? d : 0]) : 0.0);
+            }
+        double log_det_p = R.sum(acc);
+        norm = -0.5 * ((double)gdim * ulog(6.283185307179586) - log_det_p);
     }
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
@@ -536,7 +555,7 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     uint32_t rng_cache[RNG_CACHE_WORDS];
     double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
     double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
-    double red[2 * RED_MAX_VALUES * W];
+    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES : 0)];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
     double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
     // Between trees both arrays are free: the momentum refresh uses l1_v as its ChaCha word buffer (hence the 72
@@ -562,7 +581,10 @@ struct ChainCtx {
     double* lsig;       // LDS [64*DPL]: sigma of the resident chain (tile order: lane l reads its own elements)
     double* lmu;        // LDS [64*DPL]: mu
     PendEntry* pend;    // LDS
-    int dim;
+    int dim;            // elements this block holds (the chain's dim; in cluster mode this member's slice)
+    int gdim;           // the chain's dim
+    int goff;           // cluster mode: index of this member's first element in the chain's vectors, else 0
+    ClusterLink link;   // cluster mode: this chain's mailbox
     int maxdepth_cfg;
     ChainScalars& sc;   // LDS
     unsigned long long prof_t;
@@ -632,10 +654,22 @@ struct ChainCtx {
     NM_DEV const double2* tptr(const double* base) const { return reinterpret_cast<const double2*>(base) + tid(); }
 };
 
+// the thread that writes a draw's nm_draw_stats row (cluster mode: of the chain's first member)
+#if NM_CLUSTER_MODE
+#define NM_STAT_WRITER(C) (tid() == 0 && (C).link.member == 0)
+#else
+#define NM_STAT_WRITER(C) (tid() == 0)
+#endif
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, uint64_t chain, uint64_t wave) {
     const KParams& P = C.P;
-    C.dim = (int)P.dim;
+    C.dim = (int)P.dim; C.gdim = (int)P.dim; C.goff = 0;
+#if NM_CLUSTER_MODE
+    // `chain` arrives as the sub-chain index chain * cl_k + member (its own persistent vectors and copy of the scalars);
+    // C.link.{box, cnt, k, member, epoch} were set by the kernel
+    C.goff = C.link.member * (int)P.cl_slice;
+    C.dim = (int)(P.dim - (uint64_t)C.goff < P.cl_slice ? P.dim - (uint64_t)C.goff : P.cl_slice);
+#endif
     C.maxdepth_cfg = (int)P.s.maxdepth;
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
@@ -663,8 +697,15 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
         chain_sync();
     }
     C.red.init(sh.red);
+#if NM_CLUSTER_MODE
+    C.red.cl = &C.link;
+#endif
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
+#if NM_CLUSTER_MODE
+    C.dens.init_slice(P.logp_params, C.dim, C.gdim, C.goff, C.red);     // element-wise densities only (IidNormal, DiagNormal)
+#else
     C.dens.init(P.logp_params, C.dim, C.red);
+#endif
     C.dens.set_lds(sh.dens_lds);
     if constexpr (can_fail<Dens>::value) C.dens.bind(P, chain);
 }
@@ -1033,6 +1074,26 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
     // at most 17 passes (1088 cells) per chunk: wider tilings take several chunks, which keeps the refresh's register
     // footprint (4 values per pass and lane in flight) the same for every kernel.  A vector that fits one 64-lane
     // pass with room to spare is cheaper with the simple pass-at-a-time routine (K4: +10 %).
+#if NM_CLUSTER_MODE
+    // every member draws the chain's whole vector, slice after slice in stream order (the members' streams stay identical),
+    // and keeps its own slice
+    for (int j = 0; j < C.link.k; ++j) {
+        const int off = j * (int)C.P.cl_slice;
+        const int cnt = C.gdim - off < (int)C.P.cl_slice ? C.gdim - off : (int)C.P.cl_slice;
+        fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, cnt, C.zig, 64 * W, C.P.prof, C.prof_t);
+        if (j == C.link.member) {
+            const double2* s2 = C.tptr(C.l1z);
+#pragma unroll
+            for (int m = 0; m < DPL / 2; ++m) {
+                const double2 q = s2[m * 64 * W];
+                v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+                v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+            }
+        }
+        block_sync(false);
+    }
+    C.storeS(v, STAGE_V);
+#else
     if (DPL == 2 && C.dim <= 48) {
         fill_standard_normals(C.rng, C.l1z, C.dim, C.zig);
     } else {
@@ -1046,6 +1107,7 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
         v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
     C.storeS(v, STAGE_V);
+#endif
 #else
     fill_standard_normals(C.rng, C.sslot(STAGE_V), C.dim, C.zig);
     const int so = C.soS(STAGE_V);
@@ -1975,7 +2037,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 template <int DPL, int W, class Dens>
 NM_DEV void write_row(ChainCtx<DPL, W, Dens>& C, double* base, size_t row, const Tile<DPL>& t) {
     if (!base) return;
-    double* dst = base + row;
+    double* dst = base + row + C.goff;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         int d = C.elem(k);
@@ -2247,7 +2309,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     if (st != NM_CHAIN_OK) {
         sc.status = st;
-        if (P.out_stats && tid() == 0) {
+        if (P.out_stats && NM_STAT_WRITER(C)) {
             nm_draw_stats zz = {};
             zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = st;
             P.out_stats[t_out * P.n_chains + chain] = zz;
@@ -2324,7 +2386,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     }
     sc.stats_last_id = sc.mm_id;
     NM_MARK(C, 5)
-    if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    if (P.out_stats && NM_STAT_WRITER(C)) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
 }
 
@@ -2474,6 +2536,35 @@ template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
+#if NM_CLUSTER_MODE
+    // block b = member (b / 8) % k of cluster (b / 8k) * 8 + b % 8: with the round-robin placement of blocks on the 8 XCDs
+    // the members of a chain share an L2 (a performance matter only: the exchange is agent-scope)
+    const unsigned cl_k = (unsigned)P.cl_k, cl_member = (blockIdx.x / 8u) % cl_k;
+    const uint64_t cl_id = (uint64_t)(blockIdx.x / (8u * cl_k)) * 8u + blockIdx.x % 8u, n_clusters = gridDim.x / cl_k;
+    unsigned long long cl_epoch = 0ull;
+    for (uint64_t chain = cl_id; chain < P.n_chains; chain += n_clusters) {
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
+        C.link.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; C.link.cnt = P.cl_cnt + cl_id;
+        C.link.k = (int)cl_k; C.link.member = (int)cl_member; C.link.epoch = cl_epoch;
+        const uint64_t sci = chain * cl_k + cl_member;
+        ctx_begin(C, sh, sci, blockIdx.x);
+        if (C.sc.status == NM_CHAIN_OK) {
+            {
+                Tile<DPL> t;
+                C.loadP(t, P_SIG); C.store(t, C.lsig);
+                C.loadP(t, P_MU); C.store(t, C.lmu);
+            }
+            for (uint64_t t = 0; t < P.n_draws; ++t) {
+                chain_draw(C, chain, t);
+                if (C.sc.status != NM_CHAIN_OK) break;
+            }
+        }
+        ctx_end(C, sci);
+        cl_epoch = C.link.epoch;
+        __syncthreads();
+    }
+    return;
+#endif
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
@@ -2511,11 +2602,26 @@ template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
+#if NM_CLUSTER_MODE
+    const unsigned cl_k = (unsigned)P.cl_k, cl_member = (blockIdx.x / 8u) % cl_k;
+    const uint64_t cl_id = (uint64_t)(blockIdx.x / (8u * cl_k)) * 8u + blockIdx.x % 8u, n_clusters = gridDim.x / cl_k;
+    unsigned long long cl_epoch = 0ull;
+    for (uint64_t x0_chain = cl_id; x0_chain < P.n_chains; x0_chain += n_clusters) {
+        if (P.init_mask && !P.init_mask[x0_chain]) continue;
+        const uint64_t chain = x0_chain * cl_k + cl_member;                 // the sub-chain: this member's vectors and scalars
+        ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
+        C.link.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; C.link.cnt = P.cl_cnt + cl_id;
+        C.link.k = (int)cl_k; C.link.member = (int)cl_member; C.link.epoch = cl_epoch;
+        ctx_begin(C, sh, chain, blockIdx.x);
+        ChainScalars& sc = C.sc;
+#else
     for (uint64_t chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
         if (P.init_mask && !P.init_mask[chain]) continue;                  // per-chain Chain::set_position: the others keep their state
+        const uint64_t x0_chain = chain;
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
+#endif
         // stepsize::Strategy::new (stepsize/adapt.rs:67-72) belongs to the chain's construction: only the first
         // set_position of a chain does it (mm_id is still -1); a retry after BadInitGrad keeps the adaptation state
         if (sc.mm_id < 0) {
@@ -2529,7 +2635,7 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             int d = C.elem(k);
-            x.a[k] = d < C.dim ? P.x0[chain * P.dim + d] : 0.0;
+            x.a[k] = d < C.dim ? P.x0[x0_chain * P.dim + (uint64_t)C.goff + d] : 0.0;
         }
         // init_state_untransformed (transformed_hamiltonian.rs:663-685)
         (void)C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
@@ -2577,6 +2683,9 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         }
         sc.status = status;
         ctx_end(C, chain);
+#if NM_CLUSTER_MODE
+        cl_epoch = C.link.epoch;
+#endif
         __syncthreads();
     }
 }

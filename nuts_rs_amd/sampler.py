@@ -314,6 +314,10 @@ class ChainBatch:
         """64 x waves cooperating on a chain; fixes the reduction order over dim (oracle: gpu_cfg(threads_per_chain))."""
         return int(_lib.load().nm_engine_threads_per_chain(self._h))
 
+    def blocks_per_chain(self):
+        """dim > 4096: co-resident blocks that share one chain, each owning a 4096-element slice (else 1)."""
+        return int(_lib.load().nm_engine_blocks_per_chain(self._h))
+
     def dims_per_lane(self):
         return int(_lib.load().nm_engine_dims_per_lane(self._h))
 

@@ -19,6 +19,7 @@
 //     algorithms below, which the HIP engine implements operation-for-operation so that GPU and oracle
 //     agree bit-for-bit (tests/ bound detmath-vs-libm by ulps).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -33,6 +34,8 @@ struct MathCfg {
     int64_t reduce_mode = REDUCE_REF_SIMD;
     int64_t simd_lanes = 4;     // REDUCE_REF_SIMD: f64 lanes of the SIMD register (1, 2, 4, 8)
     int64_t gpu_threads = 64;   // REDUCE_GPU: threads cooperating on one chain (64 * waves)
+    int64_t gpu_slice = 0;      // REDUCE_GPU: > 0: a chain wider than one block — consecutive slices of this many elements are reduced
+                                // as above, each by its own block, and the slice totals added in slice order (engine: dim > 4096)
     int64_t lr_seq_dots = 0;    // the low-rank transformation's U'v as sequential fma dot products (the engine's matrix-core
                                 // kernel for shared matrices: an MFMA accumulates over the inner index in ascending order)
 };
@@ -201,10 +204,24 @@ struct Ctx {
     // offsets 1,2,4,8,16,32; the W=T/64 wave totals are added in wave order.
     template <class Acc>  // Acc(double acc, size_t d) -> double : one accumulation step
     double gpu_reduce(size_t n, Acc&& step) const {
+        const size_t S = (size_t)cfg.gpu_slice;
+        if (S > 0 && n > S) {
+            double total = 0.0;
+            for (size_t off = 0, b = 0; off < n; off += S, ++b) {
+                const double t = gpu_reduce_block(off, std::min(S, n - off), step);
+                total = b == 0 ? t : total + t;
+            }
+            return total;
+        }
+        return gpu_reduce_block(0, n, step);
+    }
+    template <class Acc>
+    double gpu_reduce_block(size_t off, size_t n, Acc&& step) const {
         const size_t T = (size_t)cfg.gpu_threads;
         std::vector<double> part(T, 0.0);
-        for (size_t d = 0; d < n; ++d) {
-            size_t q = d / 2, t = q % T;
+        for (size_t dl = 0; dl < n; ++dl) {
+            const size_t d = off + dl;
+            size_t q = dl / 2, t = q % T;
             part[t] = step(part[t], d);
         }
         // (a thread's elements are visited in increasing d, which is (m, j) order)

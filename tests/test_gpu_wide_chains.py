@@ -1,0 +1,69 @@
+"""Chains wider than one block (dim > 4096; the reference has no dimension limit): ceil(dim / 4096) co-resident blocks per
+chain, every block sum exchanged between them (csrc/kern_cluster.hip, dev_math.hpp).  Engine (C ABI) against the oracle with
+the matching reduction order (gpu_cfg(256, gpu_slice=4096)): draw for draw, bit for bit."""
+import numpy as np
+import pytest
+
+import nuts_rs_amd as N
+from helpers import assert_bit_exact, oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (id, dim, n_chains, num_tune, n_draws, density, settings kwargs)
+    ("dim4097", 4097, 3, 30, 45, "iid", {}),
+    ("dim5000", 5000, 3, 30, 45, "diag", {}),
+    ("dim8192_exact_slices", 8192, 2, 30, 45, "iid", {}),
+    ("dim10000", 10000, 3, 25, 40, "diag", {}),
+    ("dim20000_adam", 20000, 2, 20, 32, "iid", dict(adam=True)),
+    ("dim40000", 40000, 2, 16, 26, "diag", {}),
+    ("dim65536_max", 65536, 1, 12, 20, "iid", {}),
+    ("dim9000_many_chains", 9000, 37, 16, 26, "iid", {}),
+    ("dim6000_options", 6000, 3, 30, 45, "diag", dict(maxdepth=4, store=True)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_wide_chain_parity_bit_exact(oracle, case):
+    name, dim, n, tune, n_draws, dens, opt = case
+    s = N.DiagNutsSettings(num_chains=n, seed=100 + dim % 97, num_tune=tune, maxdepth=opt.get("maxdepth", 10),
+                           store_divergences=bool(opt.get("store")), store_gradient=bool(opt.get("store")))
+    if opt.get("adam"):
+        s.adapt_options.step_size_settings.method = N.STEP_ADAM
+    rng = np.random.default_rng(dim)
+    logp = N.LogpSpec.iid_normal(dim, 3.0) if dens == "iid" else N.LogpSpec.diag_normal(np.exp(rng.uniform(-2, 2, dim)))
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert b.blocks_per_chain() == -(-dim // 4096) and b.threads_per_chain() == 256
+    status = b.set_position(x0, raise_on_error=False)
+    assert (status == 0).all()
+    pos_g, st_g = b.draw_many(n_draws // 2)
+    pos_g2, st_g2 = b.draw_many(n_draws - n_draws // 2)           # the chains' state survives the end of a launch
+    pos_g, st_g = np.concatenate([pos_g, pos_g2]), np.concatenate([st_g, st_g2])
+    sd, mu = b.mass_matrix()
+    xs, gs, steps_g = b.positions(), b.gradients(), b.counters()["total_leapfrogs"]
+    b.close()
+    cfg = oracle.gpu_cfg(256, gpu_slice=4096)
+    pos_o, st_o, steps, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, cfg, n, x0, n_draws, n_threads=8)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    assert steps_g == steps
+    assert (xs == pos_o[-1]).all()                                 # the gathered per-chain vectors
+    assert np.isfinite(sd).all() and np.isfinite(mu).all() and np.isfinite(gs).all()
+
+
+def test_wide_chain_posterior_and_unsupported(oracle):
+    dim, n = 6000, 16
+    s = N.DiagNutsSettings(num_chains=n, seed=5, num_tune=150)
+    b = N.ChainBatch(s, N.LogpSpec.iid_normal(dim, 3.0), n)
+    b.set_position(b.init_positions_uniform())
+    pos, st = b.draw_many(230)
+    b.close()
+    post = pos[150:]
+    assert abs(post.mean() - 3.0) < 0.01 and abs(post.var() - 1.0) < 0.02 and st["diverging"][150:].sum() == 0
+    with pytest.raises(N.NutsAmdError):
+        N.ChainBatch(s, N.LogpSpec.funnel(5000), 2)                # not an element-wise density
+    with pytest.raises(N.NutsAmdError):
+        N.ChainBatch(N.LowRankNutsSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)
+    with pytest.raises(N.NutsAmdError):
+        N.ChainBatch(s, N.LogpSpec.iid_normal(70000, 0.0), 2)      # > 16 blocks per chain
