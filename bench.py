@@ -164,6 +164,30 @@ def pmc_profile(steps_dims):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """Threads worth of CPU this process may use: the affinity mask, capped by the cgroup CPU quota (a container that shows 256
+    logical CPUs may be allowed 16 CPUs' worth of time; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} logical CPUs in the affinity mask"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())    # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < n:
+        note += f", cgroup CPU quota {quota:g} CPUs: {max(1, int(round(quota)))} threads used"
+        n = max(1, int(round(quota)))
+    return n, note
+
+
 def cpu_baseline(args, cores):
     """The CPU restatement of nuts-rs (oracle/, reference arithmetic: libm + SIMD-order sums) on this box's host
     cores, WALL CLOCK: one chain per task over `cores` threads (the reference's Rayon structure, src/sampler.rs:1116),
@@ -392,9 +416,10 @@ def main():
                          "pmc": pmc_detail},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores, cores_note = usable_cores()
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cores)
+                out["cpu_baseline"]["cores_note"] = cores_note
             except Exception as e:   # the bench line must still be printed
                 out["cpu_baseline"] = {"value": None, "unit": "leapfrog-steps*dims/s", "cores": cores, "kind": "port",
                                        "sample": f"failed: {e}"}

@@ -101,7 +101,10 @@ struct ClusterLink {
     unsigned long long* cnt;     // arrivals since the launch began
     unsigned long long epoch;    // exchanges this member has completed since the launch began
     int k, member;
+    int same_xcd;                // every member reported the same XCC_ID at kernel start: the XCD's L2 is their coherence point
 };
+// the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+NM_DEV int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 0xfu); }
 
 template <int W>
 struct Reducer {
@@ -118,9 +121,18 @@ struct Reducer {
             unsigned long long* mine = L.box + ((L.epoch & 1ull) * (unsigned long long)L.k + (unsigned long long)L.member) * RED_MAX_VALUES;
 #pragma unroll
             for (int i = 0; i < N; ++i) __hip_atomic_store(&mine[i], (unsigned long long)d2u(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long want = (L.epoch + 1ull) * (unsigned long long)L.k;
-            while (__hip_atomic_load(L.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            if (L.same_xcd) {
+                // all members sit on one XCD (verified when the kernel started): its L2 is their point of coherence, the
+                // agent-scope atomics are performed there, and no cache needs writing back or invalidating — the release /
+                // acquire pair below costs about as much again as the whole leapfrog (measured: 39 -> 22 us at dim 8192)
+                __builtin_amdgcn_s_waitcnt(0);             // the partial sums are in the L2 before the arrival is counted
+                (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(L.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            } else {
+                (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(L.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            }
             const unsigned long long* all = L.box + (L.epoch & 1ull) * (unsigned long long)L.k * RED_MAX_VALUES;
 #pragma unroll
             for (int i = 0; i < N; ++i) {

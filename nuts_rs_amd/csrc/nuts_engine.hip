@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <dlfcn.h>
@@ -345,7 +346,13 @@ struct nm_engine {
     void* lr_estimator_ctx = nullptr;
     uint64_t lr_threads = 0;
     uint64_t lr_updates = 0, lr_rounds = 0;  // estimator calls / pause-resume rounds so far
+    // staging of an estimator round (grow-only): the pending chains' windows come down in one batch of asynchronous copies into
+    // pinned memory, their updates go up as ONE packed buffer that a kernel scatters into the chains' slots
+    double *h_lr_win = nullptr, *h_lr_upd = nullptr, *d_lr_upd = nullptr;
+    uint64_t* d_lr_meta = nullptr;
+    size_t h_lr_win_bytes = 0, h_lr_upd_bytes = 0, d_lr_upd_bytes = 0, d_lr_meta_bytes = 0;
     double lr_host_seconds = 0.0;
+    double lr_download_seconds = 0.0, lr_estimator_seconds = 0.0, lr_upload_seconds = 0.0;   // its parts
     // shared transformation + full-precision normal: 16 chains per block, products on the matrix cores (nuts_tile.hpp)
     bool tile_active = false;
     tile::TileMats tile_mats = {};
@@ -375,6 +382,10 @@ static void engine_free(nm_engine* e) {
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
     if (e->d_cl_box) (void)hipFree(e->d_cl_box);
+    if (e->h_lr_win) (void)hipHostFree(e->h_lr_win);
+    if (e->h_lr_upd) (void)hipHostFree(e->h_lr_upd);
+    if (e->d_lr_upd) (void)hipFree(e->d_lr_upd);
+    if (e->d_lr_meta) (void)hipFree(e->d_lr_meta);
     if (e->d_cl_cnt) (void)hipFree(e->d_cl_cnt);
     if (e->d_prof) (void)hipFree(e->d_prof);
     if (e->d_zig) (void)hipFree(e->d_zig);
@@ -781,6 +792,69 @@ __global__ __launch_bounds__(256) void lr_broadcast_kernel(const KParams P, cons
     }
 }
 
+// host threads worth starting: the logical CPUs, capped by the cgroup CPU quota (a container may show 256 CPUs and be allowed 16
+// CPUs' worth of time: more runnable threads than that are only throttled)
+static unsigned usable_host_threads() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        double per = 0.0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0.0) {
+            const double cpus = atof(q) / per;
+            if (cpus >= 1.0 && cpus < (double)n) n = (unsigned)(cpus + 0.5);
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+// An estimator round's updates, packed on the host: per pending chain `rows` = 4 + rmax vectors of dpad doubles (sigma, 1/sigma,
+// mean, mu_lr, eigenvectors) and 2 x rmax eigenvalue scales; meta[i] = {chain, n_eig, ok}.  One block per pending chain.
+__global__ __launch_bounds__(256) void lr_scatter_kernel(const KParams P, const uint64_t* meta, const double* stage, const double* vals2,
+                                                        uint64_t rmax, uint64_t n) {
+    const uint64_t dp = P.dpad, rows = 4 + rmax;
+    for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint64_t c = meta[3 * i], n_eig = meta[3 * i + 1];
+        if (!meta[3 * i + 2]) continue;
+        const double* st = stage + (size_t)i * rows * dp;
+        double* pv = P.pvec + (size_t)c * NUM_PSLOT * dp;
+        double* lv = P.lrvec + (size_t)c * (1 + P.lr_rmax) * dp;
+        double* lw = P.lrval + (size_t)c * 2 * P.lr_rmax;
+        for (uint64_t j = threadIdx.x; j < dp; j += blockDim.x) {
+            pv[(size_t)P_SIG * dp + j] = st[j];
+            pv[(size_t)P_ISIG * dp + j] = st[dp + j];
+            pv[(size_t)P_MU * dp + j] = st[2 * dp + j];
+            lv[j] = st[3 * dp + j];
+        }
+        for (uint64_t j = threadIdx.x; j < n_eig * dp; j += blockDim.x) lv[dp + j] = st[4 * dp + j];
+        for (uint64_t j = threadIdx.x; j < n_eig; j += blockDim.x) { lw[j] = vals2[i * 2 * rmax + j]; lw[P.lr_rmax + j] = vals2[i * 2 * rmax + rmax + j]; }
+    }
+}
+// lr_stage_update's checks and derived values, written into a packed row block instead of the device
+static bool lr_pack_update(nm_engine* e, ChainScalars& q, uint64_t n_eig, const double* stds, const double* mean, const double* vals,
+                           const double* vecs, const double* mu_lr, double* st /*[4 + n_eig][dpad]*/, double* v2 /*[2][rmax]*/, uint64_t rmax) {
+    const uint64_t dim = e->dim, dp = e->P.dpad;
+    auto finite = [](const double* a, uint64_t n) { for (uint64_t i = 0; i < n; ++i) if (!std::isfinite(a[i])) return false; return true; };
+    q.lr_upd_ok = 0; q.lr_upd_rank = 0; q.lr_upd_logdet = 0.0;
+    if (!finite(stds, dim) || !finite(mean, dim) || !finite(vals, n_eig) || !finite(vecs, n_eig * dim)) return false;
+    memset(st, 0, (4 + n_eig) * dp * sizeof(double));
+    for (uint64_t i = 0; i < dim; ++i) { st[i] = stds[i]; st[dp + i] = 1.0 / stds[i]; st[2 * dp + i] = mean[i]; st[3 * dp + i] = mu_lr[i]; }
+    for (uint64_t k = 0; k < n_eig; ++k) memcpy(st + (4 + k) * dp, vecs + k * dim, dim * sizeof(double));
+    double ld = -0.0;                                                                  // InnerMatrix::new (low_rank.rs:55-92)
+    for (uint64_t k = 0; k < n_eig; ++k) { ld += -0.5 * dlog(vals[k]); v2[k] = std::sqrt(vals[k]); v2[rmax + k] = 1.0 / v2[k]; }
+    q.lr_upd_ok = 1; q.lr_upd_rank = n_eig; q.lr_upd_logdet = ld;
+    return true;
+}
+template <class T>
+static hipError_t grow(T** p, size_t* have, size_t want, bool pinned_host) {
+    if (*have >= want) return hipSuccess;
+    if (*p) { if (pinned_host) (void)hipHostFree(*p); else (void)hipFree(*p); *p = nullptr; *have = 0; }
+    const size_t sz = want + want / 4;
+    hipError_t er = pinned_host ? hipHostMalloc((void**)p, sz, hipHostMallocDefault) : hipMalloc((void**)p, sz);
+    if (er == hipSuccess) *have = sz;
+    return er;
+}
+
 extern "C" nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_estimator_fn fn, void* ctx, uint64_t n_threads) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
     if (!e->lr) return fail(NM_ERR_STATE, "the engine was not created with adaptation = NM_ADAPT_LOW_RANK");
@@ -790,6 +864,12 @@ extern "C" nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_es
     return NM_OK;
 }
 extern "C" uint64_t nm_engine_lowrank_max_rank(const nm_engine* e) { return e ? e->lr_rmax : 0; }
+// Development aid (not part of include/nuts_amd.h): seconds spent in the estimator rounds so far: total, window download,
+// estimator threads, upload + scatter; rounds; estimator calls
+extern "C" void nm_debug_lowrank_timing(const nm_engine* e, double out[6]) {
+    out[0] = e->lr_host_seconds; out[1] = e->lr_download_seconds; out[2] = e->lr_estimator_seconds; out[3] = e->lr_upload_seconds;
+    out[4] = (double)e->lr_rounds; out[5] = (double)e->lr_updates;
+}
 
 extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, uint64_t n_eig, const double* h_stds, const double* h_mean,
                                              const double* h_vals, const double* h_vecs, const double* h_mu_lr) {
@@ -927,23 +1007,47 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
             if (sc[c].status == NM_CHAIN_OK && sc[c].lr_pending == LR_WAIT_HOST) pend.push_back(c);
         if (pend.empty()) break;
         const auto t0 = std::chrono::steady_clock::now();
-        unsigned nt = (unsigned)(e->lr_threads ? e->lr_threads : std::thread::hardware_concurrency());
+        unsigned nt = (unsigned)(e->lr_threads ? e->lr_threads : usable_host_threads());
         if (nt == 0) nt = 1;
         if (nt > pend.size()) nt = (unsigned)pend.size();
+        // 1. every pending chain's window -> pinned host memory: a batch of asynchronous copies, one wait
+        const size_t np = pend.size();
+        std::vector<size_t> woff(np + 1, 0);
+        uint64_t rmax = 1;
+        for (size_t i = 0; i < np; ++i) {
+            const uint64_t n = sc[pend[i]].lr_len;
+            woff[i + 1] = woff[i] + (size_t)n * 2 * dim;
+            rmax = std::max<uint64_t>(rmax, std::min<uint64_t>(dim, 2 * n));
+        }
+        rmax = std::min<uint64_t>(rmax, e->lr_rmax);
+        const uint64_t dp = e->P.dpad, rows = 4 + rmax;
+        HIP_TRY(grow(&e->h_lr_win, &e->h_lr_win_bytes, woff[np] * sizeof(double), true));
+        HIP_TRY(grow(&e->h_lr_upd, &e->h_lr_upd_bytes, np * (rows * dp + 2 * rmax) * sizeof(double), true));
+        HIP_TRY(grow(&e->d_lr_upd, &e->d_lr_upd_bytes, np * (rows * dp + 2 * rmax) * sizeof(double), false));
+        HIP_TRY(grow(&e->d_lr_meta, &e->d_lr_meta_bytes, np * 3 * sizeof(uint64_t), false));
+        for (size_t i = 0; i < np; ++i) {
+            const ChainScalars& q = sc[pend[i]];
+            HIP_TRY(hipMemcpyAsync(e->h_lr_win + woff[i], e->d_lrwin + ((size_t)pend[i] * e->lr_cap + q.lr_start) * 2 * dim,
+                                   (size_t)q.lr_len * 2 * dim * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const auto t1 = std::chrono::steady_clock::now();
+        // 2. the estimator, one chain per task, on the host threads; results packed for one upload
+        std::vector<uint64_t> meta(np * 3, 0);
+        double* const upd_vec = e->h_lr_upd;
+        double* const upd_val = e->h_lr_upd + np * rows * dp;
         std::atomic<size_t> next{0};
-        std::atomic<int> hip_failed{0};
+        std::atomic<int> too_wide{0};
         auto work = [&]() {
-            (void)hipSetDevice(e->device);
-            std::vector<double> win, draws, grads, stds(dim), mean(dim), mu(dim), vals, vecs;
+            std::vector<double> draws, grads, stds(dim), mean(dim), mu(dim), vals, vecs;
             for (;;) {
                 const size_t i = next.fetch_add(1);
-                if (i >= pend.size()) break;
+                if (i >= np) break;
                 const uint64_t c = pend[i];
                 ChainScalars& q = sc[c];
                 const uint64_t n = q.lr_len;
-                win.resize(n * 2 * dim); draws.resize(n * dim); grads.resize(n * dim);
-                if (hipMemcpy(win.data(), e->d_lrwin + ((size_t)c * e->lr_cap + q.lr_start) * 2 * dim, n * 2 * dim * 8,
-                              hipMemcpyDeviceToHost) != hipSuccess) { hip_failed++; continue; }
+                const double* win = e->h_lr_win + woff[i];
+                draws.resize(n * dim); grads.resize(n * dim);
                 for (uint64_t r = 0; r < n; ++r) {
                     memcpy(&draws[r * dim], &win[(2 * r) * dim], dim * 8);
                     memcpy(&grads[r * dim], &win[(2 * r + 1) * dim], dim * 8);
@@ -954,11 +1058,11 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
                 const int rc = e->lr_estimator(e->lr_estimator_ctx, dim, n, draws.data(), grads.data(), e->s.lr_gamma,
                                                e->s.lr_eigval_cutoff, stds.data(), mean.data(), &n_eig, vals.data(), vecs.data(), mu.data());
                 q.lr_upd_ok = 0; q.lr_upd_rank = 0; q.lr_upd_logdet = 0.0;
+                meta[3 * i] = c;
                 if (rc == 0) {
-                    if (n_eig > e->lr_rmax) { hip_failed += 1000; continue; }
-                    hipError_t er;
-                    (void)lr_stage_update(e, c, q, n_eig, stds.data(), mean.data(), vals.data(), vecs.data(), mu.data(), &er);
-                    if (er != hipSuccess) { hip_failed++; continue; }
+                    if (n_eig > rmax) { too_wide++; continue; }
+                    if (lr_pack_update(e, q, n_eig, stds.data(), mean.data(), vals.data(), vecs.data(), mu.data(),
+                                       upd_vec + i * rows * dp, upd_val + i * 2 * rmax, rmax)) { meta[3 * i + 1] = n_eig; meta[3 * i + 2] = 1; }
                 }
                 q.lr_pending = LR_ANSWERED;
             }
@@ -967,11 +1071,22 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
         for (unsigned t = 0; t + 1 < nt; ++t) th.emplace_back(work);
         work();
         for (auto& t : th) t.join();
-        e->lr_updates += pend.size();
+        const auto t2 = std::chrono::steady_clock::now();
+        e->lr_updates += np;
         e->lr_rounds += 1;
-        e->lr_host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (hip_failed.load() >= 1000) return fail(NM_ERR_UNSUPPORTED, "the estimator returned more eigenvectors than lowrank_max_rank %llu", (unsigned long long)e->lr_rmax);
-        if (hip_failed.load()) return fail(NM_ERR_HIP, "window download / transformation upload failed for %d chain(s)", hip_failed.load());
+        if (too_wide.load()) return fail(NM_ERR_UNSUPPORTED, "the estimator returned more eigenvectors than lowrank_max_rank %llu", (unsigned long long)e->lr_rmax);
+        // 3. one upload, one scatter into the chains' slots
+        HIP_TRY(hipMemcpyAsync(e->d_lr_upd, e->h_lr_upd, np * (rows * dp + 2 * rmax) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_lr_meta, meta.data(), np * 3 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(lr_scatter_kernel, dim3((unsigned)std::min<size_t>(np, 2048)), dim3(256), 0, e->stream, P, (const uint64_t*)e->d_lr_meta,
+                           (const double*)e->d_lr_upd, (const double*)(e->d_lr_upd + np * rows * dp), rmax, (uint64_t)np);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const auto t3 = std::chrono::steady_clock::now();
+        e->lr_host_seconds += std::chrono::duration<double>(t3 - t0).count();
+        e->lr_download_seconds += std::chrono::duration<double>(t1 - t0).count();
+        e->lr_estimator_seconds += std::chrono::duration<double>(t2 - t1).count();
+        e->lr_upload_seconds += std::chrono::duration<double>(t3 - t2).count();
         HIP_TRY(hipMemcpy(e->d_sc, sc.data(), nc * sizeof(ChainScalars), hipMemcpyHostToDevice));
     }
     e->draws_total += n_draws;
@@ -1094,6 +1209,21 @@ extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, doub
     nm_draw_outputs h = {};
     h.d_positions = h_positions; h.d_stats = h_stats;
     return nm_engine_draw_ex_to_host(e, n_draws, &h);
+}
+
+// Development aid (not part of include/nuts_amd.h): the XCD (HW_REG_XCC_ID) each block of a small grid ran on — the placement
+// the cluster kernels' block -> (cluster, member) map is built on
+__global__ void xcc_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = (unsigned)xcc_id(); }
+extern "C" nm_status nm_debug_xcc_ids(unsigned* h_out, unsigned n_blocks) {
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    unsigned* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n_blocks * sizeof(unsigned)));
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_blocks), dim3(64), 0, nullptr, d);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, d, n_blocks * sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return NM_OK;
 }
 
 // Development aid (not part of include/nuts_amd.h): cycle counters of NM_PROF builds; reading clears them.

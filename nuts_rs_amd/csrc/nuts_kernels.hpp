@@ -2532,6 +2532,26 @@ constexpr int draw_min_waves() {
     return W != 1 ? 1 : DPL == 2 ? NM_OCC_DPL2 : DPL == 4 ? NM_OCC_DPL4 : DPL == 8 ? NM_OCC_DPL8 : 1;
 }
 
+#if NM_CLUSTER_MODE
+// Start of a cluster-mode kernel: the members of a chain tell each other which XCD they run on (one exchange with the safe
+// release / acquire protocol); if it is the same one, the exchanges of the launch skip the cache maintenance.  Returns the
+// link to start from (epoch 1).
+template <int W>
+NM_DEV ClusterLink cluster_start(const KParams& P, double* red_lds, unsigned cl_k, unsigned cl_member, uint64_t cl_id) {
+    ClusterLink L;
+    L.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; L.cnt = P.cl_cnt + cl_id;
+    L.k = (int)cl_k; L.member = (int)cl_member; L.epoch = 0ull; L.same_xcd = 0;
+    Reducer<W> r;
+    r.init(red_lds);
+    r.cl = &L;
+    const double x = (double)xcc_id();
+    double v[2] = {x, x * x};
+    r.template cluster_combine<2>(v);
+    L.same_xcd = ((double)cl_k * v[1] == v[0] * v[0]) ? 1 : 0;       // sum of squares = square of the sum / k  <=>  all equal
+    return L;
+}
+#endif
+
 template <int DPL, int W, class Dens>
 __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
@@ -2541,11 +2561,10 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
     // the members of a chain share an L2 (a performance matter only: the exchange is agent-scope)
     const unsigned cl_k = (unsigned)P.cl_k, cl_member = (blockIdx.x / 8u) % cl_k;
     const uint64_t cl_id = (uint64_t)(blockIdx.x / (8u * cl_k)) * 8u + blockIdx.x % 8u, n_clusters = gridDim.x / cl_k;
-    unsigned long long cl_epoch = 0ull;
+    ClusterLink cl_link = cluster_start<W>(P, sh.red, cl_k, cl_member, cl_id);
     for (uint64_t chain = cl_id; chain < P.n_chains; chain += n_clusters) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
-        C.link.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; C.link.cnt = P.cl_cnt + cl_id;
-        C.link.k = (int)cl_k; C.link.member = (int)cl_member; C.link.epoch = cl_epoch;
+        C.link = cl_link;
         const uint64_t sci = chain * cl_k + cl_member;
         ctx_begin(C, sh, sci, blockIdx.x);
         if (C.sc.status == NM_CHAIN_OK) {
@@ -2560,7 +2579,7 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
             }
         }
         ctx_end(C, sci);
-        cl_epoch = C.link.epoch;
+        cl_link.epoch = C.link.epoch;
         __syncthreads();
     }
     return;
@@ -2605,13 +2624,12 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
 #if NM_CLUSTER_MODE
     const unsigned cl_k = (unsigned)P.cl_k, cl_member = (blockIdx.x / 8u) % cl_k;
     const uint64_t cl_id = (uint64_t)(blockIdx.x / (8u * cl_k)) * 8u + blockIdx.x % 8u, n_clusters = gridDim.x / cl_k;
-    unsigned long long cl_epoch = 0ull;
+    ClusterLink cl_link = cluster_start<W>(P, sh.red, cl_k, cl_member, cl_id);
     for (uint64_t x0_chain = cl_id; x0_chain < P.n_chains; x0_chain += n_clusters) {
         if (P.init_mask && !P.init_mask[x0_chain]) continue;
         const uint64_t chain = x0_chain * cl_k + cl_member;                 // the sub-chain: this member's vectors and scalars
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
-        C.link.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; C.link.cnt = P.cl_cnt + cl_id;
-        C.link.k = (int)cl_k; C.link.member = (int)cl_member; C.link.epoch = cl_epoch;
+        C.link = cl_link;
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
 #else
@@ -2684,7 +2702,7 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         sc.status = status;
         ctx_end(C, chain);
 #if NM_CLUSTER_MODE
-        cl_epoch = C.link.epoch;
+        cl_link.epoch = C.link.epoch;
 #endif
         __syncthreads();
     }

@@ -38,6 +38,9 @@ def main():
     _, st_w = b.draw_many(a.tune, positions=False)
     t_warm = time.time() - t
     c_w = b.counters()
+    import ctypes as C
+    tm = (C.c_double * 6)()
+    N.load_library().nm_debug_lowrank_timing(b._h, tm)
     b.reset_counters()
     t = time.time()
     pos, st = b.draw_many(a.draws)
@@ -50,6 +53,8 @@ def main():
         "config": f"LowRankNutsSettings, full-precision normal dim {a.dim} (4 strong directions) x {a.chains} chains, num_tune {a.tune}",
         "warmup_wall_s": t_warm, "warmup_kernel_s": c_w["kernel_ms"] * 1e-3, "warmup_launches": c_w["kernel_launches"],
         "warmup_host_share": 1.0 - c_w["kernel_ms"] * 1e-3 / t_warm,
+        "estimator_rounds_s": {"total": tm[0], "window_download": tm[1], "estimator_threads": tm[2], "upload_scatter": tm[3],
+                               "rounds": int(tm[4]), "estimator_calls": int(tm[5])},
         "updates_per_chain": float((st_w["transformation_update_id"] >= 0).sum() / a.chains),
         "n_eig_median": float(np.median(n_eig)), "n_eig_max": int(n_eig.max()),
         "sampling_leapfrogs_per_s": c_s["total_leapfrogs"] / t_s, "sampling_leapfrogs_per_draw": float(st["n_steps"].mean()),
