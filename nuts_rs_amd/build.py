@@ -47,7 +47,8 @@ def build(force=False, verbose=False, extra_flags=()):
     def compile_unit(u):
         src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o").replace(".cpp", ".o"))
         if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
+            host_only = ["-mavx2", "-mfma"] if u.endswith(".cpp") else []     # the host estimator's dense loops (no contraction: -ffp-contract=off)
+            cmd = [hipcc] + FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
