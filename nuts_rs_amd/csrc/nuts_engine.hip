@@ -22,6 +22,7 @@ using namespace nm;
 // POD mirror of nm::tile::TileMats (nuts_tile.hpp) — that header switches the whole TU to tile mode, so it is not included here.
 namespace nm { namespace tile { struct TileMats { const double *ut, *u, *p; int dim, rank, dim_kp, rank_kp, dim_st, rank_st; }; } }
 namespace nm { hipError_t launch_tile_mvn_prec(int dpl, int query, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream, int* occ); }
+namespace nm { hipError_t launch_tile_mvn_diag(int dpl, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream); }
 
 #include "zig_tables.hpp"
 // rand_distr's ZIG_NORM_X then ZIG_NORM_F (257 + 257 fixed constants; tools/gen_ziggurat_tables.py)
@@ -299,6 +300,21 @@ static nm_status ensure_device(int64_t device) {
     return NM_OK;
 }
 
+// a matrix in the matrix-core kernels' A-operand order (nuts_tile.hpp TileMats): [stripes][kpairs][64 lanes][2]
+template <class F>
+static std::vector<double> pack_mfma_operand(uint64_t R, uint64_t K, F&& elem) {
+    const uint64_t st = (R + 15) / 16, kp = (K + 7) / 8;
+    std::vector<double> out(st * kp * 128, 0.0);
+    for (uint64_t s_ = 0; s_ < st; ++s_)
+        for (uint64_t q = 0; q < kp; ++q)
+            for (uint64_t l = 0; l < 64; ++l)
+                for (uint64_t j = 0; j < 2; ++j) {
+                    const uint64_t row = 16 * s_ + (l & 15), k = 8 * q + 4 * j + (l >> 4);
+                    out[((s_ * kp + q) * 64 + l) * 2 + j] = (row < R && k < K) ? elem(row, k) : 0.0;
+                }
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------
@@ -355,6 +371,7 @@ struct nm_engine {
     double lr_download_seconds = 0.0, lr_estimator_seconds = 0.0, lr_upload_seconds = 0.0;   // its parts
     // shared transformation + full-precision normal: 16 chains per block, products on the matrix cores (nuts_tile.hpp)
     bool tile_active = false;
+    bool tile_diag_active = false;          // DiagNutsSettings on the full-precision normal: P x on the matrix cores, per-chain mass matrices
     tile::TileMats tile_mats = {};
     double *d_tile_ut = nullptr, *d_tile_u = nullptr, *d_tile_p = nullptr;
     unsigned tile_grid = 0;
@@ -539,7 +556,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         e->tile_grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(cus > 0 ? cus : 1));
     }
     size_t scratch_slots = e->n_waves > e->group_grid ? e->n_waves : e->group_grid;
-    if (lr && logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1) scratch_slots = std::max<size_t>(scratch_slots, (size_t)e->tile_grid * 16);
+    if (logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1) scratch_slots = std::max<size_t>(scratch_slots, (size_t)e->tile_grid * 16);
     const size_t svec_bytes = scratch_slots * nsslot * dpad * sizeof(double);
     E_TRY(hipMalloc(&e->d_pvec, pvec_bytes));
     E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));
@@ -558,6 +575,19 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
     if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     if (lr && logp->kind == NM_LOGP_MVN_PREC) e->h_params.assign(logp->h_params, logp->h_params + logp->n_params);
+    // DiagNutsSettings on the full-precision normal: the density's P is shared by all chains whatever their mass matrices are,
+    // so P x can run on the matrix cores 16 chains at a time (nuts_tile_diag_kernel) — same bits as the one-chain GEMV.
+    // chain_tiles: 0 = when there are enough chains to fill the blocks, 1 = never, 2 = whenever it applies
+    if (!lr && !kin && cl_k == 1 && logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1 && wv == 1 && (dpl == 2 || dpl == 4) &&
+        logp->dim <= 256 && logp->dim % 8 == 0 && e->group_grid == 0 && (cfg.chain_tiles == 2 || n_chains >= 256)) {
+        const uint64_t dim = logp->dim;
+        const double* P_ = logp->h_params;
+        const std::vector<double> pp = pack_mfma_operand(dim, dim, [&](uint64_t d, uint64_t j) { return P_[j * dim + d]; });
+        E_TRY(hipMalloc(&e->d_tile_p, pp.size() * 8));
+        E_TRY(hipMemcpy(e->d_tile_p, pp.data(), pp.size() * 8, hipMemcpyHostToDevice));
+        e->tile_mats = {nullptr, nullptr, e->d_tile_p, (int)dim, 0, (int)((dim + 7) / 8), 0, (int)((dim + 15) / 16), 0};
+        e->tile_diag_active = true;
+    }
     if (lr) {   // eigenvector slots, eigenvalue arrays and the window of draws / gradients of every chain
         // the estimator's rank is <= min(dim, 2 n_draws); a transformation given from outside may have any rank <= dim
         const uint64_t most = s.freeze_transform ? logp->dim : std::min<uint64_t>(logp->dim, 2 * (s.num_tune + 1));
@@ -1119,6 +1149,9 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
         // a launch that starts inside the warm-up takes the kernel with the adaptation compiled in
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, e->draws_launched < e->s.num_tune ? K_GROUP_TUNE : K_GROUP_DRAW, P, e->group_grid, e->stream, nullptr, e->module_launch));
         e->group_launches += 1;
+    } else if (e->tile_diag_active) {
+        HIP_TRY(launch_tile_mvn_diag(e->dpl, P, e->tile_mats, e->tile_grid, e->stream));
+        e->tile_launches += 1;
     } else
         HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_DRAW, P, e->n_waves, e->stream, nullptr, e->module_launch, e->variant));
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -1255,6 +1288,8 @@ static nm_status read_slot(nm_engine* e, int slot, double* h_out) {
     return NM_OK;
 }
 extern "C" uint64_t nm_engine_blocks_per_chain(const nm_engine* e) { return e ? e->cl_k : 0; }
+// Development aid (not part of include/nuts_amd.h): any persistent slot of every chain, [n_chains][dim]
+extern "C" nm_status nm_debug_read_slot(nm_engine* e, int slot, double* h_out) { return slot >= 0 && slot < NUM_PSLOT ? read_slot(e, slot, h_out) : NM_ERR_INVALID_ARG; }
 extern "C" nm_status nm_engine_get_positions(nm_engine* e, double* h_x) { return read_slot(e, P_X, h_x); }
 extern "C" nm_status nm_engine_get_gradients(nm_engine* e, double* h_gx) { return read_slot(e, P_GX, h_gx); }
 extern "C" nm_status nm_engine_get_mass_matrix(nm_engine* e, double* h_stds, double* h_mean) {

@@ -237,18 +237,27 @@ NM_DEV double2 buf_load2(rsrc_t r, int voff, int soff) {
 #define NM_NT_STORES 1
 #endif
 constexpr int NM_AUX_NT = NM_NT_STORES ? 2 : 0;
+// The data registers of a 128-bit buffer store must not be overwritten right behind it.  LLVM's hazard recogniser knows this
+// hazard ("VMEM store of more than 64 bits, then a VALU write of its data VGPRs": 1 wait state) but exempts MUBUF stores whose
+// soffset is an SGPR — the addressing used here — and gfx950 does show it: `buffer_store_dwordx4 v[4:7], .., s8 offen` directly
+// followed by `v_fma_f64 v[4:5], ..` stored the fma's result in lanes 12-15 of every row (first seen as a background variance
+// estimator that came out of set_position as 1e-9 instead of 0 in a few chains; tools/probes/determinism2.py).  Every such
+// store is therefore followed by an `s_nop 1` that names its data registers as inputs: they stay live for two wait states
+// (tools/check_store_hazard.py scans the generated assembly for unguarded instances).
 template <int AUX>
 NM_DEV void buf_store2_aux(rsrc_t r, int voff, int soff, double a, double b) {
     v4u q;
     q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
     q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
     __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, AUX);
+    asm volatile("s_nop 1" ::"v"(q));     // the store-data hazard above
 }
 NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
     v4u q;
     q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
     q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
     __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, 0);
+    asm volatile("s_nop 1" ::"v"(q));     // the store-data hazard above
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1328,6 +1337,11 @@ NM_DEV void commit_mass_matrix(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& sig, 
     C.storeP(mu, P_MU);
     C.store(sig, C.lsig);
     C.store(mu, C.lmu);
+#if NM_TILE_MODE
+    // the matrix-core kernel of DiagNutsSettings reads sigma / mu of the leapfrog straight from these slots (generic loads of a
+    // line that is hot in the vector L1): make the new values the ones every later load sees
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#endif
     C.sc.mm_logdet = sum_ln_tile(C, isig);
     C.sc.mm_id += 1;
 }

@@ -165,6 +165,54 @@ NM_DEV void density_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y) {
     if (y) get_col(T.sbuf, w, *y);
 }
 
+// y = P x as the ONLY rendezvous of the block (the per-chain diagonal transformation, nuts_tile_diag_kernel): with `may_exit`
+// the call returns true — for every wavefront alike — when all 16 chains have finished the current draw.
+template <int DPL>
+NM_DEV bool density_only_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y, bool may_exit) {
+    TileShared& T = *X.T;
+    const int w = X.c;
+    if (x) put_col(T.zin, w, *x);
+    tile_barrier();
+    if (may_exit) {                                   // only ever evaluated true when all 16 are in their waiting loops
+        const int done = __builtin_amdgcn_readfirstlane(*(volatile int*)&T.done);
+        if (done == TC * (X.draws_done + 1)) return true;
+    }
+    for (int s = w; s < X.M.dim_st; s += TC) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = gemm_stripe(X.M.p, s, X.M.dim_kp, T.zin, acc);
+        store_stripe(T.sbuf, s, acc);
+    }
+    tile_barrier();
+    if (y) get_col(T.sbuf, w, *y);
+    return false;
+}
+
+// The same density for chains that keep their OWN diagonal transformation (DiagNutsSettings: every chain adapts alone): the
+// precision matrix belongs to the density, so all chains share it whatever their mass matrices are.  Bit for bit the one-chain
+// MvnPrec (its y_d is the same sequential fma chain over j).
+struct TileMvnDiag {
+    static constexpr bool kNeedsLdsVector = false;
+    TileRef* X = nullptr;
+    template <int W>
+    NM_DEV void init(const double*, int, Reducer<W>&) {}
+    NM_DEV void set_lds(double*) {}
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
+        Tile<DPL> xs, y;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) xs.a[k] = elem_index<W>(k) < dim ? x.a[k] : 0.0;
+        (void)density_only_round(*X, &xs, &y, false);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const bool valid = elem_index<W>(k) < dim;
+            gx.a[k] = valid ? -y.a[k] : 0.0;
+            acc = acc + (valid ? x.a[k] * y.a[k] : 0.0);
+        }
+        return -0.5 * R.sum(acc);
+    }
+};
+
 // The full-precision normal (MvnPrec of nuts_kernels.hpp: logp = -x'Px/2, grad = -Px, y_d = sum_j fma(P[j][d], x_j, .),
 // j ascending) with the product on the matrix cores; the low-rank products of LrWrap go through the same block.
 struct TileMvnPrec {
@@ -254,6 +302,44 @@ __global__ __launch_bounds__(64 * TC) void nuts_tile_draw_kernel(const KParams P
                 density_round<DPL>(X, (const Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 (void)apply_round<DPL>(X, 0, (Tile<DPL>*)nullptr, false);
             }
+            draws_done += 1;
+        }
+        if (valid) ctx_end(C, chain);
+    }
+}
+
+// The draw kernel for DiagNutsSettings on the full-precision normal: the same 16 chains per block, each with its own adapting
+// diagonal transformation (sigma, mu are read from the chain's persistent slots: 16 x 4 KiB would not fit beside the column
+// tiles), ONE rendezvous per density evaluation.  Whatever evaluates the density — leapfrogs, the step-size search inside the
+// adaptation, the recomputation of the chosen point — is a round; a chain that has finished its draw attends with an idle column.
+template <int DPL, class Dens>
+__global__ __launch_bounds__(64 * TC) void nuts_tile_diag_kernel(const KParams P, const TileMats M) {
+    __shared__ BlockShared<DPL, 1, Dens> sh[TC];
+    __shared__ TileShared T;
+    dm_init_lds();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x == 0) T.done = 0;
+    int draws_done = 0;
+    const uint64_t n_tiles = (P.n_chains + TC - 1) / TC;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < TD * TC; i += 64 * TC) { T.zin[i] = 0.0; T.sbuf[i] = 0.0; }
+        __syncthreads();
+        const uint64_t chain = tile * TC + (uint64_t)w;
+        const bool valid = chain < P.n_chains;
+        ChainCtx<DPL, 1, Dens> C(P, sh[w].sc[0]);
+        TileRef X{&T, M, w, draws_done};
+        if (valid) {
+            ctx_begin(C, sh[w], chain, (uint64_t)blockIdx.x * TC + (uint64_t)w);
+            C.lsig = C.slot(P_SIG); C.lmu = C.slot(P_MU);      // the chain's own mass matrix, straight from its slots
+            C.dens.X = &X;
+        }
+        bool ok = valid && C.sc.status == NM_CHAIN_OK;
+        for (uint64_t t = 0; t < P.n_draws; ++t) {
+            X.draws_done = draws_done;
+            if (ok) { chain_draw(C, chain, t); ok = C.sc.status == NM_CHAIN_OK; }
+            if (lane_id() == 0) atomicAdd(&T.done, 1);
+            while (!density_only_round<DPL>(X, (const Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, true)) {}
             draws_done += 1;
         }
         if (valid) ctx_end(C, chain);

@@ -618,3 +618,34 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
     pos_o, st_o, _, failed = run_oracle(oracle, s, logp, 4, x0[:4], total, gpu_threads=tpc, n_threads=4)
     assert failed == 0
     assert_bit_exact(pos_g, st_g, pos_o, st_o)
+
+
+@pytest.mark.parametrize("dens,dim,n", [("funnel", 101, 4200), ("iid", 256, 2100), ("mvn", 64, 1300)])
+def test_late_blocks_match_oracle_and_are_deterministic(oracle, dens, dim, n):
+    """Chains handled by blocks that start late in a big grid (index >= 1024) against the oracle, and two runs against each other.
+    (These kernels cap their registers and spill; a 128-bit buffer store directly followed by a write of its data registers
+    corrupted single lanes there — nuts_kernels.hpp buf_store2 — visible as chains >= 1024 whose first mass-matrix update came
+    out different from run to run.)"""
+    s = N.DiagNutsSettings(num_chains=n, seed=77, num_tune=400)
+    if dens == "mvn":
+        a = np.random.default_rng(5).normal(size=(dim, dim))
+        logp = N.LogpSpec.mvn_precision((a @ a.T / dim + np.eye(dim) + (a @ a.T / dim + np.eye(dim)).T) / 2)
+    else:
+        logp = N.LogpSpec.funnel(dim) if dens == "funnel" else N.LogpSpec.iid_normal(dim, 3.0)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    draws = 16
+    runs = []
+    for _ in range(2):
+        b = N.ChainBatch(s, logp, n, lane_groups=1, chain_tiles=1)
+        b.set_position(x0)
+        pos, st = b.draw_many(draws)
+        runs.append((pos, st, b.mass_matrix()[0], b.threads_per_chain()))
+        b.close()
+    assert (runs[0][0].view(np.uint64) == runs[1][0].view(np.uint64)).all()
+    assert (runs[0][2].view(np.uint64) == runs[1][2].view(np.uint64)).all()
+    picks = [0, 1023] + list(range(1024, 1040)) + list(range(n - 8, n))
+    for c in picks:
+        pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(runs[0][3]), 1,
+                                            x0[c:c + 1], draws, chain_offset=c, n_threads=1)
+        assert failed == 0
+        assert_bit_exact(runs[0][0][:, c:c + 1], runs[0][1][:, c:c + 1], pos_o, st_o)

@@ -1,6 +1,6 @@
 """Throughput and tree statistics of BASELINE.json's other configurations on one GPU (K1 for scale).
 
-  python tools/bench_configs.py [k3|k4|k5|k1|all] [--draws N] [--chains C] [--lane-groups 0|1|2]
+  python tools/bench_configs.py [k3|k4|k5|k1|all] [--draws N] [--chains C] [--lane-groups 0|1|2] [--chain-tiles 0|1|2]
 
 Prints one JSON line per configuration: M1 = leapfrog-steps*dims/s and M2 = draws/s/chain for the post-warm-up
 draws, depth histogram, divergence rate, and the "lane utilisation" SURVEY asks for on the ragged config
@@ -28,7 +28,7 @@ def _k5_precision(d):
 CONFIGS = {
     "k1": dict(name="K1 iid N(3,1) dim 10", logp=lambda: N.LogpSpec.iid_normal(10, 3.0), chains=4, tune=400),
     "k3": dict(name="K3 Neal's funnel dim 101", logp=lambda: N.LogpSpec.funnel(101), chains=8192, tune=400),
-    "k5": dict(name="K5 normal with a full precision matrix dim 256 (per-chain GEMV)", logp=lambda: N.LogpSpec.mvn_precision(_k5_precision(256)),
+    "k5": dict(name="K5 normal with a full precision matrix dim 256, DiagNutsSettings (P x: matrix cores from 256 chains on, else per-chain GEMV)", logp=lambda: N.LogpSpec.mvn_precision(_k5_precision(256)),
                chains=4096, tune=400),
     "s24": dict(name="small chains: diag normal dim 24 (16 lanes per chain)", logp=lambda: N.LogpSpec.diag_normal(np.exp(np.linspace(-1, 1, 24))), chains=32768, tune=400),
     "s48": dict(name="small chains: diag normal dim 48 (32 lanes per chain)", logp=lambda: N.LogpSpec.diag_normal(np.exp(np.linspace(-1, 1, 48))), chains=32768, tune=400),
@@ -37,12 +37,12 @@ CONFIGS = {
 }
 
 
-def run(key, draws, chains=0, lane_groups=0):
+def run(key, draws, chains=0, lane_groups=0, chain_tiles=0):
     cfg = CONFIGS[key]
     logp = cfg["logp"]()
     C, D = chains or cfg["chains"], logp.dim
     s = N.DiagNutsSettings(num_chains=C, seed=20260928, num_tune=cfg["tune"], num_draws=draws)
-    b = N.ChainBatch(s, logp, C, lane_groups=lane_groups)
+    b = N.ChainBatch(s, logp, C, lane_groups=lane_groups, chain_tiles=chain_tiles)
     b.set_position(b.init_positions_uniform())
     t = time.time()
     _, st_w = b.draw_many(cfg["tune"], positions=False)
@@ -62,7 +62,7 @@ def run(key, draws, chains=0, lane_groups=0):
     util = float((st["n_steps"].sum(axis=1) / (C * st["n_steps"].max(axis=1))).mean())
     out = {
         "config": cfg["name"], "chains": C, "dim": D, "draws": draws, "threads_per_chain": b.threads_per_chain(),
-        "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups,
+        "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups, "chain_tiles": chain_tiles, "matrix_core_launches": b.tile_launches(),
         "M1_steps_dims_per_s": steps * D / dt, "M2_draws_per_s_per_chain": draws / dt,
         "leapfrogs_per_s": steps / dt, "kernel_ms": c["kernel_ms"], "warmup_s": t_warm, "warmup_kernel_ms": warm_kernel_ms,
         "group_launches": b.group_launches(),
@@ -82,4 +82,5 @@ if __name__ == "__main__":
     draws = int(sys.argv[sys.argv.index("--draws") + 1]) if "--draws" in sys.argv else 200
     for k in (["k1", "k3", "k4", "k5"] if which == "all" else [which]):
         run(k, draws, chains=int(sys.argv[sys.argv.index("--chains") + 1]) if "--chains" in sys.argv else 0,
-            lane_groups=int(sys.argv[sys.argv.index("--lane-groups") + 1]) if "--lane-groups" in sys.argv else 0)
+            lane_groups=int(sys.argv[sys.argv.index("--lane-groups") + 1]) if "--lane-groups" in sys.argv else 0,
+            chain_tiles=int(sys.argv[sys.argv.index("--chain-tiles") + 1]) if "--chain-tiles" in sys.argv else 0)
