@@ -570,8 +570,9 @@ def test_init_retry_loop_matches_reference_semantics(oracle):
 def test_baseline_configs_first_chains_match_oracle(oracle, config):
     """BASELINE.json's configurations AT THEIR OWN SIZE AND SETTINGS (4096 x 1024 iid normal; funnel 101 x 8192; 8 schools x
     65536 chains on the several-chains-per-wavefront kernel; the full-precision normal 256 x 4096 with the diagonal
-    adaptation): DiagNutsSettings defaults (400 tuning draws) + 50 draws, and chains 0-3 of that very run compared with the
-    oracle draw for draw, bit for bit — positions, tree sizes, step sizes, energies."""
+    adaptation, on the matrix-core kernel): DiagNutsSettings defaults (400 tuning draws) + 50 draws, and chains 0-3, two from the
+    middle and the last two of that very run (late blocks of the grid) compared with the oracle draw for draw, bit for bit —
+    positions, tree sizes, step sizes, energies."""
     if config == "k2":
         logp, C_ = N.LogpSpec.iid_normal(1024, 3.0), 4096
     elif config == "k3":
@@ -590,7 +591,7 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
     x0 = b.init_positions_uniform()
     status, _ = b.init_with_retries(x0)
     assert (status == 0).all()
-    # the first four chains' results only: [draws][4][dim] device buffers, the rest of the batch records nothing
+    sel = [0, 1, 2, 3, C_ // 2, C_ // 2 + 1, C_ - 2, C_ - 1]
     import torch
     total = tune + draws
     pos = torch.empty((total, C_, logp.dim), dtype=torch.float64, device="cuda") if C_ * logp.dim * total * 8 < 4e9 else None
@@ -598,8 +599,8 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
         st = torch.zeros((total, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()        # the fill runs on torch's stream, the engine on its own: it must not overtake the draws
         b.draw_device(total, pos.data_ptr(), st.data_ptr())
-        pos_g = pos[:, :4].cpu().numpy()
-        st_g = np.frombuffer(st[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(total, 4)
+        pos_g = pos[:, sel].cpu().numpy()
+        st_g = np.frombuffer(st[:, sel].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(total, len(sel))
     else:       # K2 / K3 traces are tens of GB: chunks of 50 draws
         parts = []
         for lo in range(0, total, 50):
@@ -608,16 +609,19 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
             q_ = torch.zeros((n, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()
             b.draw_device(n, p_.data_ptr(), q_.data_ptr())
-            parts.append((p_[:, :4].cpu().numpy(), np.frombuffer(q_[:, :4].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(n, 4)))
+            parts.append((p_[:, sel].cpu().numpy(), np.frombuffer(q_[:, sel].contiguous().cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(n, len(sel))))
             del p_, q_
         pos_g, st_g = np.concatenate([a for a, _ in parts]), np.concatenate([q for _, q in parts])
     tpc = b.threads_per_chain()
     if config == "k4":
         assert b.group_launches() > 0                    # the 65536-chain job runs 8 chains per wavefront
+    if config == "k5_diag":
+        assert b.tile_launches() > 0                     # P x on the matrix cores, per-chain mass matrices
     b.close()
-    pos_o, st_o, _, failed = run_oracle(oracle, s, logp, 4, x0[:4], total, gpu_threads=tpc, n_threads=4)
-    assert failed == 0
-    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    for lo, cnt, col in ((0, 4, 0), (C_ // 2, 2, 4), (C_ - 2, 2, 6)):
+        pos_o, st_o, _, failed = run_oracle(oracle, s, logp, cnt, x0[lo:lo + cnt], total, chain_id_offset=lo, gpu_threads=tpc, n_threads=4)
+        assert failed == 0
+        assert_bit_exact(pos_g[:, col:col + cnt], st_g[:, col:col + cnt], pos_o, st_o)
 
 
 @pytest.mark.parametrize("dens,dim,n", [("funnel", 101, 4200), ("iid", 256, 2100), ("mvn", 64, 1300)])
