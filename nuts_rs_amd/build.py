@@ -13,12 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnuts_amd.so")
-UNITS = ["nuts_engine.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_eight_schools.hip",
-         "kern_mvn_prec.hip", "probe_bw.hip", "lowrank_host.cpp",
-         "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_eight_schools.hip", "kern_lr_mvn_prec.hip",
-         "kern_tile_mvn_prec.hip", "kern_host_cb.hip", "kern_lr_host_cb.hip", "math_seam.hip",
-         "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_eight_schools.hip", "kern_kin_mvn_prec.hip",
-         "kern_kin_host_cb.hip", "kern_cluster.hip"]
+# (the slowest translation units first: the build is as long as its longest chain of jobs on the available cores)
+UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
+         "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_host_cb.hip",
+         "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
+         "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip",
+         "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip",
+         "lowrank_host.cpp"]
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)
