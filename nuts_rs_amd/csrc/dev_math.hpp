@@ -102,13 +102,15 @@ struct ClusterLink {
     unsigned long long epoch;    // exchanges this member has completed since the launch began
     int k, member;
     int same_xcd;                // every member reported the same XCC_ID at kernel start: the XCD's L2 is their coherence point
+    int dead;                    // an exchange timed out (a member never arrived: the device did not hold the whole grid at once?):
+                                 // no further waiting, the chain ends with an error status instead of hanging the device
 };
 // the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
 NM_DEV int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 0xfu); }
 
 template <int W>
 struct Reducer {
-    double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES in cluster mode)
+    double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES + 1 in cluster mode)
     int par;
 #if NM_CLUSTER_MODE
     ClusterLink* cl;
@@ -116,8 +118,12 @@ struct Reducer {
     template <int N>
     NM_DEV void cluster_combine(double (&v)[N]) {
         ClusterLink& L = *cl;
+        if (L.dead) return;
         double* lds_out = buf + 2 * RED_MAX_VALUES * W;
+        constexpr unsigned long long SPIN_LIMIT = 1ull << 27;        // x s_sleep 1 (~64 cycles): several seconds
         if (threadIdx.x == 0) {
+            unsigned long long spins = 0;
+            bool timed_out = false;
             unsigned long long* mine = L.box + ((L.epoch & 1ull) * (unsigned long long)L.k + (unsigned long long)L.member) * RED_MAX_VALUES;
 #pragma unroll
             for (int i = 0; i < N; ++i) __hip_atomic_store(&mine[i], (unsigned long long)d2u(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -128,11 +134,12 @@ struct Reducer {
                 // acquire pair below costs about as much again as the whole leapfrog (measured: 39 -> 22 us at dim 8192)
                 __builtin_amdgcn_s_waitcnt(0);             // the partial sums are in the L2 before the arrival is counted
                 (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (__hip_atomic_load(L.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(L.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1); if (++spins > SPIN_LIMIT) { timed_out = true; break; } }
             } else {
                 (void)__hip_atomic_fetch_add(L.cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                while (__hip_atomic_load(L.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(L.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) { __builtin_amdgcn_s_sleep(1); if (++spins > SPIN_LIMIT) { timed_out = true; break; } }
             }
+            lds_out[RED_MAX_VALUES] = timed_out ? 1.0 : 0.0;
             const unsigned long long* all = L.box + (L.epoch & 1ull) * (unsigned long long)L.k * RED_MAX_VALUES;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -144,6 +151,7 @@ struct Reducer {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = lds_out[i];
+        if (lds_out[RED_MAX_VALUES] != 0.0) L.dead = 1;
         __syncthreads();
         L.epoch += 1ull;
     }

@@ -564,7 +564,7 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     uint32_t rng_cache[RNG_CACHE_WORDS];
     double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
     double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
-    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES : 0)];
+    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES + 1 : 0)];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
     double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
     // Between trees both arrays are free: the momentum refresh uses l1_v as its ChaCha word buffer (hence the 72
@@ -2554,7 +2554,7 @@ template <int W>
 NM_DEV ClusterLink cluster_start(const KParams& P, double* red_lds, unsigned cl_k, unsigned cl_member, uint64_t cl_id) {
     ClusterLink L;
     L.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; L.cnt = P.cl_cnt + cl_id;
-    L.k = (int)cl_k; L.member = (int)cl_member; L.epoch = 0ull; L.same_xcd = 0;
+    L.k = (int)cl_k; L.member = (int)cl_member; L.epoch = 0ull; L.same_xcd = 0; L.dead = 0;
     Reducer<W> r;
     r.init(red_lds);
     r.cl = &L;
@@ -2589,11 +2589,12 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
             }
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
+                if (C.link.dead) C.sc.status = NM_CHAIN_LOGP_FATAL;      // an exchange timed out: stop instead of hanging
                 if (C.sc.status != NM_CHAIN_OK) break;
             }
         }
         ctx_end(C, sci);
-        cl_link.epoch = C.link.epoch;
+        cl_link.epoch = C.link.epoch; cl_link.dead = C.link.dead;
         __syncthreads();
     }
     return;
@@ -2713,10 +2714,13 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
                 }
             }
         }
+#if NM_CLUSTER_MODE
+        if (C.link.dead) status = NM_CHAIN_LOGP_FATAL;
+#endif
         sc.status = status;
         ctx_end(C, chain);
 #if NM_CLUSTER_MODE
-        cl_link.epoch = C.link.epoch;
+        cl_link.epoch = C.link.epoch; cl_link.dead = C.link.dead;
 #endif
         __syncthreads();
     }
