@@ -128,3 +128,24 @@ def test_sampler_over_the_hip_engine_matches_draw_many():
     pr = smp.progress()
     assert all(p.finished_draws == 100 and not p.tuning for p in pr)
     assert [p.total_num_steps for p in pr] == st["n_steps"].sum(axis=0).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", [lambda: N.DiagMclmcSettings(num_tune=50, num_draws=30, num_chains=5, seed=6),
+                                  lambda: N.DiagNutsSettings(num_tune=50, num_draws=30, num_chains=5, seed=6,
+                                                             trajectory_kind=N.KineticEnergyKind.MICROCANONICAL)],
+                         ids=["mclmc", "microcanonical_nuts"])
+def test_sampler_and_sample_helper_with_the_other_integrators(make):
+    """`Sampler` and `sample()` drive the MCLMC sampler and the non-Euclidean trajectory kinds like any other settings."""
+    s = make()
+    logp = N.LogpSpec.iid_normal(21, 3.0)
+    res = N.Sampler(s, logp, chunk_draws=9).wait_timeout(120.0)
+    assert res.kind == "trace"
+    b = N.ChainBatch(s, logp, 5)
+    b.set_position(b.init_positions_uniform())
+    pos, st = b.draw_many(80)
+    b.close()
+    assert (res.trace["positions"].view(np.uint64) == pos.view(np.uint64)).all()
+    assert (res.trace["stats"]["n_steps"] == st["n_steps"]).all()
+    pos_s, st_s = N.sample(s, logp)          # (init_with_retries: attempt 0 is the uniform init_position, like set_position above)
+    assert (pos_s.view(np.uint64) == pos.view(np.uint64)).all() and (st_s["n_steps"] == st["n_steps"]).all()
