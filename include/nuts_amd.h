@@ -113,7 +113,8 @@ typedef struct nm_settings {
      * potential (std_norm_flow / std_norm_grad_flow, src/math/util.rs:507-741).  NM_TRAJ_MICROCANONICAL: the isokinetic ESH
      * leapfrog (esh_momentum_update, src/math/cpu_math.rs:505-551; unit-sphere momentum, the point's kinetic energy is the
      * accumulated change, a divergence is |energy error| >= max_energy_error; needs dim >= 2).  The non-Euclidean kinds run
-     * with the diagonal adaptation on the one-chain-per-block kernels (built-in densities and NM_LOGP_HOST_CALLBACK). */
+     * with either adaptation (DiagNutsSettings / LowRankNutsSettings) on the one-chain-per-block kernels (built-in densities and
+     * NM_LOGP_HOST_CALLBACK). */
     uint64_t trajectory_kind;                /* NM_TRAJ_EUCLIDEAN */
     /* `MclmcSettings` (src/sampler.rs:266-317; experimental upstream): sampler = NM_SAMPLER_MCLMC replaces the NUTS tree by
      * `MclmcChain` (src/mclmc.rs:212-409): per draw round(subsample_frequency L / eps) leapfrogs of the current kinetic kind,

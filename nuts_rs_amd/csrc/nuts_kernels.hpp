@@ -543,6 +543,9 @@ template <class D>
 struct KinWrap : D {};
 template <class D> struct kin_trait { static constexpr bool value = false; };
 template <class D> struct kin_trait<KinWrap<D>> { static constexpr bool value = true; };
+// the kernels with the low-rank transformation carry the kinds too (LowRankNutsSettings::trajectory_kind): they are bound by
+// their matrix traffic, not by code size
+template <class D> struct kin_trait<LrWrap<D>> { static constexpr bool value = true; };
 // densities of the tile kernel (nuts_tile.hpp) set kTile: products with the SHARED matrices (U', U, P) are rendezvous
 // GEMMs of the block's 16 chains on the matrix cores
 template <class D, class = void> struct tile_trait { static constexpr bool value = false; };
@@ -923,6 +926,15 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
             o.v.a[k] = __builtin_fma(s.z.a[k], nes, vh * ec);
         }
     }
+    bool lr_inner = false;
+    if constexpr (lr_trait<Dens>::value) lr_inner = C.sc.lr_has_inner != 0;
+    if (lr_inner) {                               // F = the low-rank transformation (low_rank.rs:286-300), as in the Euclidean leapfrog
+        if constexpr (lr_trait<Dens>::value) {
+            transform_to_x(C, o.z, x);
+            o.logp = C.dens.template eval<DPL, W>(x, gx, C.dim, C.red);
+            transform_to_gz(C, gx, o.g);
+        }
+    } else {
     const double2* sg2 = C.tptr(C.lsig);
     const double2* mu2 = C.tptr(C.lmu);
 #pragma unroll
@@ -941,6 +953,7 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
         const double2 sg = sg2[m * 64 * W];
         o.g.a[2 * m] = gx.a[2 * m] * sg.x;
         o.g.a[2 * m + 1] = gx.a[2 * m + 1] * sg.y;
+    }
     }
     if (micro) {
         o.ke = o.ke + esh_update(C, o.g, o.v, sqrt_n * epsilon / 2.);

@@ -180,6 +180,36 @@ def test_lowrank_adaptation_bit_exact(oracle, case):
     assert (st["transformation_update_id"] >= 0).sum() >= n * 3 and st["num_eigenvalues"].max() >= (1 if "mvn" in case else 0)
 
 
+@pytest.mark.parametrize("kind", [N.KineticEnergyKind.EXACT_NORMAL, N.KineticEnergyKind.MICROCANONICAL], ids=["exact_normal", "microcanonical"])
+def test_lowrank_with_trajectory_kinds_bit_exact(oracle, kind):
+    """`LowRankNutsSettings::trajectory_kind` (src/sampler.rs:224-232 on NutsSettings<EuclideanAdaptOptions<LowRankSettings>>): the
+    geodesic and the ESH leapfrog around the low-rank transformation — a given per-chain transformation, and the whole adaptation
+    with the injected estimator."""
+    rng = np.random.default_rng(1000 + kind)
+    # (a) fixed per-chain transformations, iid normal
+    dim, n = 40, 4
+    s = lowrank_settings(num_chains=n, seed=31 + kind, num_tune=60, freeze_transform=True, trajectory_kind=kind)
+    pos, st, pos_o, st_o = run_fixed(oracle, N.LogpSpec.iid_normal(dim, 1.0), s, n, random_transform(rng, dim, 6, per_chain=n), 90, splits=(33,))
+    assert_bit_exact(pos, st, pos_o, st_o)
+    # (b) adaptation on a correlated normal
+    n, tune, draws = 4, 100, 130
+    logp = N.LogpSpec.mvn_precision(correlated_precision(rng, 20, 2)[0])
+    s = lowrank_settings(num_chains=n, seed=5, num_tune=tune, store_mass_matrix=True, trajectory_kind=kind)
+    cb_o, cb_e, rec = estimator_pair(oracle)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, logp.dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_lowrank_estimator(cb_e, n_threads=1)
+    pos, st = b.draw_many(draws)
+    tpc = b.threads_per_chain()
+    b.close()
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc), n, x0,
+                                        draws, estimator=cb_o)
+    assert failed == 0
+    assert_bit_exact(pos, st, pos_o, st_o)
+    assert (st["num_eigenvalues"] == st_o["num_eigenvalues"]).all() and (st["transformation_update_id"] >= 0).sum() >= n * 3
+
+
 def test_builtin_estimator_matches_lapack_restatement(oracle):
     """nm_lowrank_compute_update (csrc/lowrank_host.cpp) against oracle/lowrank.py on well-conditioned windows."""
     from oracle import lowrank as LR

@@ -117,8 +117,6 @@ def test_vector_statistics_with_kinds(oracle):
 
 def test_unsupported_combinations_fail_loudly():
     with pytest.raises(N.NutsAmdError):
-        N.ChainBatch(N.LowRankNutsSettings(num_chains=2, trajectory_kind=MICRO), N.LogpSpec.iid_normal(8, 0.0), 2)
-    with pytest.raises(N.NutsAmdError):
         N.ChainBatch(N.DiagNutsSettings(num_chains=2, trajectory_kind=MICRO), N.LogpSpec.iid_normal(1, 0.0), 2)
     with pytest.raises(N.NutsAmdError):
         N.ChainBatch(N.DiagNutsSettings(num_chains=2, trajectory_kind=7), N.LogpSpec.iid_normal(8, 0.0), 2)
