@@ -9,6 +9,7 @@ python tools/bench_configs.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- python tools/bench_configs.py "$@" > $OUT/trace_stdout.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT -o sq -- python tools/bench_configs.py "$@" > $OUT/sq_stdout.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT -o lds -- python tools/bench_configs.py "$@" > $OUT/lds_stdout.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA -d $OUT -o mfma -- python tools/bench_configs.py "$@" > $OUT/mfma_stdout.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch -- python tools/bench_configs.py "$@" > $OUT/fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write -- python tools/bench_configs.py "$@" > $OUT/write_stdout.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT -o tcc -- python tools/bench_configs.py "$@" > $OUT/tcc_stdout.log 2>&1
