@@ -303,10 +303,10 @@ typedef struct nm_engine_config {
     uint64_t grid_blocks;          /* 0 = auto (resident blocks of the chip).  Blocks stride over the chains */
     uint64_t lane_groups;          /* chains with dim <= 16 / 32 / 64: draw them 8 / 4 / 2 per wavefront instead of one per wavefront, same results.
                                     * 0 = auto (when there are more chains than resident wavefronts, ~2048), 1 = never, 2 = whenever the kernel applies */
-    uint64_t chain_tiles;          /* the full-precision normal at dim a multiple of 8 and <= 256: draw 16 chains per block with the dense
+    uint64_t chain_tiles;          /* the full-precision normal at dim <= 256: draw 16 chains per block with the dense
                                     * products on the matrix cores (v_mfma_f64_16x16x4_f64), same results.  (a) DiagNutsSettings: P x of the density,
                                     * every chain keeps its own adapting mass matrix; (b) one low-rank transformation shared by all chains
-                                    * (nm_engine_set_transform per_chain = 0, freeze_transform; rank a multiple of 8): U'z, U s and P x.
+                                    * (nm_engine_set_transform per_chain = 0, freeze_transform; dim and rank multiples of 8): U'z, U s and P x.
                                     * 0 = auto ((a) from 256 chains on, (b) whenever it applies), 1 = never, 2 = whenever it applies */
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */

@@ -579,7 +579,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     // so P x can run on the matrix cores 16 chains at a time (nuts_tile_diag_kernel) — same bits as the one-chain GEMV.
     // chain_tiles: 0 = when there are enough chains to fill the blocks, 1 = never, 2 = whenever it applies
     if (!lr && !kin && cl_k == 1 && logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1 && wv == 1 && (dpl == 2 || dpl == 4) &&
-        logp->dim <= 256 && logp->dim % 8 == 0 && e->group_grid == 0 && (cfg.chain_tiles == 2 || n_chains >= 256)) {
+        logp->dim <= 256 && e->group_grid == 0 && (cfg.chain_tiles == 2 || n_chains >= 256)) {      // (any dim: the packed P is zero-padded)
         const uint64_t dim = logp->dim;
         const double* P_ = logp->h_params;
         const std::vector<double> pp = pack_mfma_operand(dim, dim, [&](uint64_t d, uint64_t j) { return P_[j * dim + d]; });

@@ -25,6 +25,9 @@ CASES = [
     ("dim256_k5_17chains", 256, 17, 40, 64, {}),
     ("dim200_options", 200, 16, 40, 70, dict(maxdepth=5, max_energy_error=2.0)),
     ("dim136_adam", 136, 9, 40, 70, dict(adam=True)),
+    ("dim100_padded", 100, 18, 50, 80, {}),
+    ("dim251_padded", 251, 16, 30, 50, {}),
+    ("dim7_small", 7, 33, 60, 100, {}),
 ]
 
 
