@@ -537,7 +537,10 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         // small chains, more of them than the chip has wavefront slots: several chains per wave (nuts_group.hpp)
         const int gs = grp::group_size(logp->dim);
         const bool group_density = (logp->kind != NM_LOGP_MODULE && logp->kind != NM_LOGP_HOST_CALLBACK) || (logp->kind == NM_LOGP_MODULE && gs && e->module_group_lanes == gs);   // every built-in density has a group form
-        if (cl_k == 1 && !lr && !kin && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
+        // (the full-precision normal beyond 32 dims is faster on the matrix cores than two chains per wavefront: 3.7e8 against 3.0e8
+        // leapfrogs/s at dim 64, tools/probes/mvn_small_dims.py)
+        const bool mvn_tiles = logp->kind == NM_LOGP_MVN_PREC && logp->dim > 32 && cfg.chain_tiles != 1 && n_chains >= 256 && cfg.lane_groups != 2;
+        if (cl_k == 1 && !lr && !kin && !mvn_tiles && cfg.lane_groups != 1 && group_density && gs && (gs == 8 || logp->kind != NM_LOGP_EIGHT_SCHOOLS) && dpl == 2 && wv == 1 &&
             s.maxdepth <= (uint64_t)grp::GMAXDEPTH && (n_chains > wave_slots || cfg.lane_groups == 2)) {   // measured crossover (K4): 2048 chains
             int gocc = 0;
             dummy.dim = logp->dim;       // the group size follows the dim
