@@ -121,8 +121,8 @@ typedef struct nm_settings {
      * a partial momentum refresh (isokinetic Langevin / Ornstein-Uhlenbeck, transformed_hamiltonian.rs:770-825) on both sides
      * of each, and with dynamic_step_size the halve-and-retry ladder on a divergence (at most 10 halvings).  The step size is
      * the constant mclmc_step_size (the engine sets step_size_method = NM_STEP_FIXED, fixed_step_size = mclmc_step_size, as
-     * DiagMclmcSettings::new_chain does, sampler.rs:421-423); geometry adapts as usual.  NM_ADAPT_DIAG, built-in densities and
-     * NM_LOGP_HOST_CALLBACK, dim >= 2.  nm_draw_stats: depth = leapfrogs taken, energy_change, average_step_size. */
+     * DiagMclmcSettings::new_chain does, sampler.rs:421-423); geometry adapts as usual: NM_ADAPT_DIAG (DiagMclmcSettings) or
+     * NM_ADAPT_LOW_RANK (LowRankMclmcSettings).  Built-in densities and NM_LOGP_HOST_CALLBACK, dim >= 2.  nm_draw_stats: depth = leapfrogs taken, energy_change, average_step_size. */
     uint64_t sampler;                        /* NM_SAMPLER_NUTS */
     double   mclmc_step_size;                /* 0.5 */
     double   momentum_decoherence_length;    /* 3.0 */

@@ -6,7 +6,7 @@ Importing the package does not need a GPU; creating a ChainBatch does (there is 
 """
 from ._lib import NutsAmdError, STATS_DTYPE, VECTOR_STATS, load as load_library  # noqa: F401
 from .sampler import (AdamOptions, ChainBatch, DiagAdaptExpSettings, DiagNutsSettings, DualAverageOptions,  # noqa: F401
-                      EuclideanAdaptOptions, LogpSpec, LowRankNutsSettings, KineticEnergyKind, DiagMclmcSettings, MclmcTrajectoryKind, RecoverableLogpError, LowRankSettings, Progress, StepSizeSettings, sample,
+                      EuclideanAdaptOptions, LogpSpec, LowRankNutsSettings, KineticEnergyKind, DiagMclmcSettings, LowRankMclmcSettings, MclmcTrajectoryKind, RecoverableLogpError, LowRankSettings, Progress, StepSizeSettings, sample,
                       ADAPT_DIAG, ADAPT_LOW_RANK,
                       LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PREC, LOGP_MODULE, LOGP_HOST_CALLBACK,
                       STEP_DUAL_AVERAGE, STEP_ADAM, STEP_FIXED)
@@ -14,5 +14,5 @@ from .sampler import (AdamOptions, ChainBatch, DiagAdaptExpSettings, DiagNutsSet
 from .controller import ChainProgress, ProgressCallback, Sampler, SamplerWaitResult  # noqa: F401
 
 __all__ = ["ChainProgress", "ProgressCallback", "Sampler", "SamplerWaitResult", "AdamOptions", "ChainBatch", "DiagNutsSettings", "EuclideanAdaptOptions", "StepSizeSettings", "DualAverageOptions",
-           "DiagAdaptExpSettings", "LowRankNutsSettings", "KineticEnergyKind", "DiagMclmcSettings", "MclmcTrajectoryKind", "LowRankSettings", "LogpSpec", "Progress", "sample", "NutsAmdError", "STATS_DTYPE", "VECTOR_STATS",
+           "DiagAdaptExpSettings", "LowRankNutsSettings", "KineticEnergyKind", "DiagMclmcSettings", "LowRankMclmcSettings", "MclmcTrajectoryKind", "LowRankSettings", "LogpSpec", "Progress", "sample", "NutsAmdError", "STATS_DTYPE", "VECTOR_STATS",
            "load_library"]

@@ -461,7 +461,6 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         s.trajectory_kind = NM_TRAJ_EUCLIDEAN;      // (a NutsSettings field; MclmcChain's kind lives in the chain state)
     }
     const bool kin = mclmc || s.trajectory_kind != NM_TRAJ_EUCLIDEAN;
-    if (mclmc && lr) return fail(NM_ERR_UNSUPPORTED, "NM_SAMPLER_MCLMC runs with the diagonal adaptation (NM_ADAPT_DIAG) only");
     if (kin && logp->kind == NM_LOGP_MODULE) return fail(NM_ERR_UNSUPPORTED, "the non-Euclidean trajectory kinds / NM_SAMPLER_MCLMC with a density module: modules carry the Euclidean NUTS kernels only");
     if (s.trajectory_kind == NM_TRAJ_MICROCANONICAL && logp->dim < 2) return fail(NM_ERR_INVALID_ARG, "ESH dynamics requires at least 2 dimensions (reference src/math/cpu_math.rs:514)");
     nm_engine_config cfg;
@@ -960,7 +959,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
     // One transformation for all chains, frozen, on the full-precision normal: the draws can run 16 chains per block with
     // U', U and P on the matrix cores (nuts_tile.hpp).  The matrices are packed in MFMA operand order once, here.
     e->tile_active = false;
-    if (!per_chain && e->s.freeze_transform && e->s.trajectory_kind == NM_TRAJ_EUCLIDEAN && e->logp_kind == NM_LOGP_MVN_PREC && e->cfg.chain_tiles != 1 && e->wpc == 1 &&
+    if (!per_chain && e->s.freeze_transform && e->s.trajectory_kind == NM_TRAJ_EUCLIDEAN && e->s.sampler == NM_SAMPLER_NUTS && e->logp_kind == NM_LOGP_MVN_PREC && e->cfg.chain_tiles != 1 && e->wpc == 1 &&
         (e->dpl == 2 || e->dpl == 4) && dim <= 256 && n_eig >= 8 && n_eig <= 256 && dim % 8 == 0 && n_eig % 8 == 0 && !e->h_params.empty() &&
         sc[0].lr_upd_ok) {
         auto pack = [](uint64_t R, uint64_t K, auto&& elem) {      // [stripes][kpairs][64 lanes][2]

@@ -2148,11 +2148,14 @@ NM_DEV void mclmc_partial_refresh(ChainCtx<DPL, W, Dens>& C, Pt<DPL>& p, double 
 }
 
 template <int DPL, int W, class Dens>
-NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
+NM_DEV void finish_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain, nm_draw_stats& out, uint64_t ast, uint64_t row_idx);
+// (returns false when the chain cannot go on in this launch: failed, or — low-rank adaptation — paused for the host's estimator)
+template <int DPL, int W, class Dens>
+NM_DEV bool chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
     const nm_settings& s = P.s;
     ChainScalars& sc = C.sc;
-    nm_draw_stats out;
+    nm_draw_stats out = {};
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     // ---- Euclidean -> Microcanonical switch (mclmc.rs:490-504)
     bool resample_velocity = false;
@@ -2176,7 +2179,11 @@ NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
     Tile<DPL> x, gx;
     C.loadP(x, P_X); C.loadP(gx, P_GX);
     if (resample_velocity) sample_velocity(C, cur.v); else C.loadP(cur.v, P_V);
-    if (sc.mm_id != sc.transform_id) {                              // inv_transform_normalize (diagonal.rs:210-221)
+    if (sc.mm_id != sc.transform_id) {                              // inv_transform_normalize (diagonal.rs:210-221, low_rank.rs:302-314)
+        if constexpr (lr_trait<Dens>::value) {
+            transform_to_z(C, x, cur.z);
+            transform_to_gz(C, gx, cur.g);
+        } else {
         Tile<DPL> isig, sig, mu;
         C.loadP(isig, P_ISIG); C.load(sig, C.lsig); C.load(mu, C.lmu);
 #pragma unroll
@@ -2184,6 +2191,7 @@ NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
             const double t = __builtin_fma(-1.0, mu.a[k], x.a[k]);
             cur.z.a[k] = isig.a[k] * t;
             cur.g.a[k] = gx.a[k] * sig.a[k];
+        }
         }
         C.storeP(cur.z, P_Z); C.storeP(cur.g, P_GZ);
         sc.logdet = sc.mm_logdet;
@@ -2254,7 +2262,7 @@ NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
             zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = fatal;
             P.out_stats[t_out * P.n_chains + chain] = zz;
         }
-        return;
+        return false;
     }
     const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
     // DrawGradCollector::register_draw(current) (adapt/diagonal.rs:73-83)
@@ -2295,6 +2303,22 @@ NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
     fd = C.red.sum(fd);
     const int64_t trans_id = sc.transform_id;
     sc.total_steps += col.count;
+    out.depth = steps_taken; out.maxdepth_reached = 0; out.diverging = diverged;
+    out.index_in_trajectory = state_idx; out.transformation_index = trans_id;
+    out.logp = state_logp; out.energy = state_energy; out.energy_error = state_energy_error;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (diverged && div_has_energy) ? div_energy_error : __builtin_nan("");
+    out.energy_change = energy_change; out.average_step_size = time / (double)steps_taken;
+    if constexpr (lr_trait<Dens>::value) {          // LowRankMclmcSettings: the adaptation may hand over to the host's estimator
+        const uint64_t ast_lr = adapt_lr(C, chain, col, is_good, x, gx);
+        if (sc.lr_pending == LR_WAIT_HOST) {        // the rest of this draw happens in lr_resume
+            sc.lr_row = t_out;
+            if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+            return false;
+        }
+        finish_draw_lr(C, chain, out, ast_lr, t_out);
+        return sc.status == NM_CHAIN_OK;
+    }
     uint64_t ast = adapt(C, col, is_good, x, gx);    // the collector saw `current`; Fixed step size: the state's position is not used
     if (ast != NM_CHAIN_OK) sc.status = ast;
     out.depth = steps_taken; out.maxdepth_reached = 0; out.diverging = diverged;
@@ -2318,6 +2342,7 @@ NM_DEV void chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
     sc.stats_last_id = sc.mm_id;
     if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
+    return sc.status == NM_CHAIN_OK;
 }
 
 template <int DPL, int W, class Dens>
@@ -2325,7 +2350,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
     if constexpr (kin_trait<Dens>::value) {
-        if (P.s.sampler == NM_SAMPLER_MCLMC) { chain_draw_mclmc(C, chain, t_out); return; }
+        if (P.s.sampler == NM_SAMPLER_MCLMC) { (void)chain_draw_mclmc(C, chain, t_out); return; }
     }
     AcceptCollector col;
     DrawResult R;
@@ -2437,7 +2462,7 @@ NM_DEV void finish_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain, nm_draw_st
     out.chain_status = ast;
     out.transformation_update_id = -1;                            // LowRankMassMatrix::extract_stats (low_rank.rs:218-262)
     out.num_eigenvalues = 0;
-    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
+    if (P.s.sampler != NM_SAMPLER_MCLMC) { out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan(""); }
     if (sc.mm_id != sc.stats_last_id) {
         out.transformation_update_id = sc.mm_id;
         out.num_eigenvalues = sc.lr_has_inner ? sc.lr_rank : 0;
@@ -2460,6 +2485,7 @@ NM_DEV bool chain_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
     const uint64_t row_idx = sc.draw_count - P.row_base;
+    if (P.s.sampler == NM_SAMPLER_MCLMC) return chain_draw_mclmc(C, chain, row_idx);     // LowRankMclmcSettings
     AcceptCollector col;
     DrawResult R;
     Tile<DPL> x, gx, z, gz;

@@ -181,6 +181,17 @@ class DiagMclmcSettings:           # MclmcSettings<EuclideanAdaptOptions<DiagAda
         return s
 
 
+def LowRankMclmcSettings(**kw):    # MclmcSettings<EuclideanAdaptOptions<LowRankSettings>> (src/sampler.rs:325-328; Default: :376-384)
+    """`LowRankMclmcSettings`: the MCLMC settings with `LowRankSettings` as mass_matrix_options (num_tune 800,
+    early_mass_matrix_switch_freq 20)."""
+    a = _fixed_step_adapt_options()
+    a.mass_matrix_options = LowRankSettings()
+    a.early_mass_matrix_switch_freq = 20
+    kw.setdefault("num_tune", 800)
+    kw.setdefault("adapt_options", a)
+    return DiagMclmcSettings(**kw)
+
+
 def LowRankNutsSettings(**kw):     # src/sampler.rs:245; Default: :636-642 (num_tune 800, mass_matrix_update_freq 20)
     """`LowRankNutsSettings`: the same settings struct with `LowRankSettings` as mass_matrix_options."""
     lr = {k: kw.pop(k) for k in ("gamma", "eigval_cutoff", "store_mass_matrix") if k in kw}

@@ -1129,7 +1129,7 @@ struct Chain {
             o.divergence_energy_error = (diverged && div.has_energy_error) ? div.energy_error : NAN;
             o.chain_status = arc;
             o.transformation_update_id = h.mm.id != stats_last_id ? h.mm.id : -1;
-            o.num_eigenvalues = 0;
+            o.num_eigenvalues = (h.mm.id != stats_last_id && h.mm.has_inner) ? h.mm.rank : 0;   // MatrixStats low_rank.rs:222-229
             o.energy_change = energy_change; o.average_step_size = average_step_size;
         }
         if (vec) {
@@ -1137,7 +1137,11 @@ struct Chain {
             put(vec->gradient, next->gx);
             put(vec->transformed_position, next->z);
             put(vec->transformed_gradient, next->gz);
-            if (h.mm.id != stats_last_id) { put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean); }
+            if (h.mm.id != stats_last_id) {
+                put(vec->mass_matrix_inv, h.mm.stds); put(vec->transformation_mu, h.mm.mean);
+                if (vec->mass_matrix_eigvals && h.mm.has_inner)
+                    for (size_t i = 0; i < n; ++i) vec->mass_matrix_eigvals[i] = i < h.mm.rank ? h.mm.vals_sqrt[i] : NAN;
+            }
             if (diverged) {
                 put(vec->divergence_start, div.start_location);
                 put(vec->divergence_start_gradient, div.start_gradient);

@@ -116,3 +116,37 @@ def test_mclmc_unsupported_combinations_fail_loudly():
         N.ChainBatch(N.DiagMclmcSettings(num_chains=2, step_size=0.0), N.LogpSpec.iid_normal(4, 0.0), 2)
     with pytest.raises(N.NutsAmdError):
         N.ChainBatch(N.DiagMclmcSettings(num_chains=2, trajectory_kind=9), N.LogpSpec.iid_normal(4, 0.0), 2)
+
+
+@pytest.mark.parametrize("kind", [K.EUCLIDEAN_EARLY_THEN_MICROCANONICAL, K.MICROCANONICAL], ids=["default_kind", "microcanonical"])
+def test_lowrank_mclmc_bit_exact(oracle, kind):
+    """`LowRankMclmcSettings` (src/sampler.rs:325-328, :376-384): MclmcChain with the low-rank adaptation — the pause for the host's
+    estimator falls in the middle of MclmcChain::draw's adapt call — with the oracle's estimator injected on both sides."""
+    import ctypes as C
+    from nuts_rs_amd import _lib
+    from oracle import lowrank as LR
+    rng = np.random.default_rng(3)
+    dim, n, draws = 16, 4, 170
+    u = np.linalg.qr(rng.normal(size=(dim, 2)))[0]
+    sigma = np.eye(dim) + u @ np.diag([40.0, 15.0]) @ u.T
+    p = np.linalg.inv(sigma)
+    logp = N.LogpSpec.mvn_precision((p + p.T) / 2)
+    s = N.LowRankMclmcSettings(num_chains=n, seed=12, num_tune=120, trajectory_kind=kind, step_size=0.4)
+    rec = []
+    cb_o = LR.estimator_callback(rec)
+    cb_e = C.cast(cb_o, _lib.LOWRANK_ESTIMATOR_FN)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_lowrank_estimator(cb_e, n_threads=1)
+    pos_a, st_a = b.draw_many(60)
+    pos_b, st_b = b.draw_many(draws - 60)
+    pos_g, st_g = np.concatenate([pos_a, pos_b]), np.concatenate([st_a, st_b])
+    tpc = b.threads_per_chain()
+    b.close()
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc), n, x0, draws, estimator=cb_o)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    for f in ("energy_change", "average_step_size"):
+        assert ((st_g[f] == st_o[f]) | (np.isnan(st_g[f]) & np.isnan(st_o[f]))).all(), f
+    assert (st_g["num_eigenvalues"] == st_o["num_eigenvalues"]).all() and st_g["num_eigenvalues"].max() >= 1
