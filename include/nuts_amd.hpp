@@ -139,6 +139,35 @@ struct DiagMclmcSettings {
     }
 };
 
+// `LowRankNutsSettings` = NutsSettings<EuclideanAdaptOptions<LowRankSettings>> (src/sampler.rs:245, Default :636-642;
+// LowRankSettings src/transform/low_rank.rs:188-203).  The diagonal-only option struct of `adapt_options` is ignored.
+struct LowRankSettings { bool store_mass_matrix = false; double gamma = 1e-5, eigval_cutoff = 2.0; };
+struct LowRankNutsSettings {
+    DiagNutsSettings nuts;                      // every other NutsSettings field
+    LowRankSettings mass_matrix_options;
+    LowRankNutsSettings() { nuts.num_tune = 800; nuts.adapt_options.mass_matrix_update_freq = 20; }
+    const DiagNutsSettings& base() const { return nuts; }
+    nm_settings to_c() const {
+        nm_settings s = nuts.to_c();
+        s.adaptation = NM_ADAPT_LOW_RANK; s.store_mass_matrix = mass_matrix_options.store_mass_matrix;
+        s.lr_gamma = mass_matrix_options.gamma; s.lr_eigval_cutoff = mass_matrix_options.eigval_cutoff;
+        return s;
+    }
+};
+// `LowRankMclmcSettings` = MclmcSettings<EuclideanAdaptOptions<LowRankSettings>> (src/sampler.rs:325-328, Default :376-384)
+struct LowRankMclmcSettings {
+    DiagMclmcSettings mclmc;
+    LowRankSettings mass_matrix_options;
+    LowRankMclmcSettings() { mclmc.num_tune = 800; mclmc.adapt_options.early_mass_matrix_switch_freq = 20; }
+    DiagNutsSettings base() const { return mclmc.base(); }
+    nm_settings to_c() const {
+        nm_settings s = mclmc.to_c();
+        s.adaptation = NM_ADAPT_LOW_RANK; s.store_mass_matrix = mass_matrix_options.store_mass_matrix;
+        s.lr_gamma = mass_matrix_options.gamma; s.lr_eigval_cutoff = mass_matrix_options.eigval_cutoff;
+        return s;
+    }
+};
+
 // A registered device density (the device-side stand-in for a `CpuLogpFunc`, src/math/cpu_math.rs:885-891)
 struct LogpSpec {
     uint64_t kind = NM_LOGP_IID_NORMAL, dim = 0;
@@ -199,8 +228,10 @@ public:
         cfg.device = device; cfg.chain_id_offset = chain_id_offset;
         check(nm_engine_create(&s, &l, n_chains, &cfg, &h_));
     }
-    // `DiagMclmcSettings::new_chain` for every chain: the MCLMC sampler instead of the NUTS tree
-    ChainBatch(const DiagMclmcSettings& settings, const LogpSpec& logp, uint64_t n_chains, uint64_t chain_id_offset = 0,
+    // `<Settings>::new_chain` for every chain with the other settings types (DiagMclmcSettings, LowRankNutsSettings,
+    // LowRankMclmcSettings): anything with to_c() and base()
+    template <class S, class = decltype(std::declval<const S&>().base())>
+    ChainBatch(const S& settings, const LogpSpec& logp, uint64_t n_chains, uint64_t chain_id_offset = 0,
                int64_t device = -1)
         : settings_(settings.base()), n_(n_chains), dim_(logp.dim), offset_(chain_id_offset) {
         nm_settings s = settings.to_c();

@@ -42,3 +42,12 @@ def test_cpp_host_api_k1_matches_oracle(oracle, tmp_path):
     pos_o, st_o, steps, failed = oracle.run(s, oracle.LOGP_IID_NORMAL, 10, [3.0], oracle.gpu_cfg(64), 4, np.zeros((4, 10)), 1400)
     assert failed == 0 and (pos.view(np.uint64) == pos_o.view(np.uint64)).all()
     assert f"{steps} leapfrogs" in r.stdout
+
+
+def test_cpp_settings_types_defaults():
+    src = os.path.join(ROOT, "tests", "cpp", "settings_check.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "settings_check")
+    libdir = os.path.join(ROOT, "nuts_rs_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src,
+                           "-o", exe, "-L", libdir, "-lnuts_amd", f"-Wl,-rpath,{libdir}", "-pthread"])
+    assert subprocess.run([exe]).returncode == 0
