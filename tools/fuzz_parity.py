@@ -1,0 +1,140 @@
+"""Randomised parity sweep: engine (C ABI) against the oracle, bit for bit, over random densities, dims, chain counts, tilings,
+settings, samplers and trajectory kinds.  Not part of the test suite (minutes on a GPU); prints one line per case and a summary.
+
+  python tools/fuzz_parity.py [--cases 100] [--seed 1]"""
+import argparse
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch  # noqa: F401  (initialises the HIP runtime first)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import nuts_rs_amd as N  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from helpers import STAT_FIELDS_EXACT, oracle_settings  # noqa: E402
+
+
+def make_case(rng):
+    dens = rng.choice(["iid", "diag", "funnel", "schools", "mvn"], p=[0.3, 0.25, 0.2, 0.1, 0.15])
+    if dens == "schools":
+        dim = 10
+    elif dens == "mvn":
+        dim = int(rng.choice([3, 17, 64, 100, 200, 256, 300]))
+    elif dens == "funnel":
+        dim = int(rng.choice([2, 5, 11, 40, 101, 130, 300]))
+    else:
+        dim = int(rng.choice([1, 2, 7, 33, 64, 65, 128, 129, 257, 511, 1024, 1500, 2048, 3000, 4096, 5000]))
+    sampler = rng.choice(["nuts", "exact", "micro", "mclmc"], p=[0.5, 0.15, 0.15, 0.2])
+    if sampler in ("micro", "mclmc") and dim < 2:
+        dim = 2
+    if dim > 4096 and (dens not in ("iid", "diag") or sampler != "nuts"):
+        dim = 4096
+    n = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
+    kw = dict(num_chains=n, seed=int(rng.integers(0, 2**31)), num_tune=int(rng.choice([20, 40, 60, 100])))
+    if sampler == "mclmc":
+        kw.update(step_size=float(rng.choice([0.2, 0.5, 0.9])), momentum_decoherence_length=float(rng.choice([1.0, 3.0, 7.0])),
+                  trajectory_kind=int(rng.integers(0, 3)), dynamic_step_size=bool(rng.integers(0, 2)),
+                  subsample_frequency=float(rng.choice([0.0, 0.5, 1.0])), max_energy_error=float(rng.choice([1000.0, 5.0, 0.5])),
+                  trajectory_switch_fraction=float(rng.choice([0.0, 0.3, 0.9])))
+        s = N.DiagMclmcSettings(**kw)
+    else:
+        kw.update(maxdepth=int(rng.choice([10, 10, 6, 3])), mindepth=int(rng.choice([0, 0, 1, 2])), extra_doublings=int(rng.choice([0, 0, 1])),
+                  max_energy_error=float(rng.choice([1000.0, 1000.0, 3.0, 0.3])), check_turning=bool(rng.random() > 0.1),
+                  target_integration_time=None if rng.random() > 0.15 else float(rng.choice([0.5, 2.0])),
+                  trajectory_kind={"nuts": 0, "exact": 1, "micro": 2}[sampler])
+        if kw["mindepth"] > kw["maxdepth"]:
+            kw["mindepth"] = 0
+        s = N.DiagNutsSettings(**kw)
+        st = s.adapt_options.step_size_settings
+        r = rng.random()
+        if r < 0.15:
+            st.method = N.STEP_ADAM
+        elif r < 0.25:
+            st.method, st.fixed_step_size = N.STEP_FIXED, float(rng.choice([0.1, 0.4]))
+        if rng.random() < 0.2:
+            st.jitter = None
+        if rng.random() < 0.2:
+            st.target_accept = float(rng.choice([0.6, 0.95]))
+        if rng.random() < 0.2:
+            s.adapt_options.mass_matrix_options.use_grad_based_estimate = False
+    prng = np.random.default_rng(kw["seed"])
+    if dens == "iid":
+        logp = N.LogpSpec.iid_normal(dim, float(prng.normal()))
+    elif dens == "diag":
+        logp = N.LogpSpec.diag_normal(np.exp(prng.uniform(-4, 4, dim)))
+    elif dens == "funnel":
+        logp = N.LogpSpec.funnel(dim)
+    elif dens == "schools":
+        logp = N.LogpSpec.eight_schools()
+    else:
+        a = prng.normal(size=(dim, dim))
+        p = a @ a.T / dim + np.eye(dim)
+        logp = N.LogpSpec.mvn_precision((p + p.T) / 2)
+    eng = {}
+    if sampler == "nuts" and dens != "schools" and dim <= 4096:
+        from nuts_rs_amd.build import pick_tiling
+        combos = [(d, w) for d, w in ((2, 1), (4, 1), (8, 1), (16, 1), (8, 2), (16, 2), (4, 4), (16, 4)) if d * 64 * w >= dim]
+        if dens == "mvn":
+            combos = [c for c in combos if c != (16, 4)]
+        d, w = combos[int(rng.integers(0, len(combos)))]
+        eng.update(dims_per_lane=d, waves_per_chain=w)
+    eng["lane_groups"] = int(rng.choice([0, 1, 2]))
+    eng["chain_tiles"] = int(rng.choice([0, 1, 2]))
+    draws = kw["num_tune"] + int(rng.choice([10, 30]))
+    desc = f"{dens} dim {dim} n {n} {sampler} tune {kw['num_tune']} draws {draws} eng {eng}"
+    return s, logp, n, draws, eng, desc
+
+
+def run_case(s, logp, n, draws, eng):
+    x0 = O.init_positions_uniform(s.seed, 0, n, logp.dim)
+    b = N.ChainBatch(s, logp, n, **eng)
+    status = b.set_position(x0, raise_on_error=False)
+    cut = draws // 2
+    if (status == 0).all():
+        pa, sa = b.draw_many(cut, raise_on_error=False)
+        pb, sb = b.draw_many(draws - cut, raise_on_error=False)
+        pos, st = np.concatenate([pa, pb]), np.concatenate([sa, sb])
+    tpc, k = b.threads_per_chain(), b.blocks_per_chain()
+    b.close()
+    cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0)
+    so = oracle_settings(O, s)
+    # per chain through the step-wise interface so that a failed chain does not end the comparison
+    pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8)
+    if not (status == 0).all():
+        return "init-failed" if failed else "MISMATCH: engine refused an initial point the oracle accepts"
+    if failed:
+        return "MISMATCH: oracle chain failed, engine did not" if (st["chain_status"] == 0).all() else "both-failed"
+    if not (pos.view(np.uint64) == pos_o.view(np.uint64)).all():
+        t, c = np.argwhere((pos != pos_o).any(axis=2))[0]
+        return f"MISMATCH: positions first at draw {t} chain {c}"
+    for f in list(STAT_FIELDS_EXACT) + ["step_size", "energy", "logp"]:
+        a, bb = st[f], st_o[f]
+        same = (a == bb) | (np.isnan(a.astype(float)) & np.isnan(bb.astype(float))) if a.dtype.kind == "f" else (a == bb)
+        if not same.all():
+            t, c = np.argwhere(~same)[0]
+            return f"MISMATCH: stat {f} first at draw {t} chain {c}: {a[t, c]} vs {bb[t, c]}"
+    return "ok"
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    tally = {}
+    for i in range(a.cases):
+        s, logp, n, draws, eng, desc = make_case(rng)
+        try:
+            res = run_case(s, logp, n, draws, eng)
+        except N.NutsAmdError as e:
+            res = "unsupported: " + str(e)[:80]
+        except Exception:
+            res = "ERROR: " + traceback.format_exc().splitlines()[-1][:160]
+        key = res.split(":")[0]
+        tally[key] = tally.get(key, 0) + 1
+        print(f"[{i}] {res:14s} {desc}", flush=True)
+    print("summary:", tally)
