@@ -1,7 +1,10 @@
 """Randomised parity sweep: engine (C ABI) against the oracle, bit for bit, over random densities, dims, chain counts, tilings,
 settings, samplers and trajectory kinds.  Not part of the test suite (minutes on a GPU); prints one line per case and a summary.
 
-  python tools/fuzz_parity.py [--cases 100] [--seed 1]"""
+  python tools/fuzz_parity.py [--cases 100] [--seed 1] [--scale]
+
+--scale: thousands of chains per case (late blocks of big grids, several chains per wavefront, matrix-core kernels at their real
+sizes); ten randomly picked chains of each run are compared with the oracle."""
 import argparse
 import os
 import sys
@@ -17,7 +20,7 @@ from oracle import oracle as O  # noqa: E402
 from helpers import STAT_FIELDS_EXACT, oracle_settings  # noqa: E402
 
 
-def make_case(rng):
+def make_case(rng, scale=False):
     dens = rng.choice(["iid", "diag", "funnel", "schools", "mvn"], p=[0.3, 0.25, 0.2, 0.1, 0.15])
     if dens == "schools":
         dim = 10
@@ -33,6 +36,9 @@ def make_case(rng):
     if dim > 4096 and (dens not in ("iid", "diag") or sampler != "nuts"):
         dim = 4096
     n = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
+    if scale:
+        n = int(rng.choice([1100, 2500, 4200, 9000, 20000]))
+        dim = min(dim, 300)
     kw = dict(num_chains=n, seed=int(rng.integers(0, 2**31)), num_tune=int(rng.choice([20, 40, 60, 100])))
     if sampler == "mclmc":
         kw.update(step_size=float(rng.choice([0.2, 0.5, 0.9])), momentum_decoherence_length=float(rng.choice([1.0, 3.0, 7.0])),
@@ -88,7 +94,7 @@ def make_case(rng):
     return s, logp, n, draws, eng, desc
 
 
-def run_case(s, logp, n, draws, eng):
+def run_case(s, logp, n, draws, eng, rng=None):
     x0 = O.init_positions_uniform(s.seed, 0, n, logp.dim)
     b = N.ChainBatch(s, logp, n, **eng)
     status = b.set_position(x0, raise_on_error=False)
@@ -102,7 +108,16 @@ def run_case(s, logp, n, draws, eng):
     cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0)
     so = oracle_settings(O, s)
     # per chain through the step-wise interface so that a failed chain does not end the comparison
-    pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8)
+    if n > 100:          # a sample of the chains, each from its own global id
+        picks = sorted(set([0, n - 1] + [int(c) for c in rng.integers(0, n, 8)]))
+        outs = [O.run(so, logp.kind, logp.dim, logp.params, cfg, 1, x0[c:c + 1], draws, chain_offset=c, n_threads=1) for c in picks]
+        pos_o = np.concatenate([o[0] for o in outs], axis=1); st_o = np.concatenate([o[1] for o in outs], axis=1)
+        failed = sum(o[3] for o in outs)
+        if (status == 0).all():
+            pos, st = pos[:, picks], st[:, picks]
+        status = status[picks]
+    else:
+        pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8)
     if not (status == 0).all():
         return "init-failed" if failed else "MISMATCH: engine refused an initial point the oracle accepts"
     if failed:
@@ -123,13 +138,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scale", action="store_true")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     tally = {}
     for i in range(a.cases):
-        s, logp, n, draws, eng, desc = make_case(rng)
+        s, logp, n, draws, eng, desc = make_case(rng, a.scale)
         try:
-            res = run_case(s, logp, n, draws, eng)
+            res = run_case(s, logp, n, draws, eng, rng)
         except N.NutsAmdError as e:
             res = "unsupported: " + str(e)[:80]
         except Exception:
