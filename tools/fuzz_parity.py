@@ -79,6 +79,18 @@ def make_case(rng, scale=False):
         a = prng.normal(size=(dim, dim))
         p = a @ a.T / dim + np.eye(dim)
         logp = N.LogpSpec.mvn_precision((p + p.T) / 2)
+    transform = None
+    if sampler != "mclmc" and not scale and dim <= 1024 and rng.random() < 0.2:       # a given low-rank transformation (frozen)
+        rank = int(rng.integers(0, min(dim, 12) + 1))
+        per_chain = n if rng.random() < 0.5 else 0
+        shp = (per_chain,) if per_chain else ()
+        stds = np.exp(prng.normal(0, 0.5, shp + (dim,))); mean = prng.normal(0, 1, shp + (dim,)); mu = prng.normal(0, 0.3, shp + (dim,))
+        vals = np.exp(prng.uniform(-2, 3, shp + (rank,)))
+        mk = lambda: np.linalg.qr(prng.normal(size=(dim, max(rank, 1))))[0].T[:rank]
+        vecs = np.stack([mk() for _ in range(per_chain)]) if per_chain else mk()
+        transform = (stds, mean, vals, np.ascontiguousarray(vecs).reshape(shp + (rank, dim)), mu)
+        s = N.LowRankNutsSettings(freeze_transform=True, **kw)
+        sampler = "lowrank-" + sampler
     eng = {}
     if sampler == "nuts" and dens != "schools" and dim <= 4096:
         from nuts_rs_amd.build import pick_tiling
@@ -91,21 +103,23 @@ def make_case(rng, scale=False):
     eng["chain_tiles"] = int(rng.choice([0, 1, 2]))
     draws = kw["num_tune"] + int(rng.choice([10, 30]))
     desc = f"{dens} dim {dim} n {n} {sampler} tune {kw['num_tune']} draws {draws} eng {eng}"
-    return s, logp, n, draws, eng, desc
+    return s, logp, n, draws, eng, desc, transform
 
 
-def run_case(s, logp, n, draws, eng, rng=None):
+def run_case(s, logp, n, draws, eng, rng=None, transform=None):
     x0 = O.init_positions_uniform(s.seed, 0, n, logp.dim)
     b = N.ChainBatch(s, logp, n, **eng)
     status = b.set_position(x0, raise_on_error=False)
+    if transform is not None and (status == 0).all():
+        b.set_transform(*transform)
     cut = draws // 2
     if (status == 0).all():
         pa, sa = b.draw_many(cut, raise_on_error=False)
         pb, sb = b.draw_many(draws - cut, raise_on_error=False)
         pos, st = np.concatenate([pa, pb]), np.concatenate([sa, sb])
-    tpc, k = b.threads_per_chain(), b.blocks_per_chain()
+    tpc, k, tiles = b.threads_per_chain(), b.blocks_per_chain(), b.tile_launches() > 0
     b.close()
-    cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0)
+    cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0, lr_seq_dots=int(tiles and transform is not None))
     so = oracle_settings(O, s)
     # per chain through the step-wise interface so that a failed chain does not end the comparison
     if n > 100:          # a sample of the chains, each from its own global id
@@ -117,7 +131,7 @@ def run_case(s, logp, n, draws, eng, rng=None):
             pos, st = pos[:, picks], st[:, picks]
         status = status[picks]
     else:
-        pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8)
+        pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8, transform=transform)
     if not (status == 0).all():
         return "init-failed" if failed else "MISMATCH: engine refused an initial point the oracle accepts"
     if failed:
@@ -143,9 +157,9 @@ if __name__ == "__main__":
     rng = np.random.default_rng(a.seed)
     tally = {}
     for i in range(a.cases):
-        s, logp, n, draws, eng, desc = make_case(rng, a.scale)
+        s, logp, n, draws, eng, desc, transform = make_case(rng, a.scale)
         try:
-            res = run_case(s, logp, n, draws, eng, rng)
+            res = run_case(s, logp, n, draws, eng, rng, transform)
         except N.NutsAmdError as e:
             res = "unsupported: " + str(e)[:80]
         except Exception:
