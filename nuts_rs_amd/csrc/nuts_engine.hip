@@ -471,8 +471,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (logp->dim > CL_SLICE) {     // wider than one block: ceil(dim / 4096) blocks per chain (kern_cluster.hip)
         cl_k = (logp->dim + CL_SLICE - 1) / CL_SLICE;
         if (cl_k > CL_MAX_K) return fail(NM_ERR_UNSUPPORTED, "dim %llu > %llu", (unsigned long long)logp->dim, (unsigned long long)(CL_SLICE * CL_MAX_K));
-        if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL)
-            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal) only", (unsigned long long)logp->dim);
+        if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL && logp->kind != NM_LOGP_HOST_CALLBACK)
+            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal) and for NM_LOGP_HOST_CALLBACK", (unsigned long long)logp->dim);
         if (lr || kin) return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: Euclidean NUTS with the diagonal adaptation only", (unsigned long long)logp->dim);
         if ((cfg.dims_per_lane && cfg.dims_per_lane != 16) || (cfg.waves_per_chain && cfg.waves_per_chain != 4))
             return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096 runs on the (16 doubles, 4 waves) tiling", (unsigned long long)logp->dim);

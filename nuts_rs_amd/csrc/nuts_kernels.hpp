@@ -491,7 +491,50 @@ struct HostCb {
         mail = reinterpret_cast<CbMail*>(base);
         mx = reinterpret_cast<double*>(base + sizeof(CbMail));
         mg = mx + P.dim;
+#if NM_CLUSTER_MODE
+        next_seq = __hip_atomic_load(&mail->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;    // no request is in flight here
+#endif
     }
+#if NM_CLUSTER_MODE
+    // a chain wider than one block: every member writes its slice of the position into the chain's mailbox, the first member
+    // rings, all members wait for the answer and read their slice of the gradient
+    int goff = 0, member = 0;
+    uint64_t next_seq = 0;
+    template <int W>
+    NM_DEV void init_slice(const double*, int, int, int goff_, Reducer<W>& R) { goff = goff_; member = R.cl ? R.cl->member : 0; }
+    template <int DPL, int W>
+    NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = elem_index<W>(k);
+            if (d < dim) __hip_atomic_store(&mx[goff + d], x.a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: this member's slice is in host memory ...
+        (void)R.sum(0.0);                                         // ... and so is every other member's, once all have met here
+        int failed = 0;
+        const uint64_t seq = next_seq;
+        if (tid() == 0) {
+            if (member == 0) __hip_atomic_store(&mail->req, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long t0 = wall_clock64();           // 100 MHz
+            while (__hip_atomic_load(&mail->resp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                __builtin_amdgcn_s_sleep(64);
+                if (wall_clock64() - t0 > 6000000000ull) { failed = 1; break; }      // 60 s without an answer: the chain fails
+            }
+        }
+        next_seq = seq + 1;
+        failed = R.sum(failed ? 1.0 : 0.0) != 0.0 ? 1 : 0;         // no member rings again before all have read this answer
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const int64_t st = failed ? 2 : __hip_atomic_load(&mail->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        status = __builtin_amdgcn_readfirstlane((int)st);
+        const double lp = __hip_atomic_load(&mail->logp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            const int d = elem_index<W>(k);
+            gx.a[k] = (d < dim && status == 0) ? __hip_atomic_load(&mg[goff + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+        }
+        return uniform_f64(status == 0 ? lp : __builtin_nan(""));
+    }
+#else
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) {
 #pragma unroll
@@ -523,6 +566,7 @@ struct HostCb {
         }
         return uniform_f64(status == 0 ? lp : __builtin_nan(""));
     }
+#endif
 };
 template <class D, class = void> struct can_fail { static constexpr bool value = false; };
 template <class D> struct can_fail<D, typename std::enable_if<D::kCanFail>::type> { static constexpr bool value = true; };
@@ -719,7 +763,11 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.dens.init(P.logp_params, C.dim, C.red);
 #endif
     C.dens.set_lds(sh.dens_lds);
+#if NM_CLUSTER_MODE
+    if constexpr (can_fail<Dens>::value) C.dens.bind(P, chain / P.cl_k);      // `chain` is the sub-chain index here
+#else
     if constexpr (can_fail<Dens>::value) C.dens.bind(P, chain);
+#endif
 }
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_end(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {

@@ -67,3 +67,83 @@ def test_wide_chain_posterior_and_unsupported(oracle):
         N.ChainBatch(N.LowRankNutsSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)
     with pytest.raises(N.NutsAmdError):
         N.ChainBatch(s, N.LogpSpec.iid_normal(70000, 0.0), 2)      # > 16 blocks per chain
+    with pytest.raises(N.NutsAmdError):
+        N.ChainBatch(N.DiagMclmcSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)    # Euclidean NUTS only
+
+
+def _coupled(chain, x):
+    """a non-element-wise density: a random-walk prior (every coordinate tied to its neighbour, across the blocks' slice borders)
+    plus a weak quartic well; deterministic numpy arithmetic so that the engine's and the oracle's calls agree bit for bit"""
+    d = np.diff(x)
+    lp = -0.5 * float(np.dot(d, d)) * 4.0 - 0.5 * float(np.dot(x, x)) * 0.25 - 0.01 * float(np.sum(x ** 4))
+    g = -0.25 * x - 0.04 * x ** 3
+    g[:-1] += 4.0 * d
+    g[1:] -= 4.0 * d
+    return lp, g
+
+
+@pytest.mark.parametrize("dim,kind", [(4500, "nuts"), (9000, "nuts"), (12289, "nuts")], ids=["dim4500", "dim9000", "dim12289"])
+def test_wide_chain_host_callback_bit_exact(oracle, dim, kind):
+    """Any density for a wide chain: the members of a chain share its mailbox (each writes its slice of the position, the first
+    rings, each reads its slice of the gradient) — against the oracle's callback chain on the same Python function."""
+    n, tune, draws = 3, 12, 20
+    s = N.DiagNutsSettings(num_chains=n, seed=dim, num_tune=tune, maxdepth=5)
+    calls = {"n": 0}
+
+    def counted(chain, x):
+        calls["n"] += 1
+        return _coupled(chain, x)
+    logp = N.LogpSpec.host_callback(dim, counted, threads=2)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert b.blocks_per_chain() == -(-dim // 4096)
+    assert (b.set_position(x0, raise_on_error=False) == 0).all()
+    pos_a, st_a = b.draw_many(draws // 2)
+    pos_b, st_b = b.draw_many(draws - draws // 2)
+    pos_g, st_g = np.concatenate([pos_a, pos_b]), np.concatenate([st_a, st_b])
+    steps_g, host_calls = b.counters()["total_leapfrogs"], b.host_logp_calls()
+    b.close()
+    assert host_calls == calls["n"] and host_calls >= steps_g + n          # one call per chain per gradient, not one per block
+
+    def tramp(ctx, d, px, pg, plogp):
+        lp, g = _coupled(0, np.ctypeslib.as_array(px, shape=(d,)).copy())
+        np.ctypeslib.as_array(pg, shape=(d,))[:] = g
+        plogp[0] = lp
+        return 0
+    cb = oracle.HOST_LOGP_FN(tramp)
+    so = oracle_settings(oracle, s)
+    cfg = oracle.gpu_cfg(256, gpu_slice=4096)
+    for c in range(n):
+        ch = oracle.Chain(so, 0, dim, np.zeros(1), cfg, chain_id=c, callback=cb)
+        assert ch.set_position(x0[c]) == 0
+        for t in range(draws):
+            p, q, rc = ch.draw()
+            assert rc == 0
+            assert (p.view(np.uint64) == pos_g[t, c].view(np.uint64)).all(), (c, t)
+            for f in ("depth", "n_steps", "diverging", "step_size", "energy", "logp", "mean_tree_accept"):
+                assert q[f] == st_g[f][t, c], (f, c, t)
+
+
+def test_wide_chain_host_callback_errors(oracle):
+    """The reference's error taxonomy survives the shared mailbox: a recoverable error is a divergence, an unrecoverable one stops
+    the chain (all of its blocks), the other chains go on."""
+    dim, n = 5000, 3
+    s = N.DiagNutsSettings(num_chains=n, seed=8, num_tune=10, maxdepth=4)
+    state = {"calls": 0}
+
+    def flaky(chain, x):
+        state["calls"] += 1
+        if chain == 1 and state["calls"] > 40:
+            raise ValueError("unrecoverable")
+        if chain == 2 and abs(x[4999]) > 2.5:
+            raise N.RecoverableLogpError()
+        return -0.5 * float(np.dot(x, x)), -x
+    b = N.ChainBatch(s, N.LogpSpec.host_callback(dim, flaky, threads=1), n)
+    assert (b.set_position(b.init_positions_uniform(), raise_on_error=False) == 0).all()
+    pos, st = b.draw_many(16, raise_on_error=False)
+    b.close()
+    cs = st["chain_status"]
+    assert (cs[:, 0] == 0).all() and (cs[:, 2] == 0).all()
+    stop = np.flatnonzero(cs[:, 1] == 2)                           # NM_CHAIN_LOGP_FATAL in the draw where the chain stops ...
+    assert len(stop) == 1 and (st["n_steps"][stop[0] + 1:, 1] == 0).all()      # ... and nothing runs afterwards
+    assert np.isfinite(pos[:, 0]).all() and (st["n_steps"][:, 0] > 0).all()
