@@ -194,9 +194,10 @@ typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blo
 typedef void (*module_info_fn)(uint64_t out[5]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
-                         module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds), 3 cluster (dim > 4096)
+                         module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds), 3 cluster (dim > 4096), 4 cluster + KinWrap
     const bool lr = variant == 1;
     if (variant == 3) return launch_cluster(logp_kind, kind, P, grid, stream, occ);   // chains wider than one block (kern_cluster.hip)
+    if (variant == 4) return launch_cluster_kin(logp_kind, kind, P, grid, stream, occ);
     if (logp_kind == NM_LOGP_MODULE) return module && variant == 0 ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
     if (lr) {      // the kernels that carry the low-rank transformation (LrWrap<Density>, kern_lr_*.hip)
         switch (logp_kind) {
@@ -473,7 +474,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         if (cl_k > CL_MAX_K) return fail(NM_ERR_UNSUPPORTED, "dim %llu > %llu", (unsigned long long)logp->dim, (unsigned long long)(CL_SLICE * CL_MAX_K));
         if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL && logp->kind != NM_LOGP_HOST_CALLBACK)
             return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal) and for NM_LOGP_HOST_CALLBACK", (unsigned long long)logp->dim);
-        if (lr || kin) return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: Euclidean NUTS with the diagonal adaptation only", (unsigned long long)logp->dim);
+        if (lr) return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: the diagonal adaptation only", (unsigned long long)logp->dim);
         if ((cfg.dims_per_lane && cfg.dims_per_lane != 16) || (cfg.waves_per_chain && cfg.waves_per_chain != 4))
             return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096 runs on the (16 doubles, 4 waves) tiling", (unsigned long long)logp->dim);
         dpl = 16; wv = 4;
@@ -489,7 +490,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (!e) return fail(NM_ERR_HIP, "out of host memory");
     e->s = s; e->cfg = cfg; e->logp_kind = logp->kind; e->dim = logp->dim; e->n_chains = n_chains; e->dpl = dpl; e->wpc = wv;
     e->lr = lr;
-    e->variant = cl_k > 1 ? 3 : lr ? 1 : (kin ? 2 : 0);
+    e->variant = cl_k > 1 ? (kin ? 4 : 3) : lr ? 1 : (kin ? 2 : 0);
     e->cl_k = cl_k;
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;

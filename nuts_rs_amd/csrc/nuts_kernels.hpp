@@ -937,7 +937,7 @@ NM_DEV double esh_update_core(const Tile<DPL>& g, Tile<DPL>& p, double step_size
 }
 template <int DPL, int W, class Dens>
 NM_DEV double esh_update(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& g, Tile<DPL>& p, double step_size) {
-    return esh_update_core<DPL, W>(g, p, step_size, C.dim, C.red);
+    return esh_update_core<DPL, W>(g, p, step_size, C.gdim, C.red);
 }
 // leapfrog's divergence criterion (transformed_hamiltonian.rs:583-590)
 template <int DPL, int W, class Dens>
@@ -955,7 +955,7 @@ template <int DPL, int W, class Dens>
 NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
     const bool micro = C.sc.kin == NM_TRAJ_MICROCANONICAL;
     const double half = epsilon / 2.;
-    const double sqrt_n = __builtin_sqrt((double)C.dim);
+    const double sqrt_n = __builtin_sqrt((double)C.gdim);          // the chain's dim (cluster mode: not the slice's)
     Tile<DPL> x, gx;
     if (micro) {
         o.v = s.v;
@@ -2161,6 +2161,27 @@ NM_DEV void emit_divergence_vectors(ChainCtx<DPL, W, Dens>& C, int64_t start_idx
 template <int DPL, int W, class Dens>
 NM_DEV void mclmc_sample_noise(ChainCtx<DPL, W, Dens>& C) {           // array_gaussian(noise, ones) (mclmc.rs:250, :304, :313)
     block_sync(W == 1);
+#if NM_CLUSTER_MODE
+    // as in sample_velocity: every member draws the whole vector slice after slice; its own slice waits in a scratch slot
+    for (int j = 0; j < C.link.k; ++j) {
+        const int off = j * (int)C.P.cl_slice;
+        const int cnt = C.gdim - off < (int)C.P.cl_slice ? C.gdim - off : (int)C.P.cl_slice;
+        fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, cnt, C.zig, 64 * W, C.P.prof, C.prof_t);
+        if (j == C.link.member) {
+            Tile<DPL> nz;
+            const double2* s2 = C.tptr(C.l1z);
+#pragma unroll
+            for (int m = 0; m < DPL / 2; ++m) {
+                const double2 q = s2[m * 64 * W];
+                nz.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
+                nz.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
+            }
+            C.storeS(nz, slot_F(1));
+        }
+        block_sync(false);
+    }
+    return;
+#endif
     if (DPL == 2 && C.dim <= 48) fill_standard_normals(C.rng, C.l1z, C.dim, C.zig);
     else fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, C.dim, C.zig, 64 * W, C.P.prof, C.prof_t);
     block_sync(W == 1);
@@ -2171,6 +2192,9 @@ NM_DEV void mclmc_partial_refresh(ChainCtx<DPL, W, Dens>& C, Pt<DPL>& p, double 
     const double half_step = C.sc.step_size * factor / 2.0;
     const double L = C.P.s.momentum_decoherence_length;
     Tile<DPL> nz;
+#if NM_CLUSTER_MODE
+    C.loadR(nz, C.rs, slot_F(1));
+#else
     const double2* s2 = C.tptr(C.l1z);
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
@@ -2178,8 +2202,9 @@ NM_DEV void mclmc_partial_refresh(ChainCtx<DPL, W, Dens>& C, Pt<DPL>& p, double 
         nz.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
         nz.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
+#endif
     if (C.sc.kin == NM_TRAJ_MICROCANONICAL) {       // isokinetic Langevin on the unit sphere
-        const double nu = __builtin_sqrt(uniform_f64(dexpm1(2.0 * half_step / L)) / (double)C.dim);
+        const double nu = __builtin_sqrt(uniform_f64(dexpm1(2.0 * half_step / L)) / (double)C.gdim);
 #pragma unroll
         for (int k = 0; k < DPL; ++k) p.v.a[k] = __builtin_fma(nu, nz.a[k], p.v.a[k]);
         normalize_tile(p.v, C.red);
@@ -2305,7 +2330,7 @@ NM_DEV bool chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
     }
     if (fatal != NM_CHAIN_OK) {
         sc.status = fatal;
-        if (P.out_stats && tid() == 0) {
+        if (P.out_stats && NM_STAT_WRITER(C)) {
             nm_draw_stats zz = {};
             zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = fatal;
             P.out_stats[t_out * P.n_chains + chain] = zz;
@@ -2361,7 +2386,7 @@ NM_DEV bool chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
         const uint64_t ast_lr = adapt_lr(C, chain, col, is_good, x, gx);
         if (sc.lr_pending == LR_WAIT_HOST) {        // the rest of this draw happens in lr_resume
             sc.lr_row = t_out;
-            if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+            if (P.out_stats && NM_STAT_WRITER(C)) P.out_stats[t_out * P.n_chains + chain] = out;
             return false;
         }
         finish_draw_lr(C, chain, out, ast_lr, t_out);
@@ -2388,7 +2413,7 @@ NM_DEV bool chain_draw_mclmc(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t
         if (P.out_mm_mu) { C.load(sx, C.lmu); write_row(C, P.out_mm_mu, row, sx); }
     }
     sc.stats_last_id = sc.mm_id;
-    if (P.out_stats && tid() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    if (P.out_stats && NM_STAT_WRITER(C)) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
     return sc.status == NM_CHAIN_OK;
 }

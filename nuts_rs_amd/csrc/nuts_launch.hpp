@@ -92,6 +92,8 @@ hipError_t launch_mvn_prec_kin(int dpl, int w, KernelKind kind, const KParams& P
 hipError_t launch_host_cb_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 // chains wider than one block (kern_cluster.hip): dim > 4096, element-wise densities
 hipError_t launch_cluster(uint64_t logp_kind, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
+// ... with the non-Euclidean trajectory kinds / MCLMC (kern_cluster_kin.hip)
+hipError_t launch_cluster_kin(uint64_t logp_kind, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 // NM_LOGP_HOST_CALLBACK (kern_host_cb.hip)
 hipError_t launch_host_cb(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_host_cb_lr(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);

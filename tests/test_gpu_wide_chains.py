@@ -67,8 +67,7 @@ def test_wide_chain_posterior_and_unsupported(oracle):
         N.ChainBatch(N.LowRankNutsSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)
     with pytest.raises(N.NutsAmdError):
         N.ChainBatch(s, N.LogpSpec.iid_normal(70000, 0.0), 2)      # > 16 blocks per chain
-    with pytest.raises(N.NutsAmdError):
-        N.ChainBatch(N.DiagMclmcSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)    # Euclidean NUTS only
+
 
 
 def _coupled(chain, x):
@@ -82,12 +81,17 @@ def _coupled(chain, x):
     return lp, g
 
 
-@pytest.mark.parametrize("dim,kind", [(4500, "nuts"), (9000, "nuts"), (12289, "nuts")], ids=["dim4500", "dim9000", "dim12289"])
+@pytest.mark.parametrize("dim,kind", [(4500, "nuts"), (9000, "nuts"), (12289, "nuts"), (4600, "micro"), (5000, "mclmc")],
+                         ids=["dim4500", "dim9000", "dim12289", "dim4600_microcanonical", "dim5000_mclmc"])
 def test_wide_chain_host_callback_bit_exact(oracle, dim, kind):
     """Any density for a wide chain: the members of a chain share its mailbox (each writes its slice of the position, the first
     rings, each reads its slice of the gradient) — against the oracle's callback chain on the same Python function."""
     n, tune, draws = 3, 12, 20
-    s = N.DiagNutsSettings(num_chains=n, seed=dim, num_tune=tune, maxdepth=5)
+    if kind == "mclmc":
+        s = N.DiagMclmcSettings(num_chains=n, seed=dim, num_tune=tune, step_size=0.05, momentum_decoherence_length=1.0)
+    else:
+        s = N.DiagNutsSettings(num_chains=n, seed=dim, num_tune=tune, maxdepth=5,
+                               trajectory_kind=N.KineticEnergyKind.MICROCANONICAL if kind == "micro" else N.KineticEnergyKind.EUCLIDEAN)
     calls = {"n": 0}
 
     def counted(chain, x):
@@ -147,3 +151,46 @@ def test_wide_chain_host_callback_errors(oracle):
     stop = np.flatnonzero(cs[:, 1] == 2)                           # NM_CHAIN_LOGP_FATAL in the draw where the chain stops ...
     assert len(stop) == 1 and (st["n_steps"][stop[0] + 1:, 1] == 0).all()      # ... and nothing runs afterwards
     assert np.isfinite(pos[:, 0]).all() and (st["n_steps"][:, 0] > 0).all()
+
+
+KIND_CASES = [
+    # (id, settings, dim, density)
+    ("exact_dim5000", lambda n: N.DiagNutsSettings(num_chains=n, seed=71, num_tune=24, trajectory_kind=N.KineticEnergyKind.EXACT_NORMAL), 5000, "diag"),
+    ("micro_dim5000", lambda n: N.DiagNutsSettings(num_chains=n, seed=72, num_tune=24, trajectory_kind=N.KineticEnergyKind.MICROCANONICAL, maxdepth=6), 5000, "diag"),
+    ("micro_dim12289", lambda n: N.DiagNutsSettings(num_chains=n, seed=73, num_tune=20, trajectory_kind=N.KineticEnergyKind.MICROCANONICAL, maxdepth=5), 12289, "iid"),
+    ("mclmc_default_dim5000", lambda n: N.DiagMclmcSettings(num_chains=n, seed=74, num_tune=24, step_size=0.5), 5000, "iid"),
+    ("mclmc_micro_dim9000", lambda n: N.DiagMclmcSettings(num_chains=n, seed=75, num_tune=20, step_size=0.4,
+                                                          trajectory_kind=N.MclmcTrajectoryKind.MICROCANONICAL), 9000, "diag"),
+    ("mclmc_euclid_ladder_dim4500", lambda n: N.DiagMclmcSettings(num_chains=n, seed=76, num_tune=20, step_size=1.5, max_energy_error=3.0,
+                                                                  trajectory_kind=N.MclmcTrajectoryKind.EUCLIDEAN), 4500, "diag"),
+]
+
+
+@pytest.mark.parametrize("case", KIND_CASES, ids=[c[0] for c in KIND_CASES])
+def test_wide_chain_trajectory_kinds_and_mclmc_bit_exact(oracle, case):
+    """`trajectory_kind` (ExactNormal, Microcanonical) and the MCLMC sampler for chains wider than one block: the geodesic / ESH
+    leapfrogs' sums, the normalisations and the partial momentum refresh go through the same exchange (csrc/kern_cluster_kin.hip)."""
+    name, make, dim, dens = case
+    n, n_draws = 3, 36
+    s = make(n)
+    rng = np.random.default_rng(dim)
+    logp = N.LogpSpec.iid_normal(dim, 3.0) if dens == "iid" else N.LogpSpec.diag_normal(np.exp(rng.uniform(-2, 2, dim)))
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert b.blocks_per_chain() == -(-dim // 4096)
+    assert (b.set_position(x0, raise_on_error=False) == 0).all()
+    pos_a, st_a = b.draw_many(n_draws // 3)
+    pos_b, st_b = b.draw_many(n_draws - n_draws // 3)
+    pos_g, st_g = np.concatenate([pos_a, pos_b]), np.concatenate([st_a, st_b])
+    steps_g = b.counters()["total_leapfrogs"]
+    b.close()
+    cfg = oracle.gpu_cfg(256, gpu_slice=4096)
+    pos_o, st_o, steps, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, cfg, n, x0, n_draws, n_threads=8)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
+    assert steps_g == steps
+    if name.startswith("mclmc"):
+        for f in ("energy_change", "average_step_size"):
+            assert ((st_g[f] == st_o[f]) | (np.isnan(st_g[f]) & np.isnan(st_o[f]))).all(), f
+    if "ladder" in name:
+        assert (st_g["average_step_size"] < 1.5 * (1 - 1e-12)).sum() > 0        # the halve-and-retry ladder ran
