@@ -96,8 +96,11 @@ constexpr int RED_MAX_VALUES = 6;
 #ifndef NM_CLUSTER_MODE
 #define NM_CLUSTER_MODE 0
 #endif
+constexpr int CL_MAX_MEMBERS = 16;          // blocks per chain at most (dim <= 16 x 4096)
+constexpr int CL_BOX_WORDS = 6;              // u64 words of a chain's mailbox per (member, value): [2][k][V] counted + [2][k][2 V] tagged
 struct ClusterLink {
-    unsigned long long* box;     // [2][k][RED_MAX_VALUES] bit patterns of the members' partial sums (two epochs alternate)
+    unsigned long long* box;     // [2][k][RED_MAX_VALUES] bit patterns of the members' partial sums (two epochs alternate), then
+                                 // [2][k][2 RED_MAX_VALUES] tagged half-words of the same-XCD protocol
     unsigned long long* cnt;     // arrivals since the launch began
     unsigned long long epoch;    // exchanges this member has completed since the launch began
     int k, member;
@@ -110,17 +113,78 @@ NM_DEV int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 2
 
 template <int W>
 struct Reducer {
-    double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES + 1 in cluster mode)
+    double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES + 1 + 2 RED_MAX_VALUES CL_MAX_MEMBERS in cluster mode)
     int par;
 #if NM_CLUSTER_MODE
-    ClusterLink* cl;
-    NM_DEV void init(double* lds) { buf = lds; par = 0; cl = nullptr; }
+    ClusterLink cl;      // by value: a pointer to a link inside the chain's context would pin the whole context in scratch memory
+    NM_DEV void init(double* lds) { buf = lds; par = 0; }       // (cl is set by the kernel; k <= 1: no exchange)
     template <int N>
     NM_DEV void cluster_combine(double (&v)[N]) {
-        ClusterLink& L = *cl;
+        ClusterLink& L = cl;
         if (L.dead) return;
         double* lds_out = buf + 2 * RED_MAX_VALUES * W;
         constexpr unsigned long long SPIN_LIMIT = 1ull << 27;        // x s_sleep 1 (~64 cycles): several seconds
+#ifndef NM_CLUSTER_COUNTED
+        if (L.same_xcd) {
+            // All members sit on one XCD (verified when the kernel started): its L2 is their point of coherence and performs the
+            // agent-scope atomics, so no cache needs writing back or invalidating (the release / acquire pair of the general
+            // protocol below costs about as much again as the whole leapfrog).  Lock-free on top of that: every partial sum travels
+            // as two 8-byte words {tag = exchange number, 32 bits of the value} — single-copy atomic each, in any order — and a
+            // reader knows a value is this exchange's when both tags match: one store and one round of polling loads instead of
+            // store / wait / count / poll / load.  A slot is reused two exchanges later, which no member reaches before every
+            // member has read this one (it must complete the exchange in between first).
+            const unsigned k = (unsigned)L.k, total = 2u * N * k;
+            unsigned long long* tb = L.box + 2ull * k * RED_MAX_VALUES + (L.epoch & 1ull) * (2ull * k * RED_MAX_VALUES);
+            unsigned long long* stage = reinterpret_cast<unsigned long long*>(lds_out + RED_MAX_VALUES + 1);
+            const unsigned tag = (unsigned)(L.epoch + 1ull);
+            if (threadIdx.x < 64u) {
+                const unsigned l = threadIdx.x;
+                if (l < 2u * N) {
+                    double mine = v[0];
+#pragma unroll
+                    for (int i = 1; i < N; ++i) mine = (l >> 1) == (unsigned)i ? v[i] : mine;
+                    const unsigned long long bits = d2u(mine);
+                    const unsigned half = (l & 1u) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                    __hip_atomic_store(&tb[(unsigned)L.member * (2u * RED_MAX_VALUES) + l], ((unsigned long long)tag << 32) | half,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                unsigned long long spins = 0;
+                bool timed_out = false;
+                for (;;) {
+                    bool ok = true;
+                    for (unsigned w = l; w < total; w += 64u) {
+                        const unsigned m = w / (2u * N), j = w % (2u * N);
+                        const unsigned long long got = __hip_atomic_load(&tb[m * (2u * RED_MAX_VALUES) + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(got >> 32) == tag;
+                        stage[w] = got;
+                    }
+                    if (__ballot(!ok) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) { timed_out = true; break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the staged words, for the lanes that add them up
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (l == 0) lds_out[RED_MAX_VALUES] = timed_out ? 1.0 : 0.0;
+                if (l < (unsigned)N) {                                       // the k partials in member order
+                    double t = 0.0;
+                    for (unsigned m = 0; m < k; ++m) {
+                        const unsigned long long lo = stage[m * 2u * N + 2u * l], hi = stage[m * 2u * N + 2u * l + 1u];
+                        const double x = u2d((hi << 32) | (lo & 0xffffffffull));
+                        t = m == 0 ? x : t + x;
+                    }
+                    lds_out[l] = t;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = lds_out[i];
+            if (lds_out[RED_MAX_VALUES] != 0.0) L.dead = 1;
+            __syncthreads();
+            L.epoch += 1ull;
+            return;
+        }
+#endif
         if (threadIdx.x == 0) {
             unsigned long long spins = 0;
             bool timed_out = false;
@@ -184,7 +248,7 @@ struct Reducer {
             par ^= 1;
         }
 #if NM_CLUSTER_MODE
-        if (cl && cl->k > 1) cluster_combine<N>(v);
+        if (cl.k > 1) cluster_combine<N>(v);
 #endif
     }
     NM_DEV double sum(double x) { double v[1] = {x}; sum_n(v); return v[0]; }

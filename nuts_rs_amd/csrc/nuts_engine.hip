@@ -567,9 +567,9 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     E_TRY(hipMemsetAsync(e->d_svec, 0, svec_bytes, e->stream));
     E_TRY(hipMalloc(&e->d_sc, n_chains * cl_k * sizeof(ChainScalars)));
     if (cl_k > 1) {
-        E_TRY(hipMalloc(&e->d_cl_box, e->n_clusters * 2 * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
+        E_TRY(hipMalloc(&e->d_cl_box, e->n_clusters * CL_BOX_WORDS * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
         E_TRY(hipMalloc(&e->d_cl_cnt, e->n_clusters * sizeof(unsigned long long)));
-        E_TRY(hipMemset(e->d_cl_box, 0, e->n_clusters * 2 * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
+        E_TRY(hipMemset(e->d_cl_box, 0, e->n_clusters * CL_BOX_WORDS * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
     }
     E_TRY(hipMalloc(&e->d_prof, 32 * sizeof(unsigned long long)));
     E_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
@@ -742,7 +742,10 @@ extern "C" nm_status nm_engine_set_positions_masked(nm_engine* e, const double* 
         P.init_mask = e->d_init_mask;
     }
     e->cb_active.store(1, std::memory_order_release);
-    if (e->cl_k > 1) HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));   // the clusters' arrival counters
+    if (e->cl_k > 1) {      // the clusters' arrival counters, and their mailboxes (the tags of the last launch must not match this one's)
+        HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_cl_box, 0, e->n_clusters * CL_BOX_WORDS * e->cl_k * RED_MAX_VALUES * sizeof(unsigned long long), e->stream));
+    }
     HIP_TRY(launch(e->logp_kind, e->dpl, e->wpc, K_INIT, P, e->n_waves, e->stream, nullptr, e->module_launch, e->variant));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->cb_active.store(0, std::memory_order_release);
@@ -1145,7 +1148,10 @@ extern "C" nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, con
     P.out_mm_eigvals = out->d_mass_matrix_eigvals;
     e->cb_active.store(1, std::memory_order_release);   // NM_LOGP_HOST_CALLBACK: the service threads answer until the next synchronize
     if (e->lr) return lr_draw(e, n_draws, P);           // synchronous: the estimator rounds need the host between launches
-    if (e->cl_k > 1) HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));
+    if (e->cl_k > 1) {
+        HIP_TRY(hipMemsetAsync(e->d_cl_cnt, 0, e->n_clusters * sizeof(unsigned long long), e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_cl_box, 0, e->n_clusters * CL_BOX_WORDS * e->cl_k * RED_MAX_VALUES * sizeof(unsigned long long), e->stream));
+    }
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     // small chains, many of them: the several-chains-per-wavefront kernels compute the same draws and statistics
     if (e->group_grid) {

@@ -501,7 +501,7 @@ struct HostCb {
     int goff = 0, member = 0;
     uint64_t next_seq = 0;
     template <int W>
-    NM_DEV void init_slice(const double*, int, int, int goff_, Reducer<W>& R) { goff = goff_; member = R.cl ? R.cl->member : 0; }
+    NM_DEV void init_slice(const double*, int, int, int goff_, Reducer<W>& R) { goff = goff_; member = R.cl.member; }
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) {
 #pragma unroll
@@ -611,7 +611,7 @@ struct BlockShared {      // LDS of one block (one block = W waves = one residen
     uint32_t rng_cache[RNG_CACHE_WORDS];
     double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
     double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
-    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES + 1 : 0)];
+    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES + 1 + 2 * RED_MAX_VALUES * CL_MAX_MEMBERS : 0)];
     double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
     double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
     // Between trees both arrays are free: the momentum refresh uses l1_v as its ChaCha word buffer (hence the 72
@@ -640,7 +640,6 @@ struct ChainCtx {
     int dim;            // elements this block holds (the chain's dim; in cluster mode this member's slice)
     int gdim;           // the chain's dim
     int goff;           // cluster mode: index of this member's first element in the chain's vectors, else 0
-    ClusterLink link;   // cluster mode: this chain's mailbox
     int maxdepth_cfg;
     ChainScalars& sc;   // LDS
     unsigned long long prof_t;
@@ -712,7 +711,7 @@ struct ChainCtx {
 
 // the thread that writes a draw's nm_draw_stats row (cluster mode: of the chain's first member)
 #if NM_CLUSTER_MODE
-#define NM_STAT_WRITER(C) (tid() == 0 && (C).link.member == 0)
+#define NM_STAT_WRITER(C) (tid() == 0 && (C).red.cl.member == 0)
 #else
 #define NM_STAT_WRITER(C) (tid() == 0)
 #endif
@@ -722,8 +721,8 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.dim = (int)P.dim; C.gdim = (int)P.dim; C.goff = 0;
 #if NM_CLUSTER_MODE
     // `chain` arrives as the sub-chain index chain * cl_k + member (its own persistent vectors and copy of the scalars);
-    // C.link.{box, cnt, k, member, epoch} were set by the kernel
-    C.goff = C.link.member * (int)P.cl_slice;
+    // C.red.cl.{box, cnt, k, member, epoch} were set by the kernel
+    C.goff = C.red.cl.member * (int)P.cl_slice;
     C.dim = (int)(P.dim - (uint64_t)C.goff < P.cl_slice ? P.dim - (uint64_t)C.goff : P.cl_slice);
 #endif
     C.maxdepth_cfg = (int)P.s.maxdepth;
@@ -754,7 +753,6 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     }
     C.red.init(sh.red);
 #if NM_CLUSTER_MODE
-    C.red.cl = &C.link;
 #endif
     C.rng.init(C.sc.key, C.sc.rng_pos, sh.rng_cache);
 #if NM_CLUSTER_MODE
@@ -1147,11 +1145,11 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
 #if NM_CLUSTER_MODE
     // every member draws the chain's whole vector, slice after slice in stream order (the members' streams stay identical),
     // and keeps its own slice
-    for (int j = 0; j < C.link.k; ++j) {
+    for (int j = 0; j < C.red.cl.k; ++j) {
         const int off = j * (int)C.P.cl_slice;
         const int cnt = C.gdim - off < (int)C.P.cl_slice ? C.gdim - off : (int)C.P.cl_slice;
         fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, cnt, C.zig, 64 * W, C.P.prof, C.prof_t);
-        if (j == C.link.member) {
+        if (j == C.red.cl.member) {
             const double2* s2 = C.tptr(C.l1z);
 #pragma unroll
             for (int m = 0; m < DPL / 2; ++m) {
@@ -2163,11 +2161,11 @@ NM_DEV void mclmc_sample_noise(ChainCtx<DPL, W, Dens>& C) {           // array_g
     block_sync(W == 1);
 #if NM_CLUSTER_MODE
     // as in sample_velocity: every member draws the whole vector slice after slice; its own slice waits in a scratch slot
-    for (int j = 0; j < C.link.k; ++j) {
+    for (int j = 0; j < C.red.cl.k; ++j) {
         const int off = j * (int)C.P.cl_slice;
         const int cnt = C.gdim - off < (int)C.P.cl_slice ? C.gdim - off : (int)C.P.cl_slice;
         fill_standard_normals_bulk<(DPL * W + 1 < 17 ? DPL * W + 1 : 17)>(C.rng, reinterpret_cast<uint32_t*>(C.l1v), C.l1z, cnt, C.zig, 64 * W, C.P.prof, C.prof_t);
-        if (j == C.link.member) {
+        if (j == C.red.cl.member) {
             Tile<DPL> nz;
             const double2* s2 = C.tptr(C.l1z);
 #pragma unroll
@@ -2665,16 +2663,16 @@ constexpr int draw_min_waves() {
 template <int W>
 NM_DEV ClusterLink cluster_start(const KParams& P, double* red_lds, unsigned cl_k, unsigned cl_member, uint64_t cl_id) {
     ClusterLink L;
-    L.box = P.cl_box + cl_id * 2ull * cl_k * RED_MAX_VALUES; L.cnt = P.cl_cnt + cl_id;
+    L.box = P.cl_box + cl_id * (unsigned long long)CL_BOX_WORDS * cl_k * RED_MAX_VALUES; L.cnt = P.cl_cnt + cl_id;
     L.k = (int)cl_k; L.member = (int)cl_member; L.epoch = 0ull; L.same_xcd = 0; L.dead = 0;
     Reducer<W> r;
     r.init(red_lds);
-    r.cl = &L;
+    r.cl = L;
     const double x = (double)xcc_id();
     double v[2] = {x, x * x};
     r.template cluster_combine<2>(v);
-    L.same_xcd = ((double)cl_k * v[1] == v[0] * v[0]) ? 1 : 0;       // sum of squares = square of the sum / k  <=>  all equal
-    return L;
+    r.cl.same_xcd = ((double)cl_k * v[1] == v[0] * v[0]) ? 1 : 0;    // sum of squares = square of the sum / k  <=>  all equal
+    return r.cl;
 }
 #endif
 
@@ -2690,7 +2688,7 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
     ClusterLink cl_link = cluster_start<W>(P, sh.red, cl_k, cl_member, cl_id);
     for (uint64_t chain = cl_id; chain < P.n_chains; chain += n_clusters) {
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
-        C.link = cl_link;
+        C.red.cl = cl_link;
         const uint64_t sci = chain * cl_k + cl_member;
         ctx_begin(C, sh, sci, blockIdx.x);
         if (C.sc.status == NM_CHAIN_OK) {
@@ -2701,12 +2699,12 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
             }
             for (uint64_t t = 0; t < P.n_draws; ++t) {
                 chain_draw(C, chain, t);
-                if (C.link.dead) C.sc.status = NM_CHAIN_LOGP_FATAL;      // an exchange timed out: stop instead of hanging
+                if (C.red.cl.dead) C.sc.status = NM_CHAIN_LOGP_FATAL;      // an exchange timed out: stop instead of hanging
                 if (C.sc.status != NM_CHAIN_OK) break;
             }
         }
         ctx_end(C, sci);
-        cl_link.epoch = C.link.epoch; cl_link.dead = C.link.dead;
+        cl_link.epoch = C.red.cl.epoch; cl_link.dead = C.red.cl.dead;
         __syncthreads();
     }
     return;
@@ -2756,7 +2754,7 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
         if (P.init_mask && !P.init_mask[x0_chain]) continue;
         const uint64_t chain = x0_chain * cl_k + cl_member;                 // the sub-chain: this member's vectors and scalars
         ChainCtx<DPL, W, Dens> C(P, sh.sc[W == 1 ? 0 : wave_id()]);
-        C.link = cl_link;
+        C.red.cl = cl_link;
         ctx_begin(C, sh, chain, blockIdx.x);
         ChainScalars& sc = C.sc;
 #else
@@ -2827,12 +2825,12 @@ __global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
             }
         }
 #if NM_CLUSTER_MODE
-        if (C.link.dead) status = NM_CHAIN_LOGP_FATAL;
+        if (C.red.cl.dead) status = NM_CHAIN_LOGP_FATAL;
 #endif
         sc.status = status;
         ctx_end(C, chain);
 #if NM_CLUSTER_MODE
-        cl_link.epoch = C.link.epoch; cl_link.dead = C.link.dead;
+        cl_link.epoch = C.red.cl.epoch; cl_link.dead = C.red.cl.dead;
 #endif
         __syncthreads();
     }
