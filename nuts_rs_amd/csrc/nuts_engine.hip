@@ -20,6 +20,12 @@ using namespace nm;
 
 // the matrix-core kernel for shared matrices lives in its own (tile-mode) translation unit: kern_tile_mvn_prec.hip.
 // POD mirror of nm::tile::TileMats (nuts_tile.hpp) — that header switches the whole TU to tile mode, so it is not included here.
+#ifndef NM_TILE_CHAINS
+#define NM_TILE_CHAINS 16    // (nuts_tile.hpp: chains per block of the matrix-core kernels; tuning builds pass both to all units)
+#endif
+#ifndef NM_TILE_OCC
+#define NM_TILE_OCC 1
+#endif
 namespace nm { namespace tile { struct TileMats { const double *ut, *u, *p; int dim, rank, dim_kp, rank_kp, dim_st, rank_st; }; } }
 namespace nm { hipError_t launch_tile_mvn_prec(int dpl, int query, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream, int* occ); }
 namespace nm { hipError_t launch_tile_mvn_diag(int dpl, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream); }
@@ -555,11 +561,11 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     {   // the matrix-core kernel's grid: 16-chain tiles on resident blocks (one 16-wave block fills a CU's wave slots)
         int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
-        const uint64_t n_tiles = (n_chains + 15) / 16;
-        e->tile_grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(cus > 0 ? cus : 1));
+        const uint64_t n_tiles = (n_chains + NM_TILE_CHAINS - 1) / NM_TILE_CHAINS;
+        e->tile_grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(cus > 0 ? cus : 1) * NM_TILE_OCC);
     }
     size_t scratch_slots = e->n_waves > e->group_grid ? e->n_waves : e->group_grid;
-    if (logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1) scratch_slots = std::max<size_t>(scratch_slots, (size_t)e->tile_grid * 16);
+    if (logp->kind == NM_LOGP_MVN_PREC && cfg.chain_tiles != 1) scratch_slots = std::max<size_t>(scratch_slots, (size_t)e->tile_grid * NM_TILE_CHAINS);
     const size_t svec_bytes = scratch_slots * nsslot * dpad * sizeof(double);
     E_TRY(hipMalloc(&e->d_pvec, pvec_bytes));
     E_TRY(hipMemsetAsync(e->d_pvec, 0, pvec_bytes, e->stream));

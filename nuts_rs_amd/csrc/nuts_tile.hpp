@@ -34,7 +34,14 @@
 namespace nm {
 namespace tile {
 
-constexpr int TC = 16;              // chains = wavefronts per block
+#ifndef NM_TILE_CHAINS
+#define NM_TILE_CHAINS 16    // chains = wavefronts per block: 16 (all 16 columns of the f64 MFMA carry a chain) or 8 (half of them; tuning builds)
+#endif
+#ifndef NM_TILE_OCC
+#define NM_TILE_OCC 1        // blocks per compute unit the register allocation leaves room for
+#endif
+constexpr int TC = NM_TILE_CHAINS;  // chains = wavefronts per block
+static_assert(TC == 16 || TC == 8, "a column tile holds 16 or 8 chains");
 constexpr int TD = 256;             // rows of a column tile: dim and rank <= 256
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -60,7 +67,7 @@ struct TileShared {
 };
 // element (row, chain column) of a column tile: 16 doubles per row, columns xor-swizzled so that a wavefront writing its
 // own column (rows 2 t, 2 t + 1 per lane) spreads over the banks, while the B-operand read of a row stays a permutation
-NM_DEV int taddr(int row, int c) { return row * TC + (c ^ ((row >> 1) & 15)); }
+NM_DEV int taddr(int row, int c) { return row * TC + ((c ^ (row >> 1)) & (TC - 1)); }     // (c may be an MFMA column >= TC: it mirrors column c - TC)
 
 NM_DEV void tile_barrier() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
@@ -99,7 +106,7 @@ NM_DEV void store_stripe(double* buf, int s, v4d acc) {
 // the oracle's `sc[k] *= vals[k] - 1` (apply_lowrank_transform, cpu_math.rs:360-364)
 NM_DEV void store_stripe_scaled(double* buf, int s, v4d acc, const TileShared& T) {
     const int l = lane_id(), g = l >> 4, c = l & 15;
-    const double* scale = T.scale[T.which[c] & 1];
+    const double* scale = T.scale[T.which[c & (TC - 1)] & 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int k = 16 * s + g + 4 * r; buf[taddr(k, c)] = acc[r] * scale[k]; }
 }
@@ -246,7 +253,7 @@ struct TileMvnPrec {
 // the kernel: block b owns chain tiles b, b + grid, ...; wavefront w of a tile owns chain 16 tile + w
 // ---------------------------------------------------------------------------------------------
 template <int DPL, class Dens>
-__global__ __launch_bounds__(64 * TC) void nuts_tile_draw_kernel(const KParams P, const TileMats M) {
+__global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_draw_kernel(const KParams P, const TileMats M) {
     __shared__ BlockShared<DPL, 1, Dens> sh[TC];
     __shared__ TileShared T;
     dm_init_lds();
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(64 * TC) void nuts_tile_draw_kernel(const KParams P
 // tiles), ONE rendezvous per density evaluation.  Whatever evaluates the density — leapfrogs, the step-size search inside the
 // adaptation, the recomputation of the chosen point — is a round; a chain that has finished its draw attends with an idle column.
 template <int DPL, class Dens>
-__global__ __launch_bounds__(64 * TC) void nuts_tile_diag_kernel(const KParams P, const TileMats M) {
+__global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_diag_kernel(const KParams P, const TileMats M) {
     __shared__ BlockShared<DPL, 1, Dens> sh[TC];
     __shared__ TileShared T;
     dm_init_lds();
