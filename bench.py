@@ -62,7 +62,7 @@ def parse():
     p.add_argument("--dims-per-lane", type=int, default=0)
     p.add_argument("--no-record", action="store_true", help="do not record draws / statistics in the timed launches (comparison only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-chains", type=int, default=0, help="chains of the bounded CPU sample (0 = 2 per host core)")
+    p.add_argument("--cpu-chains", type=int, default=0, help="chains of the bounded CPU sample (0 = 8 per usable host core)")
     p.add_argument("--pmc", default="live", choices=["live", "profile", "off"],
                    help="HBM traffic of the timed launch: live rocprofv3 --pmc passes | latest committed profile, scaled | none")
     p.add_argument("--pmc-timeout", type=float, default=150.0)
@@ -194,8 +194,8 @@ def cpu_baseline(args, cores):
     same density / settings / seeds, a bounded sample of the same workload.  Labelled "port": it is NOT nuts-rs itself
     (no Rust toolchain in this image; `cargo` is probed and reported)."""
     from oracle import oracle as O
-    n = args.cpu_chains or 2 * cores
-    draws = 100
+    n = args.cpu_chains or 8 * cores        # ~20 CPU-seconds at 16 threads: 400 warm-up + 400 timed draws per chain
+    draws = 400
     s = O.default_settings(seed=args.seed, num_tune=args.num_tune, num_chains=n)
     x0 = O.init_positions_uniform(args.seed, 0, n, args.dim)
     r = O.run_wall(s, O.LOGP_IID_NORMAL, args.dim, [3.0], O.ref_cfg(), n, x0, args.num_tune, draws, n_threads=cores)

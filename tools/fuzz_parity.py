@@ -29,11 +29,11 @@ def make_case(rng, scale=False):
     elif dens == "funnel":
         dim = int(rng.choice([2, 5, 11, 40, 101, 130, 300]))
     else:
-        dim = int(rng.choice([1, 2, 7, 33, 64, 65, 128, 129, 257, 511, 1024, 1500, 2048, 3000, 4096, 5000]))
+        dim = int(rng.choice([1, 2, 7, 33, 64, 65, 128, 129, 257, 511, 1024, 1500, 2048, 3000, 4096, 5000, 9000]))
     sampler = rng.choice(["nuts", "exact", "micro", "mclmc"], p=[0.5, 0.15, 0.15, 0.2])
     if sampler in ("micro", "mclmc") and dim < 2:
         dim = 2
-    if dim > 4096 and (dens not in ("iid", "diag") or sampler != "nuts"):
+    if dim > 4096 and dens not in ("iid", "diag"):
         dim = 4096
     n = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
     if scale:
