@@ -367,8 +367,15 @@ nm_status nm_engine_draw_ex_async(nm_engine* e, uint64_t n_draws, const nm_draw_
 nm_status nm_engine_draw_async(nm_engine* e, uint64_t n_draws, double* d_positions, nm_draw_stats* d_stats);
 nm_status nm_engine_synchronize(nm_engine* e);
 
-/* Convenience: run n_draws and copy results to host buffers ([n_draws][n_chains][dim] / [n_draws][n_chains]). */
+/* Run n_draws and deliver the results to host buffers ([n_draws][n_chains][dim] / [n_draws][n_chains]) — the shape of the
+ * reference's `Chain::draw() -> (Box<[f64]>, Stats)` consumers.  The launch is cut into chunks that pass through two sets of
+ * device staging buffers: the kernel of chunk i + 1 runs while chunk i crosses PCIe on a copy stream (same draws as one launch).
+ * The copies reach the PCIe rate when the destination is pinned (nm_host_register) or has been written before; fresh pageable
+ * memory is bound by its page faults. */
 nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats);
+/* Pin / unpin a host array (hipHostRegister) that *_to_host calls will fill repeatedly. */
+nm_status nm_host_register(void* h_ptr, uint64_t bytes);
+nm_status nm_host_unregister(void* h_ptr);
 
 /* nm_engine_draw_ex with HOST destinations: the pointers of `h_out` are host arrays of the same shapes; event
  * rows that were not written read as NaN. */

@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "NM_OK", 1: "NM_ERR_INVALID_ARG", 2: "NM_ERR_NO_DEVICE", 3: "
 ABI_SYMBOLS = [
     "nm_settings_default", "nm_engine_config_default", "nm_engine_create", "nm_engine_destroy",
     "nm_engine_set_positions", "nm_init_positions_uniform", "nm_engine_draw", "nm_engine_draw_async",
-    "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
+    "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_host_register", "nm_host_unregister", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
     "nm_engine_draw_ex_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_blocks_per_chain", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
@@ -137,6 +137,8 @@ def load():
     L.nm_engine_draw_async.argtypes = [vp, u64, vp, vp]
     L.nm_engine_synchronize.argtypes = [vp]
     L.nm_engine_draw_to_host.argtypes = [vp, u64, vp, vp]
+    L.nm_host_register.argtypes = [vp, u64]
+    L.nm_host_unregister.argtypes = [vp]
     L.nm_engine_draw_ex.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]
     L.nm_engine_draw_ex_async.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]
     L.nm_engine_draw_ex_to_host.argtypes = [vp, u64, C.POINTER(NmDrawOutputs)]

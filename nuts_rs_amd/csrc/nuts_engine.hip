@@ -345,6 +345,8 @@ struct nm_engine {
     uint8_t* d_init_mask = nullptr;
     void* staging[11] = {};                 // device staging of the *_to_host calls, one per output array, grow-only
     size_t staging_bytes[11] = {};
+    hipStream_t copy_stream = nullptr;      // device -> host copies of the *_to_host calls, overlapping the next chunk's kernel
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr};
     void* module_handle = nullptr;          // NM_LOGP_MODULE: dlopen handle and its launch entry
     module_launch_fn module_launch = nullptr;
     int module_group_lanes = 0;             // lanes per chain of the module's group form (0: it has none)
@@ -402,6 +404,8 @@ static void engine_free(nm_engine* e) {
     if (e->cb_mail) (void)hipHostFree(e->cb_mail);
     if (e->module_handle) dlclose(e->module_handle);
     for (void* q : e->staging) if (q) (void)hipFree(q);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (hipEvent_t q : e->ev_chunk) if (q) (void)hipEventDestroy(q);
     if (e->d_pvec) (void)hipFree(e->d_pvec);
     if (e->d_svec) (void)hipFree(e->d_svec);
     if (e->d_sc) (void)hipFree(e->d_sc);
@@ -1199,58 +1203,105 @@ extern "C" nm_status nm_engine_draw(nm_engine* e, uint64_t n_draws, double* d_po
     return nm_engine_synchronize(e);
 }
 
+// Draws delivered to HOST memory: the launch is cut into chunks of draws that go through two sets of device staging buffers —
+// while chunk i travels to the host on the copy stream, the kernel of chunk i + 1 already runs (the draws of a chain do not
+// depend on where a launch is cut: same results as one launch).  Device staging stays bounded (2 x <= 256 MiB per output array)
+// whatever n_draws is.  The copy itself runs at the PCIe rate when the destination is pinned / registered memory
+// (nm_host_register) or has been touched before; first-touch pageable memory is bound by the page faults (~17 GB/s).
 extern "C" nm_status nm_engine_draw_ex_to_host(nm_engine* e, uint64_t n_draws, const nm_draw_outputs* h_out) {
     if (!e) return fail(NM_ERR_INVALID_ARG, "null engine");
     if (!h_out) return fail(NM_ERR_INVALID_ARG, "null nm_draw_outputs");
+    if (n_draws == 0) return NM_OK;
     HIP_TRY(hipSetDevice(e->device));
-    const size_t vec_bytes = (size_t)n_draws * e->n_chains * e->dim * sizeof(double);
-    const size_t st_bytes = (size_t)n_draws * e->n_chains * sizeof(nm_draw_stats);
-    // (host destination, device slot, bytes, is an event array)
-    nm_draw_outputs d = {};
-    struct Item { void* host; void** dev; size_t bytes; bool event; };
-    Item items[] = {
-        {h_out->d_positions, (void**)&d.d_positions, vec_bytes, false},
-        {h_out->d_stats, (void**)&d.d_stats, st_bytes, false},
-        {h_out->d_gradient, (void**)&d.d_gradient, vec_bytes, false},
-        {h_out->d_transformed_position, (void**)&d.d_transformed_position, vec_bytes, false},
-        {h_out->d_transformed_gradient, (void**)&d.d_transformed_gradient, vec_bytes, false},
-        {h_out->d_mass_matrix_inv, (void**)&d.d_mass_matrix_inv, vec_bytes, true},
-        {h_out->d_transformation_mu, (void**)&d.d_transformation_mu, vec_bytes, true},
-        {h_out->d_divergence_start, (void**)&d.d_divergence_start, vec_bytes, true},
-        {h_out->d_divergence_start_gradient, (void**)&d.d_divergence_start_gradient, vec_bytes, true},
-        {h_out->d_divergence_end, (void**)&d.d_divergence_end, vec_bytes, true},
-        {h_out->d_mass_matrix_eigvals, (void**)&d.d_mass_matrix_eigvals, vec_bytes, true},
+    const size_t vec_row = (size_t)e->n_chains * e->dim * sizeof(double);          // bytes of one draw of all chains
+    const size_t st_row = (size_t)e->n_chains * sizeof(nm_draw_stats);
+    // (host destination, bytes per draw, is an event array)
+    struct Item { char* host; size_t row; bool event; };
+    const Item items[11] = {
+        {(char*)h_out->d_positions, vec_row, false},
+        {(char*)h_out->d_stats, st_row, false},
+        {(char*)h_out->d_gradient, vec_row, false},
+        {(char*)h_out->d_transformed_position, vec_row, false},
+        {(char*)h_out->d_transformed_gradient, vec_row, false},
+        {(char*)h_out->d_mass_matrix_inv, vec_row, true},
+        {(char*)h_out->d_transformation_mu, vec_row, true},
+        {(char*)h_out->d_divergence_start, vec_row, true},
+        {(char*)h_out->d_divergence_start_gradient, vec_row, true},
+        {(char*)h_out->d_divergence_end, vec_row, true},
+        {(char*)h_out->d_mass_matrix_eigvals, vec_row, true},
     };
-    nm_status st = NM_OK;
-    int idx = 0;
-    for (Item& it : items) {
-        const int k = idx++;
-        if (!it.host || !it.bytes) continue;
-        hipError_t er = hipSuccess;
-        if (e->staging_bytes[k] < it.bytes) {              // a controller calls this once per chunk of draws: keep the buffers
+    constexpr size_t STAGE_CAP = 256ull << 20;
+    const uint64_t chunk = std::min<uint64_t>(n_draws, std::max<uint64_t>(1, STAGE_CAP / std::max(vec_row, st_row)));
+    const uint64_t n_chunks = (n_draws + chunk - 1) / chunk;
+    const int n_sets = n_chunks > 1 ? 2 : 1;
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) if (!e->ev_chunk[q]) HIP_TRY(hipEventCreateWithFlags(&e->ev_chunk[q], hipEventDisableTiming));
+    for (int k = 0; k < 11; ++k) {
+        if (!items[k].host) continue;
+        const size_t need = (size_t)n_sets * chunk * items[k].row;
+        if (e->staging_bytes[k] < need) {              // a controller calls this once per chunk of draws: keep the buffers
             if (e->staging[k]) (void)hipFree(e->staging[k]);
             e->staging[k] = nullptr; e->staging_bytes[k] = 0;
-            er = hipMalloc(&e->staging[k], it.bytes);
-            if (er == hipSuccess) e->staging_bytes[k] = it.bytes;
+            const hipError_t er = hipMalloc(&e->staging[k], need);
+            if (er != hipSuccess) return fail(NM_ERR_HIP, "device staging buffer of %zu bytes: %s", need, hipGetErrorString(er));
+            e->staging_bytes[k] = need;
         }
-        *it.dev = e->staging[k];
-        // rows a chain never writes (it stopped mid-launch, or the event did not happen) must not show an earlier call's
-        // data: vectors read as NaN (all-ones), statistics as zeros
-        if (er == hipSuccess) er = hipMemsetAsync(*it.dev, k == 1 ? 0x00 : 0xFF, it.bytes, e->stream);
-        if (er != hipSuccess) { *it.dev = nullptr; st = fail(NM_ERR_HIP, "device buffer of %zu bytes: %s", it.bytes, hipGetErrorString(er)); break; }
     }
-    if (st == NM_OK) st = nm_engine_draw_ex(e, n_draws, &d);
-    for (Item& it : items) {
-        if (st == NM_OK && *it.dev && hipMemcpy(it.host, *it.dev, it.bytes, hipMemcpyDeviceToHost) != hipSuccess)
-            st = fail(NM_ERR_HIP, "copy of a result array to the host failed");
+    auto stage = [&](int k, uint64_t i) { return (char*)e->staging[k] + (size_t)(n_sets == 2 ? (i & 1) : 0) * chunk * items[k].row; };
+    auto launch_chunk = [&](uint64_t i) -> nm_status {
+        const uint64_t c = std::min<uint64_t>(chunk, n_draws - i * chunk);
+        void* dev[11] = {};
+        for (int k = 0; k < 11; ++k) {
+            if (!items[k].host) continue;
+            dev[k] = stage(k, i);
+            // rows a chain never writes (it stopped mid-launch, or the event did not happen) must not show an earlier chunk's
+            // data: vectors read as NaN (all-ones), statistics as zeros
+            HIP_TRY(hipMemsetAsync(dev[k], k == 1 ? 0x00 : 0xFF, (size_t)c * items[k].row, e->stream));
+        }
+        nm_draw_outputs d = {};
+        d.d_positions = (double*)dev[0]; d.d_stats = (nm_draw_stats*)dev[1]; d.d_gradient = (double*)dev[2];
+        d.d_transformed_position = (double*)dev[3]; d.d_transformed_gradient = (double*)dev[4];
+        d.d_mass_matrix_inv = (double*)dev[5]; d.d_transformation_mu = (double*)dev[6];
+        d.d_divergence_start = (double*)dev[7]; d.d_divergence_start_gradient = (double*)dev[8]; d.d_divergence_end = (double*)dev[9];
+        d.d_mass_matrix_eigvals = (double*)dev[10];
+        const nm_status st = nm_engine_draw_ex_async(e, c, &d);     // (synchronous with the low-rank adaptation: estimator rounds)
+        if (st != NM_OK) return st;
+        HIP_TRY(hipEventRecord(e->ev_chunk[i & 1], e->stream));
+        return NM_OK;
+    };
+    nm_status st = launch_chunk(0);
+    for (uint64_t i = 0; i < n_chunks && st == NM_OK; ++i) {
+        if (i + 1 < n_chunks) st = launch_chunk(i + 1);          // runs while chunk i is copied
+        if (st != NM_OK) break;
+        const uint64_t c = std::min<uint64_t>(chunk, n_draws - i * chunk);
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_chunk[i & 1], 0));
+        for (int k = 0; k < 11; ++k)
+            if (items[k].host)
+                HIP_TRY(hipMemcpyAsync(items[k].host + (size_t)i * chunk * items[k].row, stage(k, i), (size_t)c * items[k].row, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));           // (its staging set is free again before chunk i + 2 is launched)
     }
+    const nm_status st_sync = nm_engine_synchronize(e);
     if (st != NM_OK) return st;
+    if (st_sync != NM_OK) return st_sync;
     // surface chain failures the way Chain::draw's Result does
     std::vector<ChainScalars> sc(e->n_chains);
     HIP_TRY(read_scalars(e, sc.data()));
     uint64_t failed = 0;
     for (auto& q : sc) if (q.status != NM_CHAIN_OK) failed++;
     if (failed) return fail(NM_ERR_LOGP_FAILURE, "%llu chain(s) stopped with an error status", (unsigned long long)failed);
+    return NM_OK;
+}
+// Pin a host array for the *_to_host calls (hipHostRegister): the copies then run at the PCIe rate, straight into it.
+extern "C" nm_status nm_host_register(void* h_ptr, uint64_t bytes) {
+    if (!h_ptr || !bytes) return fail(NM_ERR_INVALID_ARG, "null / empty host range");
+    nm_status st = ensure_device(-1);
+    if (st != NM_OK) return st;
+    HIP_TRY(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return NM_OK;
+}
+extern "C" nm_status nm_host_unregister(void* h_ptr) {
+    if (!h_ptr) return fail(NM_ERR_INVALID_ARG, "null host pointer");
+    HIP_TRY(hipHostUnregister(h_ptr));
     return NM_OK;
 }
 extern "C" nm_status nm_engine_draw_to_host(nm_engine* e, uint64_t n_draws, double* h_positions, nm_draw_stats* h_stats) {

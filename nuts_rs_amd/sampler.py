@@ -384,12 +384,20 @@ class ChainBatch:
                          float(r["step_size"]), int(r["n_steps"])) for r in st[0]]
         return pos[0], prog
 
-    def draw_many(self, n_draws, positions=True, stats=True, raise_on_error=True):
+    def draw_many(self, n_draws, positions=True, stats=True, raise_on_error=True, out=None):
         """n_draws draws of every chain; returns host arrays ([n_draws, n_chains, dim], stats [n_draws, n_chains]).
         Chains that stopped with an error (or never started: BadInitGrad) raise NM_ERR_LOGP_FAILURE after the healthy
-        chains' results are in the arrays; raise_on_error=False returns them anyway (rows of failed chains are unwritten)."""
-        pos = np.empty((n_draws, self.n_chains, self.logp.dim)) if positions else None
-        st = np.zeros((n_draws, self.n_chains), dtype=STATS_DTYPE) if stats else None
+        chains' results are in the arrays; raise_on_error=False returns them anyway (rows of failed chains are unwritten).
+        `out=(positions, stats)`: arrays of those shapes to fill (reused arrays are copied into at the PCIe rate; fresh ones
+        are bound by their page faults)."""
+        if out is not None:
+            pos, st = out
+            assert pos is None or (pos.shape == (n_draws, self.n_chains, self.logp.dim) and pos.dtype == np.float64 and pos.flags.c_contiguous)
+            assert st is None or (st.shape == (n_draws, self.n_chains) and st.dtype == STATS_DTYPE and st.flags.c_contiguous)
+            positions, stats = pos is not None, st is not None
+        else:
+            pos = np.empty((n_draws, self.n_chains, self.logp.dim)) if positions else None
+            st = np.zeros((n_draws, self.n_chains), dtype=STATS_DTYPE) if stats else None
         rc = _lib.load().nm_engine_draw_to_host(self._h, n_draws, pos.ctypes.data if positions else None,
                                                 st.ctypes.data if stats else None)
         if rc != _lib.NM_ERR_LOGP_FAILURE or raise_on_error:

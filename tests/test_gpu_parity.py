@@ -653,3 +653,42 @@ def test_late_blocks_match_oracle_and_are_deterministic(oracle, dens, dim, n):
                                             x0[c:c + 1], draws, chain_offset=c, n_threads=1)
         assert failed == 0
         assert_bit_exact(runs[0][0][:, c:c + 1], runs[0][1][:, c:c + 1], pos_o, st_o)
+
+
+def test_to_host_pipeline_equals_device_buffers(oracle):
+    """`nm_engine_draw_to_host` cuts a launch into chunks that cross PCIe while the next chunk's kernel runs: the same draws
+    as one launch into device buffers (several chunks, a partial last one), also into reused and into pinned host arrays."""
+    import torch
+    from nuts_rs_amd import _lib
+    dim, n, tune, draws = 1024, 4096, 12, 21                       # 32 MiB per draw of all chains: chunks of 8, 8, 5 draws
+    s = N.DiagNutsSettings(num_chains=n, seed=91, num_tune=tune, maxdepth=4)
+    logp = N.LogpSpec.iid_normal(dim, 3.0)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    a = N.ChainBatch(s, logp, n)
+    a.set_position(x0)
+    pos_d = torch.empty((draws, n, dim), dtype=torch.float64, device="cuda")
+    st_d = torch.empty((draws, n, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    a.draw_device(draws, pos_d.data_ptr(), st_d.data_ptr())
+    kl_a = a.counters()["kernel_launches"]
+    a.close()
+    b = N.ChainBatch(s, logp, n)
+    b.set_position(x0)
+    pos_h, st_h = b.draw_many(draws)
+    assert b.counters()["kernel_launches"] == kl_a + 2              # three chunks
+    assert (pos_h.view(np.uint64) == pos_d.cpu().numpy().view(np.uint64)).all()
+    assert (st_h.view(np.uint8).reshape(draws, n, -1) == st_d.cpu().numpy()).all()
+    # the next draws into the same arrays (touched memory), then into registered (pinned) ones: a continuation of the chains
+    c = N.ChainBatch(s, logp, n)
+    c.set_position(x0)
+    c.draw_many(draws)
+    ref_pos, ref_st = c.draw_many(draws)
+    c.close()
+    L = _lib.load()
+    _lib.check(L.nm_host_register(pos_h.ctypes.data, pos_h.nbytes))
+    try:
+        b.draw_many(draws, out=(pos_h, st_h))
+    finally:
+        _lib.check(L.nm_host_unregister(pos_h.ctypes.data))
+    b.close()
+    assert (pos_h.view(np.uint64) == ref_pos.view(np.uint64)).all() and (st_h.view(np.uint8) == ref_st.view(np.uint8)).all()
