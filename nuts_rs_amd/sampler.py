@@ -535,15 +535,18 @@ def sample(settings: DiagNutsSettings, logp: LogpSpec, x0=None, chain_id_offset=
     batch = ChainBatch(settings, logp, settings.num_chains, chain_id_offset, device)
     batch.init_with_retries(x0)                      # up to 500 initial points per chain, like the reference
     total = settings.num_tune + settings.num_draws
-    # in chunks: a call stages its whole [draws][chains][dim] trace on the device before copying it out
-    per_draw = settings.num_chains * (logp.dim * 8 + STATS_DTYPE.itemsize)
-    chunk = max(1, min(total, (chunk_bytes or (1 << 30)) // per_draw))
-    pos, st = [], []
+    # one trace, filled in place: draw_many cuts the launch into chunks itself (bounded device staging, copies under the next
+    # chunk's kernel); `chunk_bytes` > 0 additionally bounds the draws per call (e.g. to poll for interrupts in between)
+    pos = np.empty((total, batch.n_chains, logp.dim))
+    st = np.zeros((total, batch.n_chains), dtype=STATS_DTYPE)
+    per_draw = batch.n_chains * (logp.dim * 8 + STATS_DTYPE.itemsize)
+    chunk = max(1, min(total, chunk_bytes // per_draw)) if chunk_bytes else total
     done = 0
-    while done < total:
-        n = min(chunk, total - done)
-        p, q = batch.draw_many(n)
-        pos.append(p); st.append(q)
-        done += n
-    batch.close()
-    return np.concatenate(pos), np.concatenate(st)
+    try:
+        while done < total:
+            n = min(chunk, total - done)
+            batch.draw_many(n, out=(pos[done:done + n], st[done:done + n]))
+            done += n
+    finally:
+        batch.close()
+    return pos, st
