@@ -339,7 +339,15 @@ static __host__ __device__ __forceinline__ double dexp_impl(double x) {
     const double sum = __builtin_fma(th, p, DM_TAB(DM_T_LO, DM_OFF_T_LO, j));
     return __builtin_ldexp(th + sum, k);
 }
-static __host__ __device__ __noinline__ double dexp(double x) { return dexp_impl<false>(x); }
+#ifndef NM_DETMATH_INLINE
+#define NM_DETMATH_INLINE 0      // 1: exp / ln / ln_1p inlined at every call site (tuning builds; larger code, no call-boundary waits)
+#endif
+#if NM_DETMATH_INLINE
+#define NM_DM_CALL __forceinline__
+#else
+#define NM_DM_CALL __noinline__
+#endif
+static __host__ __device__ NM_DM_CALL double dexp(double x) { return dexp_impl<false>(x); }
 
 // ln(x) + c / x for finite x > 0 (c = 0: plain ln; ln_1p passes the rounding error of 1 + t)
 template <bool U>
@@ -391,8 +399,8 @@ static __host__ __device__ __forceinline__ double dlog1p_impl(double x) {
     if (!(u == u) || __builtin_isinf(u) || !(u > 0.0)) return dlog_impl<U>(u);
     return dlog_core<U>(u, x - (u - 1.0));
 }
-static __host__ __device__ __noinline__ double dlog(double x) { return dlog_impl<false>(x); }
-static __host__ __device__ __noinline__ double dlog1p(double x) { return dlog1p_impl<false>(x); }
+static __host__ __device__ NM_DM_CALL double dlog(double x) { return dlog_impl<false>(x); }
+static __host__ __device__ NM_DM_CALL double dlog1p(double x) { return dlog1p_impl<false>(x); }
 // per-lane logaddexp (reference src/math/util.rs:6-19)
 NM_DEV double logaddexp_lane(double a, double b) {
     if (a == b) return a + dlog(2.0);

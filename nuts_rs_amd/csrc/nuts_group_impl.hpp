@@ -8,6 +8,20 @@ constexpr int GPW = 64 / GS;      // chains per wavefront
 constexpr uint32_t GMASK = GS == 32 ? 0xffffffffu : ((1u << (GS & 31)) - 1u);
 using grp::GMAXDEPTH;
 
+// exp / ln / ln_1p INLINED in these kernels (they hide nm::dexp & co.: same operations, same bits): a real call starts by
+// waiting for every outstanding memory operation of the wavefront, and here 2 wavefronts per SIMD have little else to hide
+// that wait behind — measured on K4: +8 % (8192 chains), +4.5 % (65536); the one-chain kernels keep the calls (K2: inlined -3 %)
+NM_DEV double dexp(double x) { return dexp_impl<false>(x); }
+NM_DEV double dlog(double x) { return dlog_impl<false>(x); }
+NM_DEV double dlog1p(double x) { return dlog1p_impl<false>(x); }
+NM_DEV double logaddexp_lane(double a, double b) {       // per-lane logaddexp (reference src/math/util.rs:6-19)
+    if (a == b) return a + dlog(2.0);
+    double diff = a - b;
+    if (diff > 0.) return a + dlog1p(dexp(-diff));
+    if (diff < 0.) return b + dlog1p(dexp(diff));
+    return diff;
+}
+
 NM_DEV int gl() { return (int)(threadIdx.x & (unsigned)(GS - 1)); }
 NM_DEV int gg() { return (int)((threadIdx.x & 63u) / (unsigned)GS); }
 NM_DEV int gbase() { return (int)(threadIdx.x & (unsigned)(64 - GS)); }     // first lane of my group
