@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 11
+#define NM_ABI_VERSION 12
 
 typedef enum nm_status {
     NM_OK = 0,

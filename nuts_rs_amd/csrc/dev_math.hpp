@@ -136,7 +136,7 @@ struct Reducer {
             const unsigned k = (unsigned)L.k, total = 2u * N * k;
             unsigned long long* tb = L.box + 2ull * k * RED_MAX_VALUES + (L.epoch & 1ull) * (2ull * k * RED_MAX_VALUES);
             unsigned long long* stage = reinterpret_cast<unsigned long long*>(lds_out + RED_MAX_VALUES + 1);
-            const unsigned tag = (unsigned)(L.epoch + 1ull);
+            const unsigned tag = (unsigned)(L.epoch + 1ull) | 0x80000000u;     // never the 0 of a mailbox word nobody has written yet
             if (threadIdx.x < 64u) {
                 const unsigned l = threadIdx.x;
                 if (l < 2u * N) {
