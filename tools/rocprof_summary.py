@@ -11,7 +11,9 @@ import sys
 
 def trace(db, out):
     c = sqlite3.connect(db)
-    lines = ["# rocprofv3 --kernel-trace --stats : per-kernel totals (top_kernels view; durations in microseconds)"]
+    lines = ["# rocprofv3 --kernel-trace --stats : per-kernel totals (top_kernels view; durations in microseconds)",
+             "# (under bench.py the draw kernel is dispatched three times: the adaptation phase, the untimed warm-up steps, the timed steps —",
+             "#  the LAST dispatch in the per-dispatch list is the launch `roofline.kernel_ms_per_launch` refers to; avg_us averages all of them)"]
     for r in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         lines.append("%s | calls=%d | total_us=%.1f | avg_us=%.1f | pct=%.3f" % r)
     lines += ["", "# per dispatch (durations in ns): kernel | grid | wg | dur_ns | vgpr | agpr | sgpr | lds | scratch"]
