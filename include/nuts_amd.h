@@ -214,6 +214,11 @@ typedef struct nm_logp_spec {
  * kind = NM_LOGP_MODULE, module_path = "my_density.so".  `python -m nuts_rs_amd.build` has a helper
  * (nuts_rs_amd.build.build_density_module).  The module exports nm_module_launch / nm_module_info; the engine checks
  * that it was built against the same kernel-parameter layout.
+ * Errors (optional; the `Result<f64, E>` of `CpuLogpFunc::logp` with `LogpError::is_recoverable`, src/math/math.rs:9-13): a density
+ * that declares `static constexpr bool kCanFail = true;`, an `int status` member and `bind(const KParams&, uint64_t chain)` sets
+ * `status` in every eval — 0, 1 (recoverable: the leapfrog is a divergence without an energy error,
+ * src/dynamics/transformed_hamiltonian.rs:562-578) or 2 (unrecoverable: the chain stops with NM_CHAIN_LOGP_FATAL) — the same value in
+ * every thread of the chain (tests/user_density/my_walled_normal.hpp).  One-chain kernels only (no group form).
  * Group form (optional, dim <= 64): many small chains are drawn several per wavefront (nm_engine_config.lane_groups).
  * A module takes part if it also defines `template <class L> struct MyDensityGroup` with `set_lds(ptr)`,
  * `init(params, dim)` and `double eval(const double (&x)[2], double (&grad)[2], int dim) const`, where this lane holds

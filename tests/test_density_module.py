@@ -106,3 +106,80 @@ def test_user_density_group_form_matches_oracle(oracle):
     b.draw_many(5)
     assert b.group_launches() == 0
     b.close()
+
+
+WALLED = os.path.join(HERE, "user_density", "my_walled_normal.hpp")
+
+
+def ensure_walled(dim):
+    dpl, w = B.pick_tiling(dim)
+    out = os.path.join(MODDIR, f"my_walled_normal_dpl{dpl}_w{w}.so")
+    srcs = [WALLED] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp")]
+    srcs.append(os.path.join(HERE, "..", "include", "nuts_amd.h"))
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        os.makedirs(MODDIR, exist_ok=True)
+        B.build_density_module(WALLED, "MyWalledNormal", dim, out)
+    return out
+
+
+def test_fallible_module_builds():
+    assert os.path.exists(ensure_walled(24))
+
+
+@pytest.mark.gpu
+def test_fallible_user_density_matches_oracle(oracle):
+    """A device density with an error return (`kCanFail`, `status`): a recoverable error is a divergence without an energy
+    error, an unrecoverable one stops the chain — draw for draw what the oracle's chain does with a host function that applies
+    the same rules around the same arithmetic (the oracle's own N(mu, I) in the engine's reduction order)."""
+    import ctypes
+    dim, n, tune, draws = 24, 8, 60, 140
+    mu, wall1, wall2 = 0.5, 2.0, 3.1
+    path = ensure_walled(dim)
+    s = N.DiagNutsSettings(num_chains=n, seed=123, num_tune=tune, store_divergences=True)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, N.LogpSpec.module(dim, path, np.array([mu, wall1, wall2])), n, lane_groups=1)
+    status = b.set_position(x0, raise_on_error=False)
+    pos, st = b.draw_many(draws, raise_on_error=False)
+    tpc = b.threads_per_chain()
+    b.close()
+    cfg = oracle.gpu_cfg(tpc)
+    L = oracle.lib()
+    par = np.array([mu])
+    g_buf = np.zeros(dim)
+
+    def tramp(ctx, d, px, pg, plogp):
+        x = np.ctypeslib.as_array(px, shape=(d,))
+        if x[1] > wall2:
+            return 2
+        if x[0] > wall1:
+            return 1
+        out = ctypes.c_double()
+        rc = L.nmo_logp(ctypes.byref(cfg), oracle.LOGP_IID_NORMAL, d, par, 1, np.ascontiguousarray(x), g_buf, ctypes.byref(out))
+        np.ctypeslib.as_array(pg, shape=(d,))[:] = g_buf
+        plogp[0] = out.value
+        return rc
+    cb = oracle.HOST_LOGP_FN(tramp)
+    so = oracle_settings_for(oracle, s)
+    stopped = 0
+    for c in range(n):
+        ch = oracle.Chain(so, 0, dim, np.zeros(1), cfg, chain_id=c, callback=cb)
+        assert ch.set_position(x0[c]) == int(status[c]) == 0
+        for t in range(draws):
+            p, q, rc = ch.draw()
+            assert int(st["chain_status"][t, c]) == rc, (c, t)
+            if rc != 0:
+                stopped += 1
+                break
+            assert (p.view(np.uint64) == pos[t, c].view(np.uint64)).all(), (c, t)
+            for f in ("depth", "n_steps", "diverging", "step_size", "energy", "logp", "mean_tree_accept"):
+                assert q[f] == st[f][t, c], (f, c, t)
+            a, bb = q["divergence_energy_error"], st["divergence_energy_error"][t, c]
+            assert (np.isnan(a) and np.isnan(bb)) or a == bb
+    div = st["diverging"] != 0
+    assert div.sum() > 3 and np.isnan(st["divergence_energy_error"][div]).any()     # the recoverable wall was met
+    assert stopped >= 1, "no chain met the fatal wall: move it"
+
+
+def oracle_settings_for(oracle, s):
+    from helpers import oracle_settings
+    return oracle_settings(oracle, s)
