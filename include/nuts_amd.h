@@ -448,7 +448,7 @@ uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
 /* dim > 4096: a chain is spread over ceil(dim / 4096) co-resident blocks of 256 threads that each own a 4096-element slice
  * and exchange their block sums (1 for dim <= 4096).  Sums are then slice totals added in slice order; the oracle reproduces
  * it with gpu_cfg(threads_per_chain, slice = 4096).  NM_LOGP_IID_NORMAL, NM_LOGP_DIAG_NORMAL and NM_LOGP_HOST_CALLBACK (any density); NUTS with every
- * trajectory_kind and NM_SAMPLER_MCLMC, with the diagonal adaptation (not the low-rank one); dim <= 65536.  The blocks of a chain wait for each other inside the kernel: the grid never exceeds what the
+ * trajectory_kind and NM_SAMPLER_MCLMC, with the diagonal adaptation (not the low-rank one); dim <= 131072.  The blocks of a chain wait for each other inside the kernel: the grid never exceeds what the
  * device holds at once, which assumes the device is not shared with another such engine running at the same time. */
 uint64_t  nm_engine_blocks_per_chain(const nm_engine* e);
 /* draw launches served by the several-chains-per-wavefront kernels so far (nm_engine_config.lane_groups) */

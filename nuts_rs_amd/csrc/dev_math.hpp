@@ -96,7 +96,7 @@ constexpr int RED_MAX_VALUES = 6;
 #ifndef NM_CLUSTER_MODE
 #define NM_CLUSTER_MODE 0
 #endif
-constexpr int CL_MAX_MEMBERS = 16;          // blocks per chain at most (dim <= 16 x 4096)
+constexpr int CL_MAX_MEMBERS = 32;          // blocks per chain at most (dim <= 32 x 4096): the members of a chain share an XCD, which has 32 CUs
 constexpr int CL_BOX_WORDS = 6;              // u64 words of a chain's mailbox per (member, value): [2][k][V] counted + [2][k][2 V] tagged
 struct ClusterLink {
     unsigned long long* box;     // [2][k][RED_MAX_VALUES] bit patterns of the members' partial sums (two epochs alternate), then

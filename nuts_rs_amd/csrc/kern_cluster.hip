@@ -1,4 +1,4 @@
-// kern_cluster.hip — chains wider than one block (4096 < dim <= 65536): the same draw and init kernels compiled in
+// kern_cluster.hip — chains wider than one block (4096 < dim <= 131072): the same draw and init kernels compiled in
 // NM_CLUSTER_MODE, where ceil(dim / 4096) co-resident blocks of 4 wavefronts each own a 4096-element slice of ONE chain and
 // exchange every block sum through the chain's mailbox (dev_math.hpp "chains wider than one block").  Element-wise densities
 // (IidNormal, DiagNormal) and host-callback densities (any density), the (16 doubles, 4 waves) tiling only.  Own TU: the mode is a macro, like NM_TILE_MODE.

@@ -478,7 +478,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (cfg_in) cfg = *cfg_in; else nm_engine_config_default(&cfg);
     int dpl = 0, wv = 0;
     uint64_t cl_k = 1;
-    constexpr uint64_t CL_SLICE = 4096, CL_MAX_K = 16;
+    constexpr uint64_t CL_SLICE = 4096, CL_MAX_K = CL_MAX_MEMBERS;
     if (logp->dim > CL_SLICE) {     // wider than one block: ceil(dim / 4096) blocks per chain (kern_cluster.hip)
         cl_k = (logp->dim + CL_SLICE - 1) / CL_SLICE;
         if (cl_k > CL_MAX_K) return fail(NM_ERR_UNSUPPORTED, "dim %llu > %llu", (unsigned long long)logp->dim, (unsigned long long)(CL_SLICE * CL_MAX_K));

@@ -17,7 +17,8 @@ CASES = [
     ("dim10000", 10000, 3, 25, 40, "diag", {}),
     ("dim20000_adam", 20000, 2, 20, 32, "iid", dict(adam=True)),
     ("dim40000", 40000, 2, 16, 26, "diag", {}),
-    ("dim65536_max", 65536, 1, 12, 20, "iid", {}),
+    ("dim65536", 65536, 1, 12, 20, "iid", {}),
+    ("dim131072_max", 131072, 2, 8, 14, "diag", {}),
     ("dim9000_many_chains", 9000, 37, 16, 26, "iid", {}),
     ("dim6000_options", 6000, 3, 30, 45, "diag", dict(maxdepth=4, store=True)),
 ]
@@ -66,7 +67,7 @@ def test_wide_chain_posterior_and_unsupported(oracle):
     with pytest.raises(N.NutsAmdError):
         N.ChainBatch(N.LowRankNutsSettings(num_chains=2), N.LogpSpec.iid_normal(5000, 0.0), 2)
     with pytest.raises(N.NutsAmdError):
-        N.ChainBatch(s, N.LogpSpec.iid_normal(70000, 0.0), 2)      # > 16 blocks per chain
+        N.ChainBatch(s, N.LogpSpec.iid_normal(131073, 0.0), 2)     # > 32 blocks per chain
 
 
 
