@@ -642,6 +642,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     P.pvec = e->d_pvec; P.svec = e->d_svec; P.sc = e->d_sc; P.prof = e->d_prof; P.zig_x = e->d_zig; P.zig_f = e->d_zig + 257; P.logp_params = e->d_params;
     P.early_end = early_end;
     P.cl_k = cl_k; P.cl_slice = CL_SLICE; P.cl_box = e->d_cl_box; P.cl_cnt = e->d_cl_cnt;
+    { const char* g = getenv("NM_CLUSTER_GENERAL"); P.cl_general = g && g[0] == '1'; }      // the fallback protocol on request (it is otherwise taken only where a chain's blocks do not share an XCD)
     {   // MclmcChain's switch_draw = (trajectory_switch_fraction * num_tune) as u64 (sampler.rs:441; `as` saturates, NaN -> 0)
         const double q = s.trajectory_switch_fraction * num_tune_f;
         P.mclmc_switch_draw = q >= 18446744073709551616.0 ? ~0ull : (q > 0.0 ? (uint64_t)q : 0ull);

@@ -128,6 +128,7 @@ struct KParams {
     uint64_t mclmc_switch_draw;        // MclmcChain::switch_draw (sampler.rs:441)
     // chains wider than one block (NM_CLUSTER_MODE kernels): cl_k members of cl_slice elements each per chain, their mailboxes
     uint64_t cl_k, cl_slice;
+    uint64_t cl_general;               // 1: always the general (release / acquire) exchange, never the same-XCD one (NM_CLUSTER_GENERAL=1: tests)
     unsigned long long* cl_box;        // [clusters][2][cl_k][RED_MAX_VALUES]
     unsigned long long* cl_cnt;        // [clusters], zeroed before every launch
     double ln_max_step;                // ln(da_max_step_size), dual_avg.rs:59
@@ -2671,7 +2672,7 @@ NM_DEV ClusterLink cluster_start(const KParams& P, double* red_lds, unsigned cl_
     const double x = (double)xcc_id();
     double v[2] = {x, x * x};
     r.template cluster_combine<2>(v);
-    r.cl.same_xcd = ((double)cl_k * v[1] == v[0] * v[0]) ? 1 : 0;    // sum of squares = square of the sum / k  <=>  all equal
+    r.cl.same_xcd = (!P.cl_general && (double)cl_k * v[1] == v[0] * v[0]) ? 1 : 0;    // sum of squares = square of the sum / k  <=>  all equal
     return r.cl;
 }
 #endif

@@ -195,3 +195,20 @@ def test_wide_chain_trajectory_kinds_and_mclmc_bit_exact(oracle, case):
             assert ((st_g[f] == st_o[f]) | (np.isnan(st_g[f]) & np.isnan(st_o[f]))).all(), f
     if "ladder" in name:
         assert (st_g["average_step_size"] < 1.5 * (1 - 1e-12)).sum() > 0        # the halve-and-retry ladder ran
+
+
+def test_general_exchange_protocol_gives_the_same_draws(oracle, monkeypatch):
+    """The fallback of the lock-free exchange — release / acquire on an arrival counter, taken where a chain's blocks do not share
+    an XCD — forced for a whole run (NM_CLUSTER_GENERAL=1): the same bits."""
+    dim, n, tune, draws = 9000, 5, 16, 26
+    s = N.DiagNutsSettings(num_chains=n, seed=17, num_tune=tune)
+    logp = N.LogpSpec.diag_normal(np.exp(np.random.default_rng(2).uniform(-2, 2, dim)))
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    monkeypatch.setenv("NM_CLUSTER_GENERAL", "1")
+    b = N.ChainBatch(s, logp, n)
+    b.set_position(x0)
+    pos_g, st_g = b.draw_many(draws)
+    b.close()
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(256, gpu_slice=4096), n, x0, draws, n_threads=8)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
