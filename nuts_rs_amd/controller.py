@@ -13,7 +13,7 @@ from typing import Callable, List, Optional
 
 import numpy as np
 
-from .sampler import ChainBatch, DiagNutsSettings, LogpSpec
+from .sampler import STATS_DTYPE, ChainBatch, DiagNutsSettings, LogpSpec
 
 
 @dataclass
@@ -87,7 +87,7 @@ class Sampler:
         self._total_steps = np.zeros(self._n, dtype=np.int64)
         self._step_size = np.zeros(self._n)
         self._divergent = []                        # (draw index, chain) of post-warm-up divergences
-        self._trace_pos, self._trace_stats = [], []
+        self._pos = self._st = None                 # the trace, allocated once by the controller thread and filled in place
         factory = engine_factory or (lambda s, l, n, off, dev: ChainBatch(s, l, n, chain_id_offset=off, device=dev))
         self._thread = threading.Thread(target=self._main, name="nuts-amd-controller",
                                         args=(factory, logp, x0, chain_id_offset, device), daemon=True)
@@ -115,13 +115,21 @@ class Sampler:
                     if self._abort:
                         break
                 n = min(self._chunk, self._total - finished)
+                if self._st is None:                # one trace for the whole run (no per-chunk arrays to concatenate at the end)
+                    self._st = np.zeros((self._total, self._n), dtype=STATS_DTYPE)
+                    if self._store_positions:
+                        self._pos = np.empty((self._total, self._n, logp.dim))
+                dst = (self._pos[finished:finished + n] if self._store_positions else None, self._st[finished:finished + n])
                 t0 = time.monotonic()
-                pos, st = batch.draw_many(n, positions=self._store_positions)
+                try:
+                    pos, st = batch.draw_many(n, positions=self._store_positions, out=dst)
+                except TypeError:                   # an engine stand-in without `out=`
+                    pos, st = batch.draw_many(n, positions=self._store_positions)
+                    if pos is not None:
+                        dst[0][...] = pos
+                    dst[1][...] = st
                 per_draw = (time.monotonic() - t0) / n
                 with self._lock:
-                    if pos is not None:
-                        self._trace_pos.append(pos)
-                    self._trace_stats.append(st)
                     # ChainProgress::update for every (draw, chain) of the chunk (src/sampler.rs:1038-1050)
                     div = (st["diverging"] != 0) & (st["tuning"] == 0)
                     self._divergences += div.sum(axis=0)
@@ -151,10 +159,12 @@ class Sampler:
         if self._callback is not None:
             self._callback.callback(elapsed, self.progress())
 
-    def _snapshot(self):
+    def _snapshot(self, final=False):
+        """the draws finished so far: a copy while the sampler runs, the trace itself (trimmed) once its thread has ended"""
         with self._lock:
-            pos = np.concatenate(self._trace_pos, axis=0) if self._trace_pos else None
-            st = np.concatenate(self._trace_stats, axis=0) if self._trace_stats else None
+            f = self._finished
+            pos = None if self._pos is None else (self._pos[:f] if final else self._pos[:f].copy())
+            st = None if self._st is None else (self._st[:f] if final else self._st[:f].copy())
         return {"positions": pos, "stats": st}
 
     # ---- commands (src/sampler.rs:1463-1551)
@@ -191,7 +201,7 @@ class Sampler:
             self._abort = True
             self._cmd.notify_all()
         self._thread.join()
-        return self._error, self._snapshot()
+        return self._error, self._snapshot(final=True)
 
     def is_finished(self):
         return self._done.is_set()
@@ -202,5 +212,5 @@ class Sampler:
             return SamplerWaitResult("timeout", sampler=self)
         self._thread.join()
         if self._error is not None:
-            return SamplerWaitResult("err", error=self._error, trace=self._snapshot())
-        return SamplerWaitResult("trace", trace=self._snapshot())
+            return SamplerWaitResult("err", error=self._error, trace=self._snapshot(final=True))
+        return SamplerWaitResult("trace", trace=self._snapshot(final=True))
