@@ -358,13 +358,13 @@ public:
     void flush() {}
     std::vector<ChainProgress> progress() { std::lock_guard<std::mutex> g(m_); return progress_; }
     // (error or empty, trace so far) without stopping the sampler
-    std::pair<std::string, Trace> inspect() { std::lock_guard<std::mutex> g(m_); return {error_, trace_}; }
+    std::pair<std::string, Trace> inspect() { std::lock_guard<std::mutex> g(m_); return {error_, finished_part()}; }
     // stop after the launch in flight; (error or empty, trace so far)
     std::pair<std::string, Trace> abort() {
         request_abort();
         if (thread_.joinable()) thread_.join();
         std::lock_guard<std::mutex> g(m_);
-        return {error_, trace_};
+        return {error_, finished_part()};
     }
     WaitResult wait_timeout(std::chrono::duration<double> timeout) {
         std::unique_lock<std::mutex> g(m_);
@@ -372,8 +372,8 @@ public:
         g.unlock();
         if (thread_.joinable()) thread_.join();
         g.lock();
-        if (!error_.empty()) return {WaitKind::Err, trace_, error_};
-        return {WaitKind::Trace, trace_, ""};
+        if (!error_.empty()) return {WaitKind::Err, finished_part(), error_};
+        return {WaitKind::Trace, finished_part(), ""};
     }
 
 private:
@@ -383,7 +383,10 @@ private:
             ChainBatch batch(settings, logp, n_, 0, device);
             batch.init_with_retries(x0 ? &*x0 : nullptr);
             { std::lock_guard<std::mutex> g(m_); for (ChainProgress& p : progress_) p.started = true;
-              trace_.n_chains = n_; trace_.dim = dim_; }
+              trace_.n_chains = n_; trace_.dim = dim_;
+              // one trace for the whole run: the engine writes every chunk straight into its place (capacity reserved here, so the
+              // storage never moves; rows beyond n_draws are the chunk in flight)
+              trace_.positions.reserve(total_ * n_ * dim_); trace_.stats.reserve(total_ * n_); }
             uint64_t finished = 0;
             while (finished < total_) {
                 {
@@ -392,14 +395,14 @@ private:
                     if (abort_) break;
                 }
                 const uint64_t n = std::min<uint64_t>(chunk_, total_ - finished);
-                std::vector<double> pos(n * n_ * dim_);
-                std::vector<nm_draw_stats> st(n * n_);
+                double* pos; nm_draw_stats* st;
+                {   std::lock_guard<std::mutex> g(m_);
+                    trace_.positions.resize((finished + n) * n_ * dim_); trace_.stats.resize((finished + n) * n_);
+                    pos = trace_.positions.data() + finished * n_ * dim_; st = trace_.stats.data() + finished * n_; }
                 const auto t0 = std::chrono::steady_clock::now();
-                batch.draw_many(n, pos.data(), st.data());
+                batch.draw_many(n, pos, st);
                 const std::chrono::duration<double> per_draw = (std::chrono::steady_clock::now() - t0) / (double)n;
                 std::lock_guard<std::mutex> g(m_);
-                trace_.positions.insert(trace_.positions.end(), pos.begin(), pos.end());
-                trace_.stats.insert(trace_.stats.end(), st.begin(), st.end());
                 trace_.n_draws += n;
                 for (uint64_t t = 0; t < n; ++t)
                     for (uint64_t c = 0; c < n_; ++c) progress_[c].update(st[t * n_ + c], per_draw);
@@ -411,6 +414,21 @@ private:
         }
         { std::lock_guard<std::mutex> g(m_); done_ = true; }
         cv_.notify_all();
+    }
+
+    // the finished draws (m_ held): the trace itself once the controller thread has ended, else a copy of its finished rows
+    Trace finished_part() {
+        if (done_) {
+            trace_.positions.resize(trace_.n_draws * n_ * dim_); trace_.stats.resize(trace_.n_draws * n_);
+            Trace out = std::move(trace_);          // handed over once (the reference's wait / abort consume the sampler)
+            trace_ = Trace{};
+            return out;
+        }
+        Trace t;
+        t.n_draws = trace_.n_draws; t.n_chains = trace_.n_chains; t.dim = trace_.dim;
+        t.positions.assign(trace_.positions.begin(), trace_.positions.begin() + (std::ptrdiff_t)(t.n_draws * n_ * dim_));
+        t.stats.assign(trace_.stats.begin(), trace_.stats.begin() + (std::ptrdiff_t)(t.n_draws * n_));
+        return t;
     }
 
     uint64_t total_, n_, dim_, chunk_;
