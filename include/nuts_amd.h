@@ -219,6 +219,10 @@ typedef struct nm_logp_spec {
  * `status` in every eval — 0, 1 (recoverable: the leapfrog is a divergence without an energy error,
  * src/dynamics/transformed_hamiltonian.rs:562-578) or 2 (unrecoverable: the chain stops with NM_CHAIN_LOGP_FATAL) — the same value in
  * every thread of the chain (tests/user_density/my_walled_normal.hpp).  One-chain kernels only (no group form).
+ * Wide chains (dim > 4096: several blocks per chain, see nm_engine_blocks_per_chain): the module is compiled with -DNM_CLUSTER_MODE=1
+ * -DNM_MODULE_DPL=16 -DNM_MODULE_W=4 (build_density_module does it) and the density also defines
+ * `init_slice(params, dim, gdim, goff, reducer)`: its block holds elements [goff, goff + dim) of a chain of gdim elements, `eval` sees
+ * that slice, and every reducer sum spans the whole chain (tests/user_density/my_diag_normal.hpp).
  * Group form (optional, dim <= 64): many small chains are drawn several per wavefront (nm_engine_config.lane_groups).
  * A module takes part if it also defines `template <class L> struct MyDensityGroup` with `set_lds(ptr)`,
  * `init(params, dim)` and `double eval(const double (&x)[2], double (&grad)[2], int dim) const`, where this lane holds
@@ -447,7 +451,8 @@ uint64_t  nm_engine_threads_per_chain(const nm_engine* e);
 uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
 /* dim > 4096: a chain is spread over ceil(dim / 4096) co-resident blocks of 256 threads that each own a 4096-element slice
  * and exchange their block sums (1 for dim <= 4096).  Sums are then slice totals added in slice order; the oracle reproduces
- * it with gpu_cfg(threads_per_chain, slice = 4096).  NM_LOGP_IID_NORMAL, NM_LOGP_DIAG_NORMAL and NM_LOGP_HOST_CALLBACK (any density); NUTS with every
+ * it with gpu_cfg(threads_per_chain, slice = 4096).  NM_LOGP_IID_NORMAL, NM_LOGP_DIAG_NORMAL, NM_LOGP_MODULE (a fused user density built for
+ * wide chains) and NM_LOGP_HOST_CALLBACK (any density); NUTS with every
  * trajectory_kind and NM_SAMPLER_MCLMC, with the diagonal adaptation (not the low-rank one); dim <= 131072.  The blocks of a chain wait for each other inside the kernel: the grid never exceeds what the
  * device holds at once, which assumes the device is not shared with another such engine running at the same time. */
 uint64_t  nm_engine_blocks_per_chain(const nm_engine* e);

@@ -76,7 +76,11 @@ def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):
 def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None):
     """Compile a user density (a functor `struct_name` defined in `header`, see include/nuts_amd.h "User densities")
     with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s)."""
-    dpl, w = pick_tiling(dim, dims_per_lane, waves_per_chain)
+    if dim > 4096:            # several blocks per chain: the cluster-mode kernels on the (16, 4) tiling; the density brings init_slice
+        dpl, w = 16, 4
+        extra_flags = list(extra_flags) + ["-DNM_CLUSTER_MODE=1"]
+    else:
+        dpl, w = pick_tiling(dim, dims_per_lane, waves_per_chain)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     header = os.path.abspath(header)
     if group_struct:          # the density's group form: several chains per wavefront for dim <= 64

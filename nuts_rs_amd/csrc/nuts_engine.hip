@@ -197,11 +197,12 @@ extern "C" void nm_engine_config_default(nm_engine_config* c) {
 // ---------------------------------------------------------------------------------------------
 
 typedef int (*module_launch_fn)(int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ);
-typedef void (*module_info_fn)(uint64_t out[5]);
+typedef void (*module_info_fn)(uint64_t out[6]);
 
 static hipError_t launch(uint64_t logp_kind, int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ = nullptr,
                          module_launch_fn module = nullptr, int variant = 0) {     // variant: 0 plain, 1 LrWrap (low-rank transformation), 2 KinWrap (trajectory kinds), 3 cluster (dim > 4096), 4 cluster + KinWrap
     const bool lr = variant == 1;
+    if (variant == 3 && logp_kind == NM_LOGP_MODULE) return module ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;   // a module built in cluster mode
     if (variant == 3) return launch_cluster(logp_kind, kind, P, grid, stream, occ);   // chains wider than one block (kern_cluster.hip)
     if (variant == 4) return launch_cluster_kin(logp_kind, kind, P, grid, stream, occ);
     if (logp_kind == NM_LOGP_MODULE) return module && variant == 0 ? (hipError_t)module((int)kind, &P, grid, stream, occ) : hipErrorInvalidValue;
@@ -482,8 +483,9 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (logp->dim > CL_SLICE) {     // wider than one block: ceil(dim / 4096) blocks per chain (kern_cluster.hip)
         cl_k = (logp->dim + CL_SLICE - 1) / CL_SLICE;
         if (cl_k > CL_MAX_K) return fail(NM_ERR_UNSUPPORTED, "dim %llu > %llu", (unsigned long long)logp->dim, (unsigned long long)(CL_SLICE * CL_MAX_K));
-        if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL && logp->kind != NM_LOGP_HOST_CALLBACK)
-            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal) and for NM_LOGP_HOST_CALLBACK", (unsigned long long)logp->dim);
+        if (logp->kind != NM_LOGP_IID_NORMAL && logp->kind != NM_LOGP_DIAG_NORMAL && logp->kind != NM_LOGP_HOST_CALLBACK && logp->kind != NM_LOGP_MODULE)
+            return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: chains wider than one block exist for the element-wise densities (iid / diagonal normal), for density modules built for wide chains and for NM_LOGP_HOST_CALLBACK", (unsigned long long)logp->dim);
+        if (logp->kind == NM_LOGP_MODULE && kin) return fail(NM_ERR_UNSUPPORTED, "density modules carry the Euclidean NUTS kernels only");
         if (lr) return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096: the diagonal adaptation only", (unsigned long long)logp->dim);
         if ((cfg.dims_per_lane && cfg.dims_per_lane != 16) || (cfg.waves_per_chain && cfg.waves_per_chain != 4))
             return fail(NM_ERR_UNSUPPORTED, "dim %llu > 4096 runs on the (16 doubles, 4 waves) tiling", (unsigned long long)logp->dim);
@@ -519,6 +521,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         uint64_t mi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         info(mi);
         e->module_group_lanes = (int)mi[4];
+        if ((mi[5] != 0) != (cl_k > 1)) { engine_free(e); return fail(NM_ERR_INVALID_ARG, cl_k > 1 ? "dim %llu > 4096 needs a density module built for wide chains (-DNM_CLUSTER_MODE=1, init_slice)" : "this density module was built for wide chains (dim > 4096), dim is %llu", (unsigned long long)logp->dim); }
         if (mi[0] != sizeof(KParams) || mi[1] != NM_ABI_VERSION) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module built against another engine (kernel parameters %llu bytes / ABI %llu, engine %zu / %d)", (unsigned long long)mi[0], (unsigned long long)mi[1], sizeof(KParams), NM_ABI_VERSION); }
         if ((int)mi[2] != dpl || (int)mi[3] != wv) { engine_free(e); return fail(NM_ERR_INVALID_ARG, "density module was built for tiling (%llu doubles per lane, %llu waves) but dim %llu uses (%d, %d): rebuild it with nm_pick_tiling's answer", (unsigned long long)mi[2], (unsigned long long)mi[3], (unsigned long long)logp->dim, dpl, wv); }
     }

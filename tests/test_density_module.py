@@ -19,7 +19,7 @@ DIM = 40
 
 
 def module_path(dim=DIM):
-    dpl, w = B.pick_tiling(dim)
+    dpl, w = B.pick_tiling(dim) if dim <= 4096 else ("wide16", 4)
     return os.path.join(MODDIR, f"my_diag_normal_dpl{dpl}_w{w}.so")
 
 
@@ -183,3 +183,41 @@ def test_fallible_user_density_matches_oracle(oracle):
 def oracle_settings_for(oracle, s):
     from helpers import oracle_settings
     return oracle_settings(oracle, s)
+
+
+WIDE_DIM = 6000
+
+
+def test_wide_chain_module_builds():
+    m = C.CDLL(ensure_module(WIDE_DIM))
+    info = (C.c_uint64 * 8)()
+    m.nm_module_info(info)
+    assert (info[2], info[3], info[5]) == (16, 4, 1)                 # the (16, 4) tiling, built for several blocks per chain
+
+
+@pytest.mark.gpu
+def test_wide_chain_user_density_matches_builtin_and_oracle(oracle):
+    """A fused USER density for a chain wider than one block (dim > 4096): the module is compiled in cluster mode and brings
+    `init_slice`; same bits as the built-in diagonal normal and as the oracle."""
+    from helpers import oracle_settings
+    path, n, draws = ensure_module(WIDE_DIM), 3, 36
+    prec = np.exp(np.random.default_rng(4).uniform(-2, 2, WIDE_DIM))
+    s = N.DiagNutsSettings(num_chains=n, seed=78, num_tune=24)
+    x0 = oracle.init_positions_uniform(78, 0, n, WIDE_DIM)
+    out = {}
+    for name, logp in (("module", N.LogpSpec.module(WIDE_DIM, path, prec)), ("builtin", N.LogpSpec.diag_normal(prec))):
+        b = N.ChainBatch(s, logp, n)
+        assert b.blocks_per_chain() == 2
+        b.set_position(x0)
+        out[name] = b.draw_many(draws)
+        b.close()
+    assert (out["module"][0].view(np.uint64) == out["builtin"][0].view(np.uint64)).all()
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), oracle.LOGP_DIAG_NORMAL, WIDE_DIM, prec, oracle.gpu_cfg(256, gpu_slice=4096), n, x0, draws, n_threads=8)
+    assert failed == 0
+    assert_bit_exact(out["module"][0], out["module"][1], pos_o, st_o)
+    with pytest.raises(N.NutsAmdError) as e:                        # a one-block module cannot serve a wide chain, and vice versa
+        N.ChainBatch(s, N.LogpSpec.module(WIDE_DIM, ensure_module(), prec), n)
+    assert "wide chains" in str(e.value)
+    with pytest.raises(N.NutsAmdError) as e:
+        N.ChainBatch(s, N.LogpSpec.module(DIM, path, prec[:DIM]), n)
+    assert "wide chains" in str(e.value)

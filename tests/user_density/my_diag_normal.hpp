@@ -22,6 +22,20 @@ struct MyDiagNormal {
         const double log_det_p = R.sum(acc);
         norm = -0.5 * ((double)dim * nm::ulog(6.283185307179586) - log_det_p);
     }
+    // Chains wider than one block (dim > 4096; modules built with -DNM_CLUSTER_MODE=1): this block holds elements
+    // [goff, goff + dim) of a chain of gdim elements; `eval` then sees that slice, and every R.sum spans the whole chain.
+    template <int W>
+    NM_DEV void init_slice(const double* params, int dim, int gdim, int goff, nm::Reducer<W>& R) {
+        prec = params + goff;
+        double acc = 0.0;
+        for (int m = 0; m < (dim + 128 * W - 1) / (128 * W); ++m)
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * (m * 64 * W + nm::tid()) + j;
+                acc = acc + (d < dim ? nm::dlog(prec[d < dim ? d : 0]) : 0.0);
+            }
+        const double log_det_p = R.sum(acc);
+        norm = -0.5 * ((double)gdim * nm::ulog(6.283185307179586) - log_det_p);
+    }
     template <int DPL, int W>
     NM_DEV double eval(const nm::Tile<DPL>& x, nm::Tile<DPL>& gx, int dim, nm::Reducer<W>& R) const {
         double acc = 0.0;
