@@ -358,13 +358,13 @@ public:
     void flush() {}
     std::vector<ChainProgress> progress() { std::lock_guard<std::mutex> g(m_); return progress_; }
     // (error or empty, trace so far) without stopping the sampler
-    std::pair<std::string, Trace> inspect() { std::lock_guard<std::mutex> g(m_); return {error_, finished_part()}; }
+    std::pair<std::string, Trace> inspect() { std::lock_guard<std::mutex> g(m_); return {error_, finished_part(false)}; }
     // stop after the launch in flight; (error or empty, trace so far)
     std::pair<std::string, Trace> abort() {
         request_abort();
         if (thread_.joinable()) thread_.join();
         std::lock_guard<std::mutex> g(m_);
-        return {error_, finished_part()};
+        return {error_, finished_part(true)};
     }
     WaitResult wait_timeout(std::chrono::duration<double> timeout) {
         std::unique_lock<std::mutex> g(m_);
@@ -372,8 +372,8 @@ public:
         g.unlock();
         if (thread_.joinable()) thread_.join();
         g.lock();
-        if (!error_.empty()) return {WaitKind::Err, finished_part(), error_};
-        return {WaitKind::Trace, finished_part(), ""};
+        if (!error_.empty()) return {WaitKind::Err, finished_part(true), error_};
+        return {WaitKind::Trace, finished_part(true), ""};
     }
 
 private:
@@ -416,12 +416,15 @@ private:
         cv_.notify_all();
     }
 
-    // the finished draws (m_ held): the trace itself once the controller thread has ended, else a copy of its finished rows
-    Trace finished_part() {
-        if (done_) {
+    // the finished draws (m_ held).  `consume` (wait_timeout / abort, which consume the sampler in the reference:
+    // src/sampler.rs:1487-1552) hands the trace itself over once the controller thread has ended; inspect() never does — it
+    // clones the finished rows (src/sampler.rs:1469-1485), however often and whenever it is called.
+    Trace finished_part(bool consume) {
+        if (consume && done_) {
             trace_.positions.resize(trace_.n_draws * n_ * dim_); trace_.stats.resize(trace_.n_draws * n_);
-            Trace out = std::move(trace_);          // handed over once (the reference's wait / abort consume the sampler)
+            Trace out = std::move(trace_);
             trace_ = Trace{};
+            trace_.n_chains = out.n_chains; trace_.dim = out.dim;
             return out;
         }
         Trace t;

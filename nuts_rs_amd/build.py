@@ -33,9 +33,38 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(path, seen=None):
+    """The quoted includes a source pulls in (recursively, resolved against csrc/ and include/): a unit is recompiled when
+    one of ITS headers changed, not when any header did (nuts_tile.hpp concerns two units of 26)."""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for base in (os.path.dirname(path), CSRC, os.path.join(HERE, "..", "include")):
+            q = os.path.normpath(os.path.join(base, name))
+            if os.path.exists(q):
+                if q not in seen:
+                    seen.add(q)
+                    _includes(q, seen)
+                break
+    return seen
+
+
+def _obj(u):
+    return os.path.join(OBJ, u.replace(".hip", ".o").replace(".cpp", ".o"))
+
+
+def _unit_stale(u):
+    src = os.path.join(CSRC, u)
+    return _newer(_obj(u), [src] + sorted(_includes(src)))
+
+
 def needs_build():
-    deps = [os.path.join(CSRC, f) for f in UNITS + HEADERS]
-    return _newer(LIB, deps)
+    """True when the library is missing, older than one of its objects, or an object is older than its source / its headers."""
+    return any(_unit_stale(u) for u in UNITS) or _newer(LIB, [_obj(u) for u in UNITS])
 
 
 def build(force=False, verbose=False, extra_flags=()):
@@ -46,8 +75,8 @@ def build(force=False, verbose=False, extra_flags=()):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
     def compile_unit(u):
-        src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o").replace(".cpp", ".o"))
-        if force or _newer(obj, [src] + hdrs):
+        src, obj = os.path.join(CSRC, u), _obj(u)
+        if force or _unit_stale(u):
             host_only = ["-mavx2", "-mfma"] if u.endswith(".cpp") else []     # the host estimator's dense loops (no contraction: -ffp-contract=off)
             cmd = [hipcc] + FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
             if verbose:

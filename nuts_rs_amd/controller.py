@@ -7,6 +7,7 @@ between launches.  Names, return shapes and the bookkeeping of `ChainProgress` (
 reference's; the trace is a dict of host arrays instead of a `TraceStorage`.
 """
 import threading
+import inspect
 import time
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
@@ -105,6 +106,12 @@ class Sampler:
             self._fire_callback(0.0)
             last_cb = time.monotonic()
             finished = 0
+            # decided ONCE from the signature: a TypeError raised inside a real draw_many (after the kernel has advanced the
+            # chains) must surface, not trigger a second, trace-skipping call
+            try:
+                takes_out = "out" in inspect.signature(batch.draw_many).parameters
+            except (TypeError, ValueError):
+                takes_out = False
             while finished < self._total:
                 with self._cmd:
                     if self._paused and not self._abort:
@@ -121,9 +128,9 @@ class Sampler:
                         self._pos = np.empty((self._total, self._n, logp.dim))
                 dst = (self._pos[finished:finished + n] if self._store_positions else None, self._st[finished:finished + n])
                 t0 = time.monotonic()
-                try:
+                if takes_out:
                     pos, st = batch.draw_many(n, positions=self._store_positions, out=dst)
-                except TypeError:                   # an engine stand-in without `out=`
+                else:                               # an engine stand-in without `out=`
                     pos, st = batch.draw_many(n, positions=self._store_positions)
                     if pos is not None:
                         dst[0][...] = pos

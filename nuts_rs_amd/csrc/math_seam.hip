@@ -289,13 +289,16 @@ extern "C" nm_status nm_math_create(const nm_logp_spec* logp, nm_math** out) {
     if (!m) return mfail(NM_ERR_HIP, "out of host memory");
     m->spec = *logp; m->dim = logp->dim; m->dpl = (int)dpl; m->w = (int)w; m->dpad = 64ull * dpl * w;
     static const double X[257] = NM_ZIG_NORM_X, F[257] = NM_ZIG_NORM_F;
+    // Stream discipline (DESIGN "Stream discipline"): every fill, copy and kernel of this Math runs on m->stream; the null stream
+    // is never used (it is not ordered against a hipStreamNonBlocking stream).
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&m->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double));
-    if (e == hipSuccess && logp->n_params) e = hipMemcpy(m->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && logp->n_params) e = hipMemcpyAsync(m->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice, m->stream);
     if (e == hipSuccess) e = hipMalloc(&m->d_zig, 2 * 257 * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(m->d_zig, X, sizeof X, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(m->d_zig + 257, F, sizeof F, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->d_zig, X, sizeof X, hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->d_zig + 257, F, sizeof F, hipMemcpyHostToDevice, m->stream);
     if (e == hipSuccess) e = hipMalloc(&m->d_out, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);      // (h_params belongs to the caller: consumed before returning)
     if (e != hipSuccess) { nm_math_destroy(m); return mfail(NM_ERR_HIP, "nm_math_create", e); }
     m->spec.h_params = nullptr;
     *out = m;
@@ -316,21 +319,27 @@ extern "C" nm_status nm_vec_new(nm_math* m, nm_vec** out) {          // new_arra
     if (!m || !out) return mfail(NM_ERR_INVALID_ARG, "null argument");
     nm_vec* v = new (std::nothrow) nm_vec{nullptr};
     if (!v) return mfail(NM_ERR_HIP, "out of host memory");
+    // The zero fill runs on the Math's own stream, like every later operation on the vector.  (Round 2 used a null-stream
+    // hipMemset here: not ordered against m->stream, it could land after the first kernel's store into the new vector —
+    // reproduced by tools/probes/vec_new_race.py.)  The wait keeps nm_vec_free / another handle's use trivially safe.
     hipError_t e = hipMalloc(&v->d, m->dpad * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(v->d, 0, m->dpad * sizeof(double));
-    if (e != hipSuccess) { delete v; return mfail(NM_ERR_HIP, "nm_vec_new", e); }
+    if (e == hipSuccess) e = hipMemsetAsync(v->d, 0, m->dpad * sizeof(double), m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) { if (v->d) (void)hipFree(v->d); delete v; return mfail(NM_ERR_HIP, "nm_vec_new", e); }
     *out = v;
     return NM_OK;
 }
 extern "C" void nm_vec_free(nm_vec* v) { if (v) { if (v->d) (void)hipFree(v->d); delete v; } }
 extern "C" nm_status nm_vec_read_from_slice(nm_math* m, nm_vec* dst, const double* h) {
     if (!m || !dst || !h) return mfail(NM_ERR_INVALID_ARG, "null argument");
-    hipError_t e = hipMemcpy(dst->d, h, m->dim * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(dst->d, h, m->dim * sizeof(double), hipMemcpyHostToDevice, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     return e == hipSuccess ? NM_OK : mfail(NM_ERR_HIP, "read_from_slice", e);
 }
 extern "C" nm_status nm_vec_write_to_slice(nm_math* m, const nm_vec* src, double* h) {
     if (!m || !src || !h) return mfail(NM_ERR_INVALID_ARG, "null argument");
-    hipError_t e = hipMemcpy(h, src->d, m->dim * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(h, src->d, m->dim * sizeof(double), hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     return e == hipSuccess ? NM_OK : mfail(NM_ERR_HIP, "write_to_slice", e);
 }
 #define NM_CHECK(...) do { const void* ps_[] = {__VA_ARGS__}; for (const void* p_ : ps_) if (!p_) return mfail(NM_ERR_INVALID_ARG, "null argument"); } while (0)

@@ -398,6 +398,27 @@ struct nm_engine {
     std::atomic<uint64_t> cb_calls{0};
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Stream discipline (DESIGN "Stream discipline"): device memory the library owns is only ever touched on the stream of the
+// handle that owns it (nm_engine::stream / the caller's `stream` argument of the batch helpers), never on the null stream.
+// The handles' streams are hipStreamNonBlocking, so a null-stream hipMemset / kernel is NOT ordered against them (round 2's
+// red test: a zero fill that landed after the kernel it should have preceded).  Host <-> device copies go through copy_on /
+// copy2d_on: enqueued on the owning stream, and the host waits for THAT stream — ordered after everything queued before it,
+// complete (so the host buffer may be reused or freed) when the call returns.  tests/test_stream_discipline.py greps the
+// sources for the forbidden forms.
+// ---------------------------------------------------------------------------------------------
+static hipError_t copy_on(hipStream_t s, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    if (n == 0) return hipSuccess;
+    const hipError_t er = hipMemcpyAsync(dst, src, n, kind, s);
+    return er != hipSuccess ? er : hipStreamSynchronize(s);
+}
+static hipError_t copy2d_on(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind) {
+    if (width == 0 || height == 0) return hipSuccess;
+    const hipError_t er = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, s);
+    return er != hipSuccess ? er : hipStreamSynchronize(s);
+}
+
 static void engine_free(nm_engine* e) {
     if (!e) return;
     e->cb_stop.store(1);
@@ -434,8 +455,8 @@ static void engine_free(nm_engine* e) {
 }
 // the chains' scalars (cluster mode: the copy of every chain's first member)
 static hipError_t read_scalars(nm_engine* e, ChainScalars* out) {
-    if (e->cl_k == 1) return hipMemcpy(out, e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost);
-    return hipMemcpy2D(out, sizeof(ChainScalars), e->d_sc, e->cl_k * sizeof(ChainScalars), sizeof(ChainScalars), e->n_chains, hipMemcpyDeviceToHost);
+    if (e->cl_k == 1) return copy_on(e->stream, out, e->d_sc, e->n_chains * sizeof(ChainScalars), hipMemcpyDeviceToHost);
+    return copy2d_on(e->stream, out, sizeof(ChainScalars), e->d_sc, e->cl_k * sizeof(ChainScalars), sizeof(ChainScalars), e->n_chains, hipMemcpyDeviceToHost);
 }
 
 extern "C" void nm_engine_destroy(nm_engine* e) { engine_free(e); }
@@ -582,14 +603,14 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     if (cl_k > 1) {
         E_TRY(hipMalloc(&e->d_cl_box, e->n_clusters * CL_BOX_WORDS * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
         E_TRY(hipMalloc(&e->d_cl_cnt, e->n_clusters * sizeof(unsigned long long)));
-        E_TRY(hipMemset(e->d_cl_box, 0, e->n_clusters * CL_BOX_WORDS * cl_k * RED_MAX_VALUES * sizeof(unsigned long long)));
+        E_TRY(hipMemsetAsync(e->d_cl_box, 0, e->n_clusters * CL_BOX_WORDS * cl_k * RED_MAX_VALUES * sizeof(unsigned long long), e->stream));
     }
     E_TRY(hipMalloc(&e->d_prof, 32 * sizeof(unsigned long long)));
-    E_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
+    E_TRY(hipMemsetAsync(e->d_prof, 0, 32 * sizeof(unsigned long long), e->stream));
     E_TRY(hipMalloc(&e->d_zig, 2 * 257 * sizeof(double)));
     E_TRY(hipMalloc(&e->d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
     E_TRY(hipMalloc(&e->d_x0, n_chains * logp->dim * sizeof(double)));
-    if (logp->n_params) E_TRY(hipMemcpy(e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    if (logp->n_params) E_TRY(copy_on(e->stream, e->d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     if (lr && logp->kind == NM_LOGP_MVN_PREC) e->h_params.assign(logp->h_params, logp->h_params + logp->n_params);
     // DiagNutsSettings on the full-precision normal: the density's P is shared by all chains whatever their mass matrices are,
     // so P x can run on the matrix cores 16 chains at a time (nuts_tile_diag_kernel) — same bits as the one-chain GEMV.
@@ -600,7 +621,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         const double* P_ = logp->h_params;
         const std::vector<double> pp = pack_mfma_operand(dim, dim, [&](uint64_t d, uint64_t j) { return P_[j * dim + d]; });
         E_TRY(hipMalloc(&e->d_tile_p, pp.size() * 8));
-        E_TRY(hipMemcpy(e->d_tile_p, pp.data(), pp.size() * 8, hipMemcpyHostToDevice));
+        E_TRY(copy_on(e->stream, e->d_tile_p, pp.data(), pp.size() * 8, hipMemcpyHostToDevice));
         e->tile_mats = {nullptr, nullptr, e->d_tile_p, (int)dim, 0, (int)((dim + 7) / 8), 0, (int)((dim + 15) / 16), 0};
         e->tile_diag_active = true;
     }
@@ -620,7 +641,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
         E_TRY(hipMalloc(&e->d_lrwin, wb));
     }
     // ziggurat tables of rand_distr's StandardNormal: the fixed ZIG_NORM_X / ZIG_NORM_F constants (zig_tables.hpp), x then f
-    E_TRY(hipMemcpy(e->d_zig, kZigTables, sizeof kZigTables, hipMemcpyHostToDevice));
+    E_TRY(copy_on(e->stream, e->d_zig, kZigTables, sizeof kZigTables, hipMemcpyHostToDevice));
     // per-chain scalars: NutsChain::new / GlobalStrategy::new state (the DualAverage is reset on the device)
     {
         std::vector<ChainScalars> sc(n_chains * cl_k);       // cluster mode: every member keeps an identical copy
@@ -636,7 +657,7 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
             q.current_window_size = s.mass_matrix_switch_freq;
             q.status = NM_CHAIN_OK;
         }
-        E_TRY(hipMemcpy(e->d_sc, sc.data(), n_chains * cl_k * sizeof(ChainScalars), hipMemcpyHostToDevice));
+        E_TRY(copy_on(e->stream, e->d_sc, sc.data(), n_chains * cl_k * sizeof(ChainScalars), hipMemcpyHostToDevice));
     }
     KParams& P = e->P;
     memset(&P, 0, sizeof P);
@@ -801,13 +822,13 @@ static bool lr_stage_update(nm_engine* e, uint64_t c, ChainScalars& q, uint64_t 
     double* pv = e->d_pvec + (size_t)c * NUM_PSLOT * dpad;
     double* lv = e->d_lrvec + (size_t)c * (1 + e->lr_rmax) * dpad;
     double* lw = e->d_lrval + (size_t)c * 2 * e->lr_rmax;
-    hipError_t er = hipMemcpy(pv + (size_t)P_SIG * dpad, stds, dim * 8, hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMemcpy(pv + (size_t)P_ISIG * dpad, isig.data(), dim * 8, hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMemcpy(pv + (size_t)P_MU * dpad, mean, dim * 8, hipMemcpyHostToDevice);
-    if (er == hipSuccess) er = hipMemcpy(lv, mu_lr, dim * 8, hipMemcpyHostToDevice);
-    if (er == hipSuccess && n_eig) er = hipMemcpy2D(lv + dpad, dpad * 8, vecs, dim * 8, dim * 8, n_eig, hipMemcpyHostToDevice);
-    if (er == hipSuccess && n_eig) er = hipMemcpy(lw, vs.data(), n_eig * 8, hipMemcpyHostToDevice);
-    if (er == hipSuccess && n_eig) er = hipMemcpy(lw + e->lr_rmax, vi.data(), n_eig * 8, hipMemcpyHostToDevice);
+    hipError_t er = copy_on(e->stream, pv + (size_t)P_SIG * dpad, stds, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = copy_on(e->stream, pv + (size_t)P_ISIG * dpad, isig.data(), dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = copy_on(e->stream, pv + (size_t)P_MU * dpad, mean, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = copy_on(e->stream, lv, mu_lr, dim * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = copy2d_on(e->stream, lv + dpad, dpad * 8, vecs, dim * 8, dim * 8, n_eig, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = copy_on(e->stream, lw, vs.data(), n_eig * 8, hipMemcpyHostToDevice);
+    if (er == hipSuccess && n_eig) er = copy_on(e->stream, lw + e->lr_rmax, vi.data(), n_eig * 8, hipMemcpyHostToDevice);
     *err = er;
     if (er != hipSuccess) return false;
     q.lr_upd_ok = 1; q.lr_upd_rank = n_eig; q.lr_upd_logdet = ld;
@@ -973,7 +994,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
         if (er != hipSuccess) return fail(NM_ERR_HIP, "upload of the transformation: %s", hipGetErrorString(er));
         sc[c].lr_pending = LR_SET_TRANSFORM;            // committed by the next launch (LowRankMassMatrix::update)
     }
-    if (per_chain) HIP_TRY(hipMemcpy(e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    if (per_chain) HIP_TRY(copy_on(e->stream, e->d_sc, sc.data(), e->n_chains * sizeof(ChainScalars), hipMemcpyHostToDevice));
     // One transformation for all chains, frozen, on the full-precision normal: the draws can run 16 chains per block with
     // U', U and P on the matrix cores (nuts_tile.hpp).  The matrices are packed in MFMA operand order once, here.
     e->tile_active = false;
@@ -1000,7 +1021,7 @@ extern "C" nm_status nm_engine_set_transform(nm_engine* e, uint64_t per_chain, u
             if (*dst) (void)hipFree(*dst);
             *dst = nullptr;
             hipError_t er = hipMalloc(dst, src.size() * 8);
-            return er != hipSuccess ? er : hipMemcpy(*dst, src.data(), src.size() * 8, hipMemcpyHostToDevice);
+            return er != hipSuccess ? er : copy_on(e->stream, *dst, src.data(), src.size() * 8, hipMemcpyHostToDevice);
         };
         HIP_TRY(up(&e->d_tile_ut, ut)); HIP_TRY(up(&e->d_tile_u, u)); HIP_TRY(up(&e->d_tile_p, pp));
         e->tile_mats = {e->d_tile_ut, e->d_tile_u, e->d_tile_p, (int)dim, (int)n_eig, (int)((dim + 7) / 8), (int)((n_eig + 7) / 8),
@@ -1023,9 +1044,9 @@ extern "C" nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, doub
     for (uint64_t c = 0; c < e->n_chains; ++c) {
         if (h_n_eig) h_n_eig[c] = sc[c].lr_has_inner ? sc[c].lr_rank : 0;
         const double* lv = e->d_lrvec + (size_t)c * (1 + R) * dpad;
-        if (h_mu_lr) HIP_TRY(hipMemcpy(h_mu_lr + c * dim, lv, dim * 8, hipMemcpyDeviceToHost));
-        if (h_vecs) HIP_TRY(hipMemcpy2D(h_vecs + c * R * dim, dim * 8, lv + dpad, dpad * 8, dim * 8, R, hipMemcpyDeviceToHost));
-        if (h_vals_sqrt) HIP_TRY(hipMemcpy(h_vals_sqrt + c * R, e->d_lrval + (size_t)c * 2 * R, R * 8, hipMemcpyDeviceToHost));
+        if (h_mu_lr) HIP_TRY(copy_on(e->stream, h_mu_lr + c * dim, lv, dim * 8, hipMemcpyDeviceToHost));
+        if (h_vecs) HIP_TRY(copy2d_on(e->stream, h_vecs + c * R * dim, dim * 8, lv + dpad, dpad * 8, dim * 8, R, hipMemcpyDeviceToHost));
+        if (h_vals_sqrt) HIP_TRY(copy_on(e->stream, h_vals_sqrt + c * R, e->d_lrval + (size_t)c * 2 * R, R * 8, hipMemcpyDeviceToHost));
     }
     return NM_OK;
 }
@@ -1051,7 +1072,7 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         nm_status st = collect_timing(e);
         if (st != NM_OK) return st;
-        HIP_TRY(hipMemcpy(sc.data(), e->d_sc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on(e->stream, sc.data(), e->d_sc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
         std::vector<uint64_t> pend;
         for (uint64_t c = 0; c < nc; ++c)
             if (sc[c].status == NM_CHAIN_OK && sc[c].lr_pending == LR_WAIT_HOST) pend.push_back(c);
@@ -1137,7 +1158,7 @@ static nm_status lr_draw(nm_engine* e, uint64_t n_draws, const KParams& P_in) {
         e->lr_download_seconds += std::chrono::duration<double>(t1 - t0).count();
         e->lr_estimator_seconds += std::chrono::duration<double>(t2 - t1).count();
         e->lr_upload_seconds += std::chrono::duration<double>(t3 - t2).count();
-        HIP_TRY(hipMemcpy(e->d_sc, sc.data(), nc * sizeof(ChainScalars), hipMemcpyHostToDevice));
+        HIP_TRY(copy_on(e->stream, e->d_sc, sc.data(), nc * sizeof(ChainScalars), hipMemcpyHostToDevice));
     }
     e->draws_total += n_draws;
     e->draws_launched += n_draws;
@@ -1350,10 +1371,13 @@ extern "C" nm_status nm_debug_xcc_ids(unsigned* h_out, unsigned n_blocks) {
     if (st != NM_OK) return st;
     unsigned* d = nullptr;
     HIP_TRY(hipMalloc(&d, n_blocks * sizeof(unsigned)));
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_blocks), dim3(64), 0, nullptr, d);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_out, d, n_blocks * sizeof(unsigned), hipMemcpyDeviceToHost));
+    hipStream_t s = nullptr;
+    hipError_t er = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (er == hipSuccess) { hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_blocks), dim3(64), 0, s, d); er = hipGetLastError(); }
+    if (er == hipSuccess) er = copy_on(s, h_out, d, n_blocks * sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (s) (void)hipStreamDestroy(s);
     (void)hipFree(d);
+    if (er != hipSuccess) return fail(NM_ERR_HIP, "xcc probe: %s", hipGetErrorString(er));
     return NM_OK;
 }
 
@@ -1362,8 +1386,9 @@ extern "C" nm_status nm_debug_read_prof(nm_engine* e, unsigned long long out[32]
     if (!e || !out) return fail(NM_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(out, e->d_prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(e->d_prof, 0, 32 * sizeof(unsigned long long)));
+    HIP_TRY(copy_on(e->stream, out, e->d_prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemsetAsync(e->d_prof, 0, 32 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return NM_OK;
 }
 
@@ -1376,12 +1401,12 @@ static nm_status read_slot(nm_engine* e, int slot, double* h_out) {
     if (e->cl_k > 1) {      // a chain's vector is the concatenation of its members' slices
         for (uint64_t m = 0; m < e->cl_k; ++m) {
             const uint64_t off = m * P.cl_slice, len = std::min<uint64_t>(P.cl_slice, e->dim - off);
-            HIP_TRY(hipMemcpy2D(h_out + off, e->dim * sizeof(double), e->d_pvec + (m * NUM_PSLOT + (size_t)slot) * P.dpad,
+            HIP_TRY(copy2d_on(e->stream, h_out + off, e->dim * sizeof(double), e->d_pvec + (m * NUM_PSLOT + (size_t)slot) * P.dpad,
                                 (size_t)e->cl_k * NUM_PSLOT * P.dpad * sizeof(double), len * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
         }
         return NM_OK;
     }
-    HIP_TRY(hipMemcpy2D(h_out, e->dim * sizeof(double), e->d_pvec + (size_t)slot * P.dpad,
+    HIP_TRY(copy2d_on(e->stream, h_out, e->dim * sizeof(double), e->d_pvec + (size_t)slot * P.dpad,
                         (size_t)NUM_PSLOT * P.dpad * sizeof(double), e->dim * sizeof(double), e->n_chains, hipMemcpyDeviceToHost));
     return NM_OK;
 }
@@ -1627,7 +1652,7 @@ extern "C" nm_status nm_leapfrog_batch(const nm_logp_spec* logp, uint64_t n, uin
     if (n == 0) return NM_OK;
     double* d_params = nullptr;
     HIP_TRY(hipMalloc(&d_params, (logp->n_params ? logp->n_params : 1) * sizeof(double)));
-    if (logp->n_params) HIP_TRY(hipMemcpy(d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
+    if (logp->n_params) HIP_TRY(copy_on((hipStream_t)stream, d_params, logp->h_params, logp->n_params * sizeof(double), hipMemcpyHostToDevice));
     LfArgs A;
     memset(&A, 0, sizeof A);
     A.P.dim = logp->dim; A.P.dpad = 64ull * dpl; A.P.logp_params = d_params; A.P.n_chains = n;
@@ -1732,12 +1757,12 @@ extern "C" nm_status nm_standard_normal_batch(uint64_t n, uint64_t count, const 
     HIP_TRY(hipMalloc(&d_keys, keys.size() * 4));
     HIP_TRY(hipMalloc(&d_zig, t.size() * 8));
     HIP_TRY(hipMalloc(&d_words, n * 8));
-    HIP_TRY(hipMemcpy(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_zig, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(copy_on((hipStream_t)stream, d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_on((hipStream_t)stream, d_zig, t.data(), t.size() * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(normal_batch_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, count, d_keys, d_zig, d_zig + 257, d_out, d_words);
     hipError_t er = hipGetLastError();
     if (er == hipSuccess) er = hipStreamSynchronize((hipStream_t)stream);
-    if (er == hipSuccess && h_words_consumed) er = hipMemcpy(h_words_consumed, d_words, n * 8, hipMemcpyDeviceToHost);
+    if (er == hipSuccess && h_words_consumed) er = copy_on((hipStream_t)stream, h_words_consumed, d_words, n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d_keys); (void)hipFree(d_zig); (void)hipFree(d_words);
     if (er != hipSuccess) return fail(NM_ERR_HIP, "standard_normal_batch: %s", hipGetErrorString(er));
     return NM_OK;

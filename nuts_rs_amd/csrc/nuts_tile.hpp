@@ -63,11 +63,22 @@ struct TileShared {
     double sig[TD], mu[TD];  // the shared DiagMassMatrix part (tile order of a one-wave chain)
     double scale[2][TD];     // lambda^(1/2) - 1, lambda^(-1/2) - 1
     int which[TC];           // per column: the scale its current apply uses
-    int done;                // monotone count of finished (wave, draw) pairs
+    int done[2];             // monotone counts of finished (wave, draw) pairs, one per draw parity (see tile_all_done)
 };
 // element (row, chain column) of a column tile: 16 doubles per row, columns xor-swizzled so that a wavefront writing its
 // own column (rows 2 t, 2 t + 1 per lane) spreads over the banks, while the B-operand read of a row stays a permutation
 NM_DEV int taddr(int row, int c) { return row * TC + ((c ^ (row >> 1)) & (TC - 1)); }     // (c may be an MFMA column >= TC: it mirrors column c - TC)
+
+// The end of a draw is a BLOCK-UNIFORM decision: every wave reads the counter of the current draw right after the same barrier and
+// must see the same value.  With one counter a wave whose chain is absent or failed could leave draw d and count itself into draw
+// d + 1 before a slower wave had read the counter for draw d — that wave then saw 16 (d + 1) + 1, stayed in its waiting loop, and
+// the barrier phases of the block parted for good.  Draw d therefore counts in done[d & 1], whose target is
+// 16 (d / 2 + 1): a wave of draw d + 1 touches the OTHER counter, and no wave reaches draw d + 2 before every wave has left draw
+// d + 1, i.e. long after all reads for draw d.
+NM_DEV void tile_count_done(int* done, int draws_done) { if (lane_id() == 0) atomicAdd(&done[draws_done & 1], 1); }
+NM_DEV bool tile_all_done(const int* done, int draws_done) {
+    return __builtin_amdgcn_readfirstlane(*(volatile const int*)&done[draws_done & 1]) == (NM_TILE_CHAINS) * ((draws_done >> 1) + 1);
+}
 
 NM_DEV void tile_barrier() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
@@ -138,8 +149,7 @@ NM_DEV bool apply_round(TileRef& X, int which, Tile<DPL>* v, bool may_exit) {
     }
     tile_barrier();
     if (may_exit) {                                   // only ever evaluated true when all 16 are in their waiting loops
-        const int done = __builtin_amdgcn_readfirstlane(*(volatile int*)&T.done);
-        if (done == TC * (X.draws_done + 1)) return true;
+        if (tile_all_done(T.done, X.draws_done)) return true;
     }
     for (int s = w; s < X.M.rank_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -181,8 +191,7 @@ NM_DEV bool density_only_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y, boo
     if (x) put_col(T.zin, w, *x);
     tile_barrier();
     if (may_exit) {                                   // only ever evaluated true when all 16 are in their waiting loops
-        const int done = __builtin_amdgcn_readfirstlane(*(volatile int*)&T.done);
-        if (done == TC * (X.draws_done + 1)) return true;
+        if (tile_all_done(T.done, X.draws_done)) return true;
     }
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_draw_
     __shared__ TileShared T;
     dm_init_lds();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) T.done = 0;
+    if (threadIdx.x == 0) { T.done[0] = 0; T.done[1] = 0; }
     int draws_done = 0;
     const uint64_t n_tiles = (P.n_chains + TC - 1) / TC;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_draw_
         for (uint64_t t = P.row_base; t < P.draw_end; ++t) {
             X.draws_done = draws_done;
             if (ok && C.sc.draw_count == t) ok = chain_draw_lr(C, chain) && C.sc.status == NM_CHAIN_OK;
-            if (lane_id() == 0) atomicAdd(&T.done, 1);
+            tile_count_done(T.done, draws_done);
             // attend the block's rendezvous with an empty column until every chain of the tile has finished this draw
             for (;;) {
                 if (apply_round<DPL>(X, 0, (Tile<DPL>*)nullptr, true)) break;
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_diag_
     __shared__ TileShared T;
     dm_init_lds();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) T.done = 0;
+    if (threadIdx.x == 0) { T.done[0] = 0; T.done[1] = 0; }
     int draws_done = 0;
     const uint64_t n_tiles = (P.n_chains + TC - 1) / TC;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(64 * TC, NM_TILE_OCC * TC / 4) void nuts_tile_diag_
         for (uint64_t t = 0; t < P.n_draws; ++t) {
             X.draws_done = draws_done;
             if (ok) { chain_draw(C, chain, t); ok = C.sc.status == NM_CHAIN_OK; }
-            if (lane_id() == 0) atomicAdd(&T.done, 1);
+            tile_count_done(T.done, draws_done);
             while (!density_only_round<DPL>(X, (const Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, true)) {}
             draws_done += 1;
         }

@@ -138,9 +138,6 @@ extern "C" int nm_probe_bandwidth_impl(uint64_t kind, uint64_t bytes_per_array, 
     if (needs_b && (e = hipMalloc(&b, n16 * 16)) != hipSuccess) return fin(e);
     if (needs_c && (e = hipMalloc(&c, n16 * 16)) != hipSuccess) return fin(e);
     if ((e = hipMalloc(&sink, 8)) != hipSuccess) return fin(e);
-    if (a && (e = hipMemset(a, 0x11, n16 * 16)) != hipSuccess) return fin(e);
-    if (b && (e = hipMemset(b, 0x22, n16 * 16)) != hipSuccess) return fin(e);
-    if (c && (e = hipMemset(c, 0, n16 * 16)) != hipSuccess) return fin(e);
     int cus = 256;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -149,6 +146,11 @@ extern "C" int nm_probe_bandwidth_impl(uint64_t kind, uint64_t bytes_per_array, 
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fin(e);
+    // the fills run on the probe's own stream: a null-stream fill is not ordered against a hipStreamNonBlocking stream
+    if (a && e == hipSuccess) e = hipMemsetAsync(a, 0x11, n16 * 16, st);
+    if (b && e == hipSuccess) e = hipMemsetAsync(b, 0x22, n16 * 16, st);
+    if (c && e == hipSuccess) e = hipMemsetAsync(c, 0, n16 * 16, st);
+    if (e != hipSuccess) { (void)hipStreamDestroy(st); return fin(e); }
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     double best = -1.0;
     for (int variant = 0; variant < 4 && e == hipSuccess; ++variant) {           // the fastest launch shape is the probe's answer

@@ -3,7 +3,9 @@
 //   no GPU : prints "NM_ERR_NO_DEVICE" and exits 3 (the engine has no CPU fallback)
 //   GPU    : writes [1400][4][10] doubles of draws (chains seeded like the reference's Sampler) and exits 0
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "nuts_amd.hpp"
@@ -40,6 +42,20 @@ int main(int argc, char** argv) {
         uint64_t steps2 = 0;
         for (const ChainProgress& p : pr) steps2 += p.total_num_steps;
         if (steps2 != steps || pr[0].finished_draws != total || pr[0].tuning) { std::printf("ChainProgress mismatch\n"); return 1; }
+        {   // inspect() clones and never consumes (src/sampler.rs:1469-1485): polled after the run has ended it keeps returning the
+            // whole trace, and the consuming wait_timeout() afterwards still hands all draws over
+            Sampler ctl2(settings, logp, std::vector<double>(4 * 10, 0.0), 200);
+            for (int spin = 0; spin < 12000 && ctl2.inspect().second.n_draws != total; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));           // (the controller thread has set done_ by now)
+            const auto a = ctl2.inspect(), b = ctl2.inspect();
+            Sampler::WaitResult r2 = ctl2.wait_timeout(std::chrono::seconds(120));
+            if (a.second.n_draws != total || b.second.n_draws != total || r2.kind != Sampler::WaitKind::Trace || r2.trace.n_draws != total ||
+                a.second.positions != trace || b.second.positions != trace || r2.trace.positions != trace) {
+                std::printf("inspect() after the end of the run lost draws (%llu, %llu, %llu of %llu)\n", (unsigned long long)a.second.n_draws,
+                            (unsigned long long)b.second.n_draws, (unsigned long long)r2.trace.n_draws, (unsigned long long)total);
+                return 1;
+            }
+        }
         if (argc > 1) {
             std::FILE* f = std::fopen(argv[1], "wb");
             std::fwrite(trace.data(), sizeof(double), trace.size(), f);

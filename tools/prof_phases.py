@@ -32,7 +32,15 @@ def main():
     tune = int(sys.argv[3]) if len(sys.argv) > 3 else 400
     draws = int(sys.argv[4]) if len(sys.argv) > 4 else 200
     s = N.DiagNutsSettings(num_chains=chains, seed=20260928, num_tune=tune, num_draws=draws)
-    b = N.ChainBatch(s, N.LogpSpec.iid_normal(dim, 3.0), chains)
+    # PROF_LOGP=funnel: Neal's funnel at `dim`; PROF_FIXED_STEP=<eps>: fixed step size without jitter (deep trees on demand);
+    # PROF_MAXDEPTH=<d>
+    if os.environ.get("PROF_FIXED_STEP"):
+        st = s.adapt_options.step_size_settings
+        st.method, st.fixed_step_size, st.jitter = N.sampler.STEP_FIXED, float(os.environ["PROF_FIXED_STEP"]), None
+    if os.environ.get("PROF_MAXDEPTH"):
+        s.maxdepth = int(os.environ["PROF_MAXDEPTH"])
+    logp = N.LogpSpec.funnel(dim) if os.environ.get("PROF_LOGP") == "funnel" else N.LogpSpec.iid_normal(dim, 3.0)
+    b = N.ChainBatch(s, logp, chains)
     b.set_position(b.init_positions_uniform())
     L = _lib.load()
     L.nm_debug_read_prof.argtypes = [C.c_void_p, C.c_void_p]
