@@ -19,7 +19,10 @@ UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lr_mvn_prec.h
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
          "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
          "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip",
-         "lowrank_host.cpp"]
+         "lowrank_host.cpp", "lowrank_host.cpp@avx2", "lowrank_dispatch.cpp"]
+# "<file>@<variant>": the same source compiled a second time (lowrank_host.cpp: plain x86-64 and -mavx2 -mfma; a run-time dispatcher picks)
+VARIANT_FLAGS = {"": ["-DNM_LR_IMPL_NAME=nm_lowrank_compute_update_base"],
+                 "avx2": ["-mavx2", "-mfma", "-DNM_LR_IMPL_NAME=nm_lowrank_compute_update_avx2"]}
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)
@@ -53,12 +56,17 @@ def _includes(path, seen=None):
     return seen
 
 
+def _src(u):
+    return os.path.join(CSRC, u.split("@")[0])
+
+
 def _obj(u):
-    return os.path.join(OBJ, u.replace(".hip", ".o").replace(".cpp", ".o"))
+    name, _, variant = u.partition("@")
+    return os.path.join(OBJ, name.replace(".hip", "").replace(".cpp", "") + ("_" + variant if variant else "") + ".o")
 
 
 def _unit_stale(u):
-    src = os.path.join(CSRC, u)
+    src = _src(u)
     return _newer(_obj(u), [src] + sorted(_includes(src)))
 
 
@@ -75,9 +83,9 @@ def build(force=False, verbose=False, extra_flags=()):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
     def compile_unit(u):
-        src, obj = os.path.join(CSRC, u), _obj(u)
+        src, obj = _src(u), _obj(u)
         if force or _unit_stale(u):
-            host_only = ["-mavx2", "-mfma"] if u.endswith(".cpp") else []     # the host estimator's dense loops (no contraction: -ffp-contract=off)
+            host_only = VARIANT_FLAGS[u.partition("@")[2]] if u.startswith("lowrank_host.cpp") else []
             cmd = [hipcc] + FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)

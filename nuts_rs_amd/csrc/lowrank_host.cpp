@@ -294,7 +294,14 @@ bool spd_mean(const Mat& cov_draws, const Mat& cov_grads, Mat& out) {
 }  // namespace
 
 // declared in include/nuts_amd.h.  draws / grads: [n_draws][dim] (row = one draw); vecs out: [n_eig][dim].
-extern "C" int nm_lowrank_compute_update(void*, uint64_t dim_, uint64_t n_, const double* draws_in, const double* grads_in,
+// This file is compiled TWICE (nuts_rs_amd/build.py): plain x86-64 as nm_lowrank_compute_update_base, and with -mavx2 -mfma as
+// nm_lowrank_compute_update_avx2 (its dense loops vectorise; no contraction: -ffp-contract=off, so both give the same bits);
+// lowrank_dispatch.cpp exports nm_lowrank_compute_update and picks one by what the CPU it runs on supports (a library built here
+// must not die with SIGILL on a host without AVX2).
+#ifndef NM_LR_IMPL_NAME
+#define NM_LR_IMPL_NAME nm_lowrank_compute_update_base
+#endif
+extern "C" int NM_LR_IMPL_NAME(void*, uint64_t dim_, uint64_t n_, const double* draws_in, const double* grads_in,
                                          double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
                                          double* vals_out, double* vecs_out, double* mu_out) {
     const size_t dim = dim_, n = n_;

@@ -527,7 +527,8 @@ extern "C" nm_status nm_engine_create(const nm_settings* settings, const nm_logp
     e->cl_k = cl_k;
     (void)hipGetDevice(&e->device);
     const uint64_t dpad = 64ull * (uint64_t)dpl * (uint64_t)wv;
-    const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth);
+    // (tilings with batched merges keep the z of the last NM_RING leaves behind the tree's other scratch slots: resolve_chunk)
+    const uint64_t nsslot = (uint64_t)num_sslots((int)s.maxdepth) + ((dpl <= 4 && wv == 1 && cl_k == 1) ? (uint64_t)NM_RING : 0);
 #define E_TRY(expr)                                                                                 \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \

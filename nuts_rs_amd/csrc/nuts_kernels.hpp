@@ -66,6 +66,14 @@ __host__ __device__ inline int slot_F(int k) { return S_DYN + 2 * k; }
 __host__ __device__ inline int slot_L(int maxdepth, int k) { return S_DYN + 2 * (maxdepth + 1) + 2 * k; }
 __host__ __device__ inline int slot_C(int maxdepth, int p) { return S_DYN + 4 * (maxdepth + 1) + p; }
 __host__ __device__ inline int num_sslots(int maxdepth) { return S_DYN + 4 * (maxdepth + 1) + (maxdepth + 3); }
+// Batched merges (DPL <= 4, one wave per chain; see resolve_chunk): the z of the last NM_RING leaves, one slot per leaf (leaf n of
+// a doubling lives in slot n mod NM_RING), behind the slots above.  The host adds NM_RING to nsslot for these tilings.
+constexpr int NM_RING = 64;
+__host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(maxdepth) + i; }
+#ifndef NM_BATCH_MERGES
+#define NM_BATCH_MERGES 1        // 0: every merge evaluated where the reference evaluates it (tuning / bisecting builds)
+#endif
+template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && !NM_TILE_MODE && !NM_CLUSTER_MODE; }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
 struct ChainScalars {
@@ -1022,6 +1030,9 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
 template <int DPL, int W, class Dens>
 NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
+#ifdef NM_X_NO_LEAPFROG           // timing experiment only: the tree without its integrator
+    if (!x_out && !gx_out) { o.z = s.z; o.v = s.v; o.g = s.g; o.logp = s.logp + epsilon * 1e-6; o.ke = s.ke; return; }
+#endif
     if constexpr (kin_trait<Dens>::value) {
         if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { leapfrog_kin(C, s, o, epsilon, x_out, gx_out); return; }
     }
@@ -1676,6 +1687,10 @@ enum TreeStop { STOP_NONE = 0, STOP_TURNING = 1, STOP_DIVERGING = 2, STOP_FATAL 
 // multinomial merge weights (reference merge_into, src/nuts.rs:172-207).  Returns take_B.
 template <int DPL, int W, class Dens>
 NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
+#ifdef NM_X_NO_MERGE_MATH      // timing experiment only (results are wrong): what do the merges' special functions + Bernoulli cost?
+    total = (a_log_size > b_log_size ? a_log_size : b_log_size) + 0.5; (void)is_main; (void)fatal;
+    return false;
+#endif
     NM_MARK(C, 13)
     total = logaddexp(a_log_size, b_log_size);
     NM_MARK(C, 14)
@@ -1720,6 +1735,123 @@ NM_DEV int cand_to_pool(ChainCtx<DPL, W, Dens>& C, uint32_t& used, const Tile<DP
     used |= 1u << p;
     C.storeS_nt(z, slot_C(C.maxdepth_cfg, p));
     return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched multinomial merges (round 3).  Measured on one funnel chain (tools/leaf_latency.py, profiles/r03*): of the 2.23 us a
+// leaf costs a lone wavefront, 0.93 us are the merges' scalar arithmetic — logaddexp (exp + ln_1p), exp, a Bernoulli word — a
+// dependent chain evaluated 64 lanes wide for ONE value, once per leaf.  But a merge needs nothing from the leapfrogs that
+// follow it, and nothing that follows needs the merge before the doubling ends: U-turn tests read end points, divergence reads
+// energies, and the multinomial candidate is consumed by the merge into the main tree.  So the merges of levels 1..6 are
+// deferred and evaluated per aligned chunk of 64 leaves, VECTORISED: lane n keeps the log-weight of leaf n (the AcceptCollector
+// trick), level k of the merge tree is ONE evaluation of the special functions across the lanes that close a level-k sub-tree
+// (32, 16, .. 1 merges at once), six rounds for 63 merges.  Each merge computes exactly what merge_into computes
+// (src/nuts.rs:172-207) on the same operands, so the bits are the same; the random words are handed out afterwards in the
+// reference's post-order (by closing leaf, then by level: a prefix count over the lanes of the merges that consume a word), so
+// the stream position and every Bernoulli outcome are the sequential ones.  A doubling that stops early (U-turn at level k of
+// leaf n, divergence) performed, in the reference, exactly the merges that close at leaves before n plus levels 1..k at n: the
+// same routine counts their words with a mask (their outcomes die with the discarded sub-tree).  Levels >= 7 (one merge per 64
+// leaves) stay sequential, with the chunk as their "leaf".  The candidate of an unresolved sub-tree is not known when its
+// registers are reused, so every leaf's z goes to a ring of NM_RING scratch slots (one streaming store per leaf instead of one
+// candidate store per pair); the winner is copied to the candidate pool when its chunk becomes a pending sub-tree.
+// ---------------------------------------------------------------------------------------------
+struct ChunkResult { double log_size; int cand_lane; bool fatal; };
+NM_DEV double shfl_f64(double x, int src_lane) {
+    const int lo = __shfl(__double2loint(x), src_lane), hi = __shfl(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+// Eighteen inlined special-function evaluations: the transition has exactly ONE call site for it (three of them pushed the leaf
+// loop's registers into scratch: 503 spilled SGPRs; as a real call it corrupted the LrWrap<HostCb> kernel's state).
+// wv: lane l holds the log-weight of the chunk's leaf l.  The merges performed are those closing at lanes < n_last (every
+// level up to m) and levels 1..k_last at lane n_last (packed: m | n_last << 8 | k_last << 16).  `words` points at the chain's
+// next random word in the LDS cache (the caller made sure 128 words are there).  Returns the level-m node's log size
+// (meaningful when the chunk is complete: n_last = 2^m - 1, k_last = m) and, packed, its candidate lane | fatal << 8 |
+// words consumed << 16.
+struct ChunkOut { double log_size; uint32_t packed; };
+typedef const __attribute__((address_space(3))) uint32_t* lds_words_t;       // an LDS pointer (ds_read, not a flat load)
+NM_DEV ChunkOut resolve_chunk_core(double wv, uint32_t shape, lds_words_t words) {
+    const int m = (int)(shape & 0xff), n_last = (int)((shape >> 8) & 0xff), k_last = (int)((shape >> 16) & 0xff);
+    const int l = lane_id();
+    const double ln2 = dlog_impl<false>(2.0);
+    double ls = wv;                      // log size of the sub-tree this lane currently closes (level 0: its own leaf)
+    uint64_t pint[6];                    // Bernoulli thresholds of this lane's merges, by level
+    uint32_t need = 0, sure = 0, bad = 0, perf = 0;
+#pragma unroll
+    for (int k = 1; k <= 6; ++k) {
+        pint[k - 1] = 0;
+        if (k <= m) {                    // (m is wave-uniform)
+            const int h = 1 << (k - 1);
+            const bool part = ((l + 1) & ((1 << k) - 1)) == 0;                    // this lane closes a level-k sub-tree
+            const bool done = part && (l < n_last || (l == n_last && k <= k_last));
+            const double a = shfl_f64(ls, l - h), b = ls;                         // A = the sibling that closed h leaves earlier
+            const double diff = a - b;
+            const double e = dexp_impl<false>(diff > 0. ? -diff : diff);
+            const double lp = dlog1p_impl<false>(e);
+            const double total = a == b ? a + ln2 : (diff > 0. ? a + lp : (diff < 0. ? b + lp : diff));   // logaddexp (util.rs:6-19)
+            const bool ge = b >= total;                                           // self.log_size = the merged size (not the main tree)
+            const double p_ = dexp_impl<false>(b - total);
+            const bool in01 = p_ >= 0.0 && p_ < 1.0;                              // random_bool(p): p outside [0, 1) draws nothing
+            pint[k - 1] = in01 ? (uint64_t)(p_ * 18446744073709551616.0) : 0ull;
+            if (done) {
+                perf |= 1u << k;
+                if (ge || (!in01 && p_ == 1.0)) sure |= 1u << k;
+                else if (in01) need |= 1u << k;
+                else bad |= 1u << k;
+            }
+            if (part) ls = total;
+        }
+    }
+    const uint32_t fatal = __ballot(bad != 0) != 0ull ? 1u : 0u;
+    // the words, in post-order: by closing lane, then by level
+    uint32_t before = 0, total_words = 0;
+#pragma unroll
+    for (int k = 1; k <= 6; ++k) {
+        const uint64_t bm = __ballot((need >> k) & 1u);
+        before += __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+        total_words += 2u * (uint32_t)__builtin_popcountll(bm);
+    }
+    uint32_t take = sure;
+#pragma unroll
+    for (int k = 1; k <= 6; ++k) {
+        if ((need >> k) & 1u) {
+            const uint32_t q = before + (uint32_t)__builtin_popcount(need & ((1u << k) - 1u));
+            const uint64_t w = ((uint64_t)words[2u * q + 1u] << 32) | words[2u * q];
+            if (w < pint[k - 1]) take |= 1u << k;
+        }
+    }
+    // candidates: the merged sub-tree keeps A's draw unless B's is taken (src/nuts.rs:199-205)
+    int cand = l;
+#pragma unroll
+    for (int k = 1; k <= 6; ++k) {
+        if (k <= m) {
+            const int from = __shfl(cand, l - (1 << (k - 1)));
+            if ((perf >> k) & 1u) cand = ((take >> k) & 1u) ? cand : from;
+        }
+    }
+    const int top = (1 << m) - 1;
+    ChunkOut R;
+    R.log_size = readlane_f64(ls, top);
+    R.packed = (uint32_t)__builtin_amdgcn_readlane(cand, top) | (fatal << 8) | ((uint32_t)__builtin_amdgcn_readfirstlane((int)total_words) << 16);
+    return R;
+}
+template <int DPL, int W, class Dens>
+NM_DEV ChunkResult resolve_chunk(ChainCtx<DPL, W, Dens>& C, double wv, int m, int n_last, int k_last) {
+    if (!C.rng.has(128)) C.rng.refill();                                          // at most 63 merges x 2 words
+    const ChunkOut o = resolve_chunk_core(wv, (uint32_t)m | ((uint32_t)n_last << 8) | ((uint32_t)k_last << 16),
+                                          (lds_words_t)(C.rng.cache + (uint32_t)(C.rng.pos - C.rng.base)));
+    C.rng.pos += (uint64_t)(o.packed >> 16);
+    ChunkResult R;
+    R.log_size = uniform_f64(o.log_size);
+    R.cand_lane = __builtin_amdgcn_readfirstlane((int)(o.packed & 0xff));
+    R.fatal = ((o.packed >> 8) & 1u) != 0;
+    return R;
+}
+// the chunk's winner leaves the ring: its z goes to a pool slot (the ring is overwritten by the next 64 leaves)
+template <int DPL, int W, class Dens>
+NM_DEV int ring_to_pool(ChainCtx<DPL, W, Dens>& C, uint32_t& used, int ring_lane) {
+    Tile<DPL> z;
+    C.loadS(z, slot_R(C.maxdepth_cfg, ring_lane));
+    return cand_to_pool(C, used, z);
 }
 
 // nuts::draw (reference src/nuts.rs:281-388).  On entry the chain's current point is in its slots P_*.
@@ -1777,6 +1909,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     [[maybe_unused]] double left_ke = ke_init, right_ke = ke_init;   // the edges' kinetic_energy: an input of the microcanonical leapfrog only
     CandRef mc = {-1, sc.logp, ke_init, 0};
     uint32_t used = 0;   // candidate-pool occupancy bitmask
+    // batched merges (resolve_chunk): lane (n mod 64) keeps leaf n's log-weight, logp and kinetic energy until its chunk is resolved
+    constexpr bool BATCH = batched_merges<DPL, W>();
+    [[maybe_unused]] double wv = 0., lpv = 0., kev = 0.;
 
     uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
     if (s.has_target_integration_time) {                         // src/nuts.rs:300-320
@@ -1916,6 +2051,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if constexpr (kin_trait<Dens>::value) O.ke = fwd ? right_ke : left_ke;
             }
             for (uint64_t n = 0; n < nleaf; n += 2) {
+                if constexpr (!BATCH) {
+                // ======== every merge where the reference evaluates it (tilings without the batched merges; unchanged since round 2) ========
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
                 NM_MARK(C, 16)
@@ -2049,6 +2186,210 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
                     C.pend[t] = e;
                 }
+                } else {
+                // ======== batched merges (resolve_chunk): DPL <= 4, one wave per chain ========
+                // ---- even leaf n
+                double wE = 0., wO = 0.;
+                NM_MARK(C, 16)
+                leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                NM_MARK(C, 17)
+                E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
+                NM_LEAF_ACCOUNT(O, E, wE)
+                // BATCH: what the single resolve_chunk site below has to do for this pair — the merges closing at lanes < rs_nl
+                // and levels 1..rs_kl at lane rs_nl (a divergence: the merges that closed before the divergent leaf drew their
+                // words, src/nuts.rs:131-136; the even leaf closes nothing, so both leaves of a pair give lane n - 1)
+                [[maybe_unused]] bool rs_do = false;
+                [[maybe_unused]] int rs_nl = 0, rs_kl = 0;
+                const int mm = depth < 6 ? (int)depth : 6;      // levels the batch covers
+                if constexpr (BATCH) {
+                    if (stop == STOP_DIVERGING && (n & 63) != 0) {
+                        rs_do = true; rs_nl = (int)(n & 63) - 1; rs_kl = (int)__builtin_ctz(~(unsigned)rs_nl);
+                    }
+                }
+                if (stop == STOP_NONE) {
+                if constexpr (BATCH) {
+                    if (lane_id() == (int)(n & 63)) { wv = wE; lpv = E.logp; kev = E.ke; }
+                }
+                // ---- odd leaf n + 1
+                NM_MARK(C, 18)
+                leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                NM_MARK(C, 19)
+                O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
+                NM_LEAF_ACCOUNT(E, O, wO)
+                if constexpr (BATCH) {
+                    if (stop == STOP_DIVERGING && (n & 63) != 0) {
+                        rs_do = true; rs_nl = (int)(n & 63) - 1; rs_kl = (int)__builtin_ctz(~(unsigned)rs_nl);
+                    }
+                }
+                }
+                const uint64_t nn = n + 1;
+                const int t = (int)__builtin_ctzll(~nn);           // trailing ones of the odd leaf: merges up to level t
+                // ---- every U-turn test this leaf completes (levels 1..t, and the top-level one when it is the last leaf
+                // of the doubling) BEFORE any merge arithmetic: the tests only read fixed end points, so their HBM round
+                // trips overlap each other instead of alternating with the merges' long scalar chains (exp, ln_1p,
+                // Bernoulli), which run afterwards on the recorded bits.  A turning level ends the doubling, so higher
+                // levels are not even loaded.  Bit k of turn_bits: the level-k test says "turning".
+                uint32_t turn_bits = 0;
+                bool chunk_end = false;      // BATCH: this leaf closes its chunk (64 leaves, or the whole doubling when it is smaller)
+                if (stop == STOP_NONE) {
+                if constexpr (BATCH) {
+                    if (lane_id() == (int)((n + 1) & 63)) { wv = wO; lpv = O.logp; kev = O.ke; }
+                }
+                    NM_MARK(C, 20)
+                    if (check) {
+                        if (turning_regs(E, O, fwd, C.red)) turn_bits |= 2u;
+                        for (int k = 2; k <= t && turn_bits == 0; ++k) {
+                            // (A.first,B.last) (A.last,B.last) (A.first,B.first) in generation order  [src/nuts.rs:143-161]
+                            const uint64_t a_first = nn + 1 - (1ull << k);
+                            const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
+                            const int so_afz = C.soS(slot_F(fa)), so_afv = C.soS(slot_F(fa) + 1);
+                            const int so_alz = C.soS(slot_L(MD, k - 1)), so_alv = C.soS(slot_L(MD, k - 1) + 1);
+                            double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+                            if (k == 2) {
+                                const double2* l1z2 = C.tptr(C.l1z);      // A.last = L[1] lives in LDS
+                                const double2* l1v2 = C.tptr(C.l1v);
+#pragma unroll
+                                for (int m = 0; m < DPL / 2; ++m) {
+                                    const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
+                                    const double2 lz = l1z2[m * 64 * W], lv = l1v2[m * 64 * W];
+#pragma unroll
+                                    for (int j = 0; j < 2; ++j) {
+                                        const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
+                                        const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
+                                        const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
+                                        const double bz = E.z.a[2 * m + j], bv = E.v.a[2 * m + j];
+                                        if (fwd) {
+                                            turn_acc(azj, avj, cz, cv, s1, s2);
+                                            turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                            turn_acc(azj, avj, bz, bv, s5, s6);
+                                        } else {
+                                            turn_acc(cz, cv, azj, avj, s1, s2);
+                                            turn_acc(cz, cv, lzj, lvj, s3, s4);
+                                            turn_acc(bz, bv, azj, avj, s5, s6);
+                                        }
+                                    }
+                                    NM_GROUP_BARRIER(m);
+                                }
+                            } else {
+                                const int so_bfz = C.soS(slot_F(k - 1)), so_bfv = C.soS(slot_F(k - 1) + 1);
+#pragma unroll
+                                for (int m = 0; m < DPL / 2; ++m) {
+                                    const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
+                                    const double2 lz = C.ld2(C.rs, so_alz, m), lv = C.ld2(C.rs, so_alv, m);
+                                    const double2 bz2 = C.ld2(C.rs, so_bfz, m), bv2 = C.ld2(C.rs, so_bfv, m);
+#pragma unroll
+                                    for (int j = 0; j < 2; ++j) {
+                                        const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
+                                        const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
+                                        const double bz = j ? bz2.y : bz2.x, bv = j ? bv2.y : bv2.x;
+                                        const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
+                                        if (fwd) {
+                                            turn_acc(azj, avj, cz, cv, s1, s2);
+                                            turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                            turn_acc(azj, avj, bz, bv, s5, s6);
+                                        } else {
+                                            turn_acc(cz, cv, azj, avj, s1, s2);
+                                            turn_acc(cz, cv, lzj, lvj, s3, s4);
+                                            turn_acc(bz, bv, azj, avj, s5, s6);
+                                        }
+                                    }
+                                    NM_GROUP_BARRIER(m);
+                                }
+                            }
+                            { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
+                            if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
+                        }
+                    }
+                NM_MARK(C, 21)
+                if constexpr (BATCH) {
+                    const int ln = (int)(nn & 63);
+                    chunk_end = ln == 63 || nn + 1 == nleaf;
+                    // the pair's z go to the ring HERE, behind the tests' loads (a load waits for every older store on this
+                    // hardware: one counter for both) and as far ahead of the next pair's loads as possible; a pair that ends the
+                    // doubling early never needs them
+                    if (turn_bits == 0) {
+                        C.storeS_nt(E.z, slot_R(MD, (int)(n & 63)));
+                        C.storeS_nt(O.z, slot_R(MD, ln));
+                    }
+                    if (turn_bits != 0 || chunk_end) {
+                        // a turning level k ends the doubling after its merge (src/nuts.rs:163-169): levels 1..k of this leaf are performed
+                        rs_do = true; rs_nl = ln; rs_kl = turn_bits ? (int)__builtin_ctz(turn_bits) : t;
+                    }
+                }
+                }
+                int k_seq = 2;               // first level the sequential loop below merges
+                if constexpr (BATCH) {
+                    k_seq = 7;
+                    if (rs_do) {             // the ONE site of the batched merges
+                        const ChunkResult cr = resolve_chunk(C, wv, mm, rs_nl, rs_kl < mm ? rs_kl : mm);
+                        if (cr.fatal) { fatal = true; stop = STOP_FATAL; }
+                        else if (stop == STOP_NONE) {
+                            sub_log_size = cr.log_size;
+                            const int cl = cr.cand_lane;
+                            sub_cand = CandRef{NM_RING + cl, readlane_f64(lpv, cl), readlane_f64(kev, cl),
+                                               edge_idx + (int64_t)sign * (int64_t)((nn & ~63ull) + (uint64_t)cl + 1)};
+                            if (turn_bits != 0 && rs_kl <= mm) stop = STOP_TURNING;
+                        }
+                    }
+                    if (stop != STOP_NONE) break;
+                } else {
+                    if (stop != STOP_NONE) break;
+                // ---- level-1 merge: A = {E}, B = {O}
+                    double total;
+                    const bool take = merge_weights(C, wE, wO, false, total, fatal);
+                    sub_cand = take ? CandRef{-2, O.logp, O.ke, O.idx} : CandRef{-3, E.logp, E.ke, E.idx};
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if (turn_bits & 2u) { stop = STOP_TURNING; break; }
+                }
+                if (!BATCH || chunk_end)
+                for (int k = k_seq; k <= t; ++k) {
+                    const PendEntry A = C.pend[k - 1];
+                    double total;
+                    const bool take = merge_weights(C, A.log_size, sub_log_size, false, total, fatal);
+                    if (take) {
+                        used &= ~(1u << A.cand_slot);
+                    } else {
+                        if (sub_cand.slot >= 0 && sub_cand.slot < NM_RING) used &= ~(1u << sub_cand.slot);
+                        sub_cand = {A.cand_slot, A.cand_logp, A.cand_ke, A.cand_idx};
+                    }
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if ((turn_bits >> k) & 1u) { stop = STOP_TURNING; break; }
+                }
+                if (stop != STOP_NONE) break;
+                NM_MARK(C, 22)
+                // F: the even leaf (still in E) is the first leaf of the sub-trees of level >= 2 that start at n.  Stored here,
+                // after the merges: every call of the merge arithmetic waits for all stores in flight, and nothing reads F
+                // before the next pair.  (At depth 1 leaf 0 is still in E when the top-level tests need it.)
+#ifndef NM_X_NO_SCRATCH_STORES   // (timing experiment only: results are wrong without the stores)
+                if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {
+                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
+                    C.storeS(E.z, fs);
+                    C.storeS(E.v, fs + 1);
+                }
+#endif
+                if (n + 2 < nleaf) {
+                    // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
+#ifndef NM_X_NO_SCRATCH_STORES
+                    if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
+                    else { C.storeS(O.z, slot_L(MD, t)); C.storeS(O.v, slot_L(MD, t) + 1); }
+                    if (!BATCH || chunk_end) {
+                    if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
+                    else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
+                    else if (sub_cand.slot >= NM_RING) sub_cand.slot = ring_to_pool(C, used, sub_cand.slot - NM_RING);
+                    }
+#else
+                    if (sub_cand.slot < 0) sub_cand.slot = 0;
+#endif
+                    if (!BATCH || chunk_end) {       // (batched: only a whole chunk becomes a pending sub-tree, of level t >= 6)
+                    PendEntry e;
+                    e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
+                    e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
+                    C.pend[t] = e;
+                    }
+                }
+                }
                 NM_MARK(C, 23)
             }
         }
@@ -2072,8 +2413,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             if (mc.slot >= 0) used &= ~(1u << mc.slot);
             if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
             else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
+            else if (sub_cand.slot >= NM_RING) sub_cand.slot = ring_to_pool(C, used, sub_cand.slot - NM_RING);
             mc = sub_cand;
-        } else if (sub_cand.slot >= 0) {
+        } else if (sub_cand.slot >= 0 && sub_cand.slot < NM_RING) {
             used &= ~(1u << sub_cand.slot);
         }
         // Will there be another doubling?  If not (U-turn with no extra doublings, or the depth limit), nothing reads
@@ -2640,7 +2982,9 @@ NM_DEV void lr_resume(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
 // Minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument): the small
 // tilings are latency-bound with few lanes busy, so more resident chains per CU beat a spill-free allocation there.
 #ifndef NM_OCC_DPL2
-#define NM_OCC_DPL2 4    // <= 128 VGPRs: K4 +17 %, K3 +6 % (tools/bench_configs.py); DPL 4 at 3 waves: no gain
+#define NM_OCC_DPL2 2    // <= 256 VGPRs.  (Rounds 1-2: 4 waves / 128 VGPRs, K4 +17 %, K3 +6 %.  Round 3, with the batched merges: at 128 the
+                         // leaf loop spills (205 VGPRs) and one funnel chain needs 2.15 us per leapfrog; at 256 nothing spills: 1.56 us, and
+                         // 8192 chains run at 9.7e8 leapfrogs/s against 6.7e8 — profiles/r03g_*)
 #endif
 #ifndef NM_OCC_DPL4
 #define NM_OCC_DPL4 2    // the DPL 4 kernels sit at 252..262 VGPRs: pin them below 256 (neutral for the elementwise densities,

@@ -111,6 +111,42 @@ def test_host_callback_low_rank_transformation(oracle):
     assert abs((sample[:, 1] - sample[:, 0] ** 2).mean()) < 0.2
 
 
+def test_host_callback_low_rank_adaptation_bit_exact(oracle):
+    """LowRankNutsSettings around a host density, the estimator's linear algebra injected identically on both sides (as in
+    tests/test_gpu_lowrank.py): windows, pauses, re-whitening, the banana's deep trees and its divergences must agree bit for
+    bit with the oracle's callback chain (LrWrap<HostCb>: the combination no other parity test runs)."""
+    from test_gpu_lowrank import estimator_pair
+    dim, n, tune, draws = 6, 5, 120, 170
+    s = N.LowRankNutsSettings(num_chains=n, seed=17, num_tune=tune, store_divergences=True)
+    cb_o, cb_e, rec = estimator_pair(oracle)
+    b = N.ChainBatch(s, N.LogpSpec.host_callback(dim, banana, threads=2), n)
+    x0 = b.init_positions_uniform()
+    status = b.set_position(x0, raise_on_error=False)
+    b.set_lowrank_estimator(cb_e, n_threads=1)
+    pos, st = b.draw_many(draws, raise_on_error=False)
+    tpc = b.threads_per_chain()
+    b.close()
+    n_eng = len(rec)
+
+    def tramp(ctx, d, px, pg, plogp):
+        lp, g = banana(0, np.ctypeslib.as_array(px, shape=(d,)).copy())
+        np.ctypeslib.as_array(pg, shape=(d,))[:] = g
+        plogp[0] = lp
+        return 0
+    cb = oracle.HOST_LOGP_FN(tramp)
+    so = oracle_settings(oracle, s)
+    res = []
+    for c in range(n):
+        ch = oracle.Chain(so, 0, dim, np.zeros(1), oracle.gpu_cfg(tpc), chain_id=c, callback=cb)
+        oracle.lib().nmo_chain_set_estimator(ch._h, cb_o, None)
+        rc = ch.set_position(x0[c])
+        rows = [ch.draw() for _ in range(draws)] if rc == 0 else []
+        res.append((rc, rows))
+    compare(status, pos, st, res)
+    assert len(rec) == 2 * n_eng and n_eng >= 3 * n and st["depth"].max() >= 5
+    assert (st["transformation_update_id"] >= 0).sum() >= 3 * n
+
+
 def test_recoverable_errors_become_divergences(oracle):
     def walled(chain, x):
         if x[0] > 1.5:                       # outside the support: a recoverable error, like a failed ODE solve

@@ -77,6 +77,19 @@ def main():
            "f64_dense_TFLOPs": steps * flop_per_leapfrog / kern_s / 1e12,
            "matrix_bytes_per_leapfrog": 8.0 * (2 * D * r + D * D), "matrix_read_TBps": steps * 8.0 * (2 * D * r + D * D) / kern_s / 1e12,
            "whitened_draws": {"mean": float(z.mean()), "var": float(z.var())}}
+    if os.environ.get("NM_TILE_PROF"):     # a -DNM_TILE_PROF=1 build: cycles per wavefront in chain code / barrier waits / matrix-core products
+        import ctypes as Ct
+        from nuts_rs_amd import _lib
+        L = _lib.load()
+        L.nm_debug_read_prof.argtypes = [Ct.c_void_p, Ct.c_void_p]
+        buf = np.zeros(32, dtype=np.uint64)
+        L.nm_debug_read_prof(b._h, buf.ctypes.data)
+        chain_, wait_, mma_, rounds_, idle_ = (float(buf[i]) for i in (16, 17, 18, 19, 20))
+        tot = chain_ + wait_ + mma_ + idle_
+        out["tile_prof"] = {"note": "both launches (tune + timed); s_memtime cycles summed over all wavefronts",
+                            "chain_code_frac": chain_ / tot, "barrier_wait_frac": wait_ / tot, "matrix_product_frac": mma_ / tot,
+                            "idle_column_between_rounds_frac": idle_ / tot, "rendezvous_of_wave0": rounds_,
+                            "cycles_per_wave_round": tot / max(rounds_, 1.0) / 16.0}
     print(json.dumps(out))
     b.close()
 

@@ -27,12 +27,13 @@ def main():
     ap.add_argument("--step", type=float, default=0.002)
     ap.add_argument("--chains", default="1,256,1024,8192")
     ap.add_argument("--lane-groups", type=int, default=0)
+    ap.add_argument("--no-turn", action="store_true", help="check_turning = false: the tree without its U-turn tests")
     a = ap.parse_args()
     out = []
     for nc in [int(x) for x in a.chains.split(",")]:
         logp = {"funnel": lambda: N.LogpSpec.funnel(a.dim), "iid": lambda: N.LogpSpec.iid_normal(a.dim, 3.0),
                 "schools": N.LogpSpec.eight_schools}[a.logp]()
-        s = N.DiagNutsSettings(num_chains=nc, seed=11, num_tune=1, num_draws=a.draws, maxdepth=a.maxdepth)
+        s = N.DiagNutsSettings(num_chains=nc, seed=11, num_tune=1, num_draws=a.draws, maxdepth=a.maxdepth, check_turning=not a.no_turn)
         st = s.adapt_options.step_size_settings
         st.method, st.fixed_step_size, st.jitter = N.sampler.STEP_FIXED, a.step, None
         b = N.ChainBatch(s, logp, nc, lane_groups=a.lane_groups)
@@ -42,7 +43,7 @@ def main():
         b.draw_device(a.draws)
         c = b.counters()
         per_chain = c["total_leapfrogs"] / nc
-        row = {"logp": a.logp, "dim": logp.dim, "chains": nc, "maxdepth": a.maxdepth, "draws": a.draws, "leapfrogs_per_chain": per_chain,
+        row = {"lib": os.path.basename(os.environ.get("NUTS_AMD_LIB", "libnuts_amd.so")), "no_turn": a.no_turn, "logp": a.logp, "dim": logp.dim, "chains": nc, "maxdepth": a.maxdepth, "draws": a.draws, "leapfrogs_per_chain": per_chain,
                "kernel_ms": c["kernel_ms"], "us_per_leapfrog_of_one_chain": c["kernel_ms"] * 1e3 / per_chain,
                "leapfrogs_per_s": c["total_leapfrogs"] / (c["kernel_ms"] * 1e-3), "threads_per_chain": b.threads_per_chain(),
                "dims_per_lane": b.dims_per_lane(), "group_launches": b.group_launches()}
