@@ -63,6 +63,9 @@ def parse():
     p.add_argument("--dims-per-lane", type=int, default=0)
     p.add_argument("--no-record", action="store_true", help="do not record draws / statistics in the timed launches (comparison only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--dist-always", action="store_true",
+                   help="initialise torch.distributed even for one rank (the barrier and the timing reductions then run through the backend's "
+                        "single-rank paths: lets a one-GPU box execute the RCCL code an 8-GPU node will)")
     p.add_argument("--cpu-chains", type=int, default=0, help="chains of the bounded CPU sample (0 = 8 per usable host core)")
     p.add_argument("--pmc", default="live", choices=["live", "profile", "off"],
                    help="HBM traffic of the timed launch: live rocprofv3 --pmc passes | latest committed profile, scaled | none")
@@ -265,10 +268,12 @@ def main():
     torch.cuda.set_device(device_index)
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_always:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:

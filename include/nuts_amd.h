@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 12
+#define NM_ABI_VERSION 13
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -570,6 +570,19 @@ nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]
 #define NM_PROBE_COPY_NT 4   /* copy with non-temporal stores (the cache policy of the engine's candidate / per-draw stores) */
 nm_status nm_probe_bandwidth(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
                              uint64_t* bytes_read_per_iter, uint64_t* bytes_written_per_iter);
+
+/* ---------------------------------------------------------------------------------------------
+ * The per-rank half of the OPT-IN pooled adaptation (north_star's "RCCL cross-chain Welford reduction"; NOT reference
+ * behaviour — every reference chain adapts alone, src/adapt_strategy.rs:24-39 — and never the default; nuts_rs_amd/pooled.py
+ * drives it).  Reduces one window of recorded draws and gradients (device buffers [n_rows][dim] as nm_engine_draw_ex leaves
+ * them, n_rows = window draws x local chains) to d_out[2][1 + 2 dim] = {count, mean[dim], M2[dim]} for the draws and for the
+ * gradients, on `stream`, asynchronously.  With d_stats (the window's nm_draw_stats rows, same row order) a row counts only if
+ * its chain is healthy and the draw is one the reference's DrawGradCollector keeps (is_good, src/transform/adapt/diagonal.rs:
+ * 57-84).  The ranks exchange d_out with one all_gather (RCCL) and merge the partials in rank order (Chan).  Deterministic.
+ * ------------------------------------------------------------------------------------------- */
+nm_status nm_pooled_partials(uint64_t n_rows, uint64_t dim, const double* d_positions, const double* d_gradients,
+                             const nm_draw_stats* d_stats, double* d_out, void* stream);
+const char* nm_pooled_last_error(void);
 
 const char* nm_last_error(void);
 uint64_t    nm_abi_version(void);

@@ -73,7 +73,10 @@ __host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(m
 #ifndef NM_BATCH_MERGES
 #define NM_BATCH_MERGES 1        // 0: every merge evaluated where the reference evaluates it (tuning / bisecting builds)
 #endif
-template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && !NM_TILE_MODE && !NM_CLUSTER_MODE; }
+#ifndef NM_BATCH_IN_TILES
+#define NM_BATCH_IN_TILES 0
+#endif
+template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && (!NM_TILE_MODE || NM_BATCH_IN_TILES) && !NM_CLUSTER_MODE; }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
 struct ChainScalars {

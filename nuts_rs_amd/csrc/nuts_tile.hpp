@@ -93,72 +93,27 @@ NM_DEV void get_col(const double* buf, int c, Tile<DPL>& t) {
     for (int k = 0; k < DPL; ++k) t.a[k] = buf[taddr(elem_index<1>(k), c)];
 }
 
-// one 16-row stripe: acc += M[stripe rows][:] B, inner index ascending (an fma chain per output entry).
-// Round 3: the loop is software-pipelined by hand.  Round 2's form (generic pointers, `#pragma unroll 4` that the compiler
-// declined) compiled to one flat load of the A operand + two FLAT loads of the LDS tile + `s_waitcnt vmcnt(0) lgkmcnt(0)` in
-// front of every pair of MFMAs: each k-pair paid a whole L2 round trip, the matrix pipe was busy 41 % of the time and the products
-// took 63 % of a wavefront's cycles (tools/bench_k5.py with a -DNM_TILE_PROF=1 build, profiles/r03h_k5_tile_phases.json).  Now the
-// A operands come through a buffer descriptor (SGPR base + immediate offsets: no 64-bit address arithmetic) in groups of four
-// k-pairs, the NEXT group's four loads are in flight while the current group's eight MFMAs run, and the B operands are read
-// with ds_read from eight per-lane LDS addresses computed once per stripe (the swizzle of a row depends on the k-pair only mod 4).
-// The order of the fma chain is unchanged (k ascending, one accumulator): the same bits.
-typedef const __attribute__((address_space(3))) double* lds_f64_t;
-typedef double v2d __attribute__((ext_vector_type(2)));
-// (the operands stay in the loads' own <4 x i32> registers until an MFMA consumes them: converting at load time costs moves that
-// wait for the load, i.e. no prefetch at all)
-NM_DEV v4d gemm_group(const v4u (&a)[4], lds_f64_t bp, const int (&i0)[4], const int (&i1)[4], int u, v4d acc) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const double b0 = bp[i0[v] + 32 * TC * u], b1 = bp[i1[v] + 32 * TC * u];
-        const v2d av = __builtin_bit_cast(v2d, a[v]);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b1, acc, 0, 0, 0);
-    }
-    return acc;
-}
-NM_DEV void gemm_load_group(v4u (&a)[4], rsrc_t ra, int voff, int so) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff + v * 1024, so, 0);
-}
-NM_DEV v4d gemm_stripe(const double* packed, int n_stripes, int s, int kpairs, const double* b, v4d acc) {
+// one 16-row stripe: acc += M[stripe rows][:] B, inner index ascending (an fma chain per output entry)
+NM_DEV v4d gemm_stripe(const double* packed, int s, int kpairs, const double* b, v4d acc) {
     const int l = lane_id(), kk = l >> 4, c = l & 15;
-    const int kp = force_sgpr(kpairs), groups = kp >> 2;         // (wave-uniform: the branches below are scalar)
-    // the descriptor ends with the packed matrix: the loop's prefetch runs up to two groups past the stripe — into the next stripe, or
-    // past the end, where a buffer load returns zeros instead of faulting
-    const rsrc_t ra = make_rsrc(packed, (uint64_t)n_stripes * (uint64_t)kp * 1024u);
-    int so = force_sgpr(s * kp * 1024);
-    const int voff = l * 16;
-    lds_f64_t bp = (lds_f64_t)b;
-    int i0[4], i1[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { i0[v] = taddr(8 * v + kk, c); i1[v] = taddr(8 * v + kk + 4, c); }
-    v4u a0[4], a1[4];
-    gemm_load_group(a0, ra, voff, so);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int u = 0; u < groups; u += 2) {
-        // the loads are unconditional on purpose: behind a branch the compiler must wait for ALL outstanding loads at the join
-        // (vmcnt(0)), i.e. for the group it has just requested
-        // (and pinned with scheduling barriers: left alone, the machine scheduler sinks each group of loads to just in front of its
-        // first use to save registers, which is the opposite of a prefetch)
-        gemm_load_group(a1, ra, voff, so + 4096);                       // group u + 1 in flight under group u's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        acc = gemm_group(a0, bp, i0, i1, u, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm_load_group(a0, ra, voff, so + 8192);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 1 < groups) acc = gemm_group(a1, bp, i0, i1, u + 1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        so += 8192;
-    }
-    for (int q = groups * 4; q < kp; ++q) {                              // the last k-pairs of an inner length that is not a multiple of 32
-        const v2d a = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, force_sgpr((s * kp + q) * 1024), 0));
+    const double2* ap = reinterpret_cast<const double2*>(packed) + (size_t)s * (size_t)kpairs * 64 + l;
+#pragma unroll 4
+    for (int q = 0; q < kpairs; ++q) {
+        const double2 a = ap[(size_t)q * 64];
         const int r0 = 8 * q + kk;
-        const double b0 = bp[taddr(r0, c)], b1 = bp[taddr(r0 + 4, c)];
+        const double b0 = b[taddr(r0, c)], b1 = b[taddr(r0 + 4, c)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc, 0, 0, 0);
     }
     return acc;
 }
+// Round 3 measured a hand-pipelined form of this loop (A operands through a buffer descriptor in groups of four k-pairs, the next
+// group's loads pinned in front of the current group's MFMAs with scheduling barriers, B operands by ds_read from eight
+// precomputed per-lane addresses; the loop above compiles to flat loads and a full `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of
+// every pair of MFMAs).  The products' share of a wavefront's cycles fell from 63 % to 55 % (NM_TILE_PROF), but the 32 extra
+// registers of the operand ring cost the chain code between the rounds as much: shared low-rank K5 3.80e7 -> 3.85e7 leapfrogs/s,
+// DiagNutsSettings K5 1.25e8 -> 1.10e8.  With four wavefronts per SIMD taking turns on the matrix pipe the load latency of one
+// is already covered by the others; rejected (profiles/r03h_k5_tile_phases.json, r03j_*).
 // C/D layout of the f64 MFMA: lane (g = l >> 4, c = l & 15) holds rows 16 s + g + 4 r, r = 0..3, of column c
 NM_DEV void store_stripe(double* buf, int s, v4d acc) {
     const int l = lane_id(), g = l >> 4, c = l & 15;
@@ -224,7 +179,7 @@ NM_DEV bool apply_round(TileRef& X, int which, Tile<DPL>* v, bool may_exit) {
     }
     for (int s = w; s < X.M.rank_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gemm_stripe(X.M.ut, X.M.rank_st, s, X.M.dim_kp, T.zin, acc);
+        acc = gemm_stripe(X.M.ut, s, X.M.dim_kp, T.zin, acc);
         store_stripe_scaled(T.sbuf, s, acc, T);
     }
     NM_TP_ADD(X, acc_mma)
@@ -232,7 +187,7 @@ NM_DEV bool apply_round(TileRef& X, int which, Tile<DPL>* v, bool may_exit) {
     NM_TP_ADD(X, acc_wait)
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = load_stripe(T.zin, s);
-        acc = gemm_stripe(X.M.u, X.M.dim_st, s, X.M.rank_kp, T.sbuf, acc);
+        acc = gemm_stripe(X.M.u, s, X.M.rank_kp, T.sbuf, acc);
         store_stripe(T.zin, s, acc);
     }
     NM_TP_ADD(X, acc_mma)
@@ -252,7 +207,7 @@ NM_DEV void density_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y) {
     NM_TP_ADD(X, acc_wait)
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gemm_stripe(X.M.p, X.M.dim_st, s, X.M.dim_kp, T.zin, acc);
+        acc = gemm_stripe(X.M.p, s, X.M.dim_kp, T.zin, acc);
         store_stripe(T.sbuf, s, acc);
     }
     NM_TP_ADD(X, acc_mma)
@@ -276,7 +231,7 @@ NM_DEV bool density_only_round(TileRef& X, const Tile<DPL>* x, Tile<DPL>* y, boo
     }
     for (int s = w; s < X.M.dim_st; s += TC) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = gemm_stripe(X.M.p, X.M.dim_st, s, X.M.dim_kp, T.zin, acc);
+        acc = gemm_stripe(X.M.p, s, X.M.dim_kp, T.zin, acc);
         store_stripe(T.sbuf, s, acc);
     }
     NM_TP_ADD(X, acc_mma)

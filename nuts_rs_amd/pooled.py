@@ -8,7 +8,8 @@ behaviour â€” every reference chain adapts alone (src/adapt_strategy.rs:24-39) â
 separate driver, `pooled_warmup`, never the default.  All chains of all ranks share ONE diagonal transformation:
 the engine runs with the transformation frozen (its own mass-matrix adaptation off, step size adapting per chain as
 usual), records draws and gradients of a window in device buffers, each rank reduces its chains' window to
-(count, mean[D], M2[D]) for draws and for gradients on the device, the ranks exchange those 2 (2 D + 1) doubles with
+(count, mean[D], M2[D]) for draws and for gradients with the engine's reduction kernel (nm_pooled_partials: only healthy
+chains' `is_good` draws count, like the reference's collector), the ranks exchange those 2 (2 D + 1) doubles with
 ONE all_gather per window (torch.distributed: RCCL over xGMI with the nccl backend, issued on a side stream so the next
 window's kernel is already running; gloo in the tests), merge them in rank order with Chan's formula, and every rank
 sets sigma = (var_x / var_g)^(1/4), mean = x_bar + sigma^2 g_bar (the reference's diagonal estimate,
@@ -64,13 +65,17 @@ def pooled_welford(local, dist=None):
     return out
 
 
-def _partial_device(x):
-    """(count, mean[D], M2[D]) over the rows of a device tensor [n, D] (one pass, in f64, on the tensor's device)."""
+def _partials_device(pos, grad, stats, stream):
+    """[2][1 + 2 D] = (count, mean[D], M2[D]) of the window's draws and gradients, by the engine's own reduction kernel
+    (nm_pooled_partials, csrc/pooled_reduce.hip) on `stream`: rows of stopped chains and draws the reference's collector
+    would not keep (not `is_good`) are left out."""
     import torch
-    n = x.shape[0]
-    mean = x.mean(dim=0)
-    m2 = ((x - mean) ** 2).sum(dim=0)
-    return torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=x.device), mean, m2])
+    from . import _lib
+    w, nc, dim = pos.shape
+    out = torch.empty((2, 1 + 2 * dim), dtype=torch.float64, device=pos.device)
+    _lib.check_status(_lib.load().nm_pooled_partials(w * nc, dim, pos.data_ptr(), grad.data_ptr(), stats.data_ptr(), out.data_ptr(),
+                                                     stream.cuda_stream), _lib.load().nm_pooled_last_error)
+    return out
 
 
 def _merge_payloads(payloads, d):
@@ -129,15 +134,21 @@ def pooled_warmup(batch, num_tune, dist=None, windows=None, collective_device=No
         if on_window:
             on_window(at, s_h, m_h)
 
+    from .sampler import STATS_DTYPE
     for w in windows:
         pos = torch.empty((w, nc, dim), dtype=torch.float64, device=dev)
         grad = torch.empty((w, nc, dim), dtype=torch.float64, device=dev)
-        batch.draw_device_ex(w, positions=pos.data_ptr(), gradient=grad.data_ptr())     # the window's kernel
-        if pending is not None:                # the previous window's exchange ran beside this kernel; apply it now
-            finish(pending)
+        # zero-filled statistics: a chain that has stopped writes no rows, and an all-zero row is not a draw the collector keeps
+        stats = torch.zeros((w, nc, STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream(dev).synchronize()       # (the fill runs on torch's stream, the engine on its own)
+        batch.draw_device_ex(w, positions=pos.data_ptr(), stats=stats.data_ptr(), gradient=grad.data_ptr())     # the window's kernel
+        if pending is not None:                # the previous window's exchange ran beside this kernel; apply it now:
+            finish(pending)                    # the pooled transformation lags the draws by ONE window (documented, deliberate)
         done += w
         with torch.cuda.stream(side):          # this window's partials + the collective, off the engine's stream
-            payload = torch.cat([_partial_device(pos.reshape(-1, dim)), _partial_device(grad.reshape(-1, dim))]).to(cdev)
+            for t in (pos, grad, stats):
+                t.record_stream(side)
+            payload = _partials_device(pos, grad, stats, side).reshape(-1).to(cdev)
             gathered = [torch.empty_like(payload) for _ in range(world)]
             if world > 1:
                 work = dist.all_gather(gathered, payload, async_op=True)

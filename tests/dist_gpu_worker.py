@@ -19,22 +19,29 @@ def main():
     import nuts_rs_amd as N
     from nuts_rs_amd import pooled
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    backend = os.environ.get("NM_TEST_BACKEND", "gloo")
+    if backend == "nccl":            # RCCL: one rank per GPU (LOCAL_RANK), the collective's payload stays on the device
+        dev_index = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    else:
+        dev_index = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
     dim, C_, tune, draws, seed = 24, 20, 60, 30, 77
     off, n_local = pooled.shard_chains(world * C_, world, rank)
     prec = np.exp(np.linspace(-2, 2, dim))
     if mode == "shard":
         s = N.DiagNutsSettings(num_chains=world * C_, seed=seed, num_tune=tune)
-        b = N.ChainBatch(s, N.LogpSpec.diag_normal(prec), n_local, chain_id_offset=off, device=0)
+        b = N.ChainBatch(s, N.LogpSpec.diag_normal(prec), n_local, chain_id_offset=off, device=dev_index)
         b.set_position(b.init_positions_uniform())
         pos, st = b.draw_many(tune + draws)
         np.savez(os.path.join(outdir, f"shard_{rank}.npz"), pos=pos, n_steps=st["n_steps"], chain=st["chain"], step=st["step_size"])
     else:
         s = N.LowRankNutsSettings(num_chains=world * C_, seed=seed, num_tune=tune, freeze_transform=True)
-        b = N.ChainBatch(s, N.LogpSpec.diag_normal(prec), n_local, chain_id_offset=off, device=0)
+        b = N.ChainBatch(s, N.LogpSpec.diag_normal(prec), n_local, chain_id_offset=off, device=dev_index)
         b.set_position(b.init_positions_uniform())
-        ups = pooled.pooled_warmup(b, tune, dist, windows=[10, 10, 20], collective_device="cpu")
+        ups = pooled.pooled_warmup(b, tune, dist, windows=[10, 10, 20], collective_device=None if backend == "nccl" else "cpu")
         pos, st = b.draw_many(draws)
         np.savez(os.path.join(outdir, f"pooled_{rank}.npz"), pos=pos, n_steps=st["n_steps"], sigma=np.stack([u[1] for u in ups]),
                  mean=np.stack([u[2] for u in ups]))

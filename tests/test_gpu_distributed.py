@@ -27,10 +27,10 @@ def free_port():
     return p
 
 
-def launch(mode, outdir, nproc=2):
+def launch(mode, outdir, nproc=2, backend="gloo"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), mode, str(outdir)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NM_TEST_BACKEND=backend)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
 
@@ -77,3 +77,56 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--pmc", "off"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode != 0 and b"GPU(s) visible" in r.stderr
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_rccl_pooled_adaptation_and_bench():
+    """The N > 1 path over RCCL itself (torch.distributed backend "nccl"), not gloo: the pooled adaptation's all_gather with its
+    payload on the device, and bench.py's barrier / reductions.  With two or more GPUs visible: two ranks, one per GPU; on a
+    one-GPU box: the same code with world size 1 (RCCL initialises, the collectives are its single-rank paths) — so that an
+    8-GPU node needs no code the suite has not executed."""
+    import tempfile
+    n = 2 if _visible_gpus() >= 2 else 1
+    with tempfile.TemporaryDirectory() as d:
+        launch("pooled", d, nproc=n, backend="nccl")
+        runs = [np.load(os.path.join(d, f"pooled_{r}.npz")) for r in range(n)]
+    true_sd = np.exp(np.linspace(-2, 2, 24)) ** -0.5
+    for r in runs[1:]:
+        assert (r["sigma"] == runs[0]["sigma"]).all() and (r["mean"] == runs[0]["mean"]).all()
+    assert np.abs(np.log(runs[0]["sigma"][-1] / true_sd)).max() < (0.25 if n == 2 else 0.4)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "nccl", "--steps", "6", "--warmup", "2",
+                        "--repeats", "2", "--chains", "64", "--dim", "128", "--num-tune", "30", "--pmc", "off", "--no-cpu-baseline",
+                        "--dist-always", "--master-port", str(free_port())],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == n and d["value"] > 0
+
+
+def test_pooled_partials_kernel_matches_numpy():
+    """nm_pooled_partials (csrc/pooled_reduce.hip): count / mean / M2 of the rows the reference's collector keeps."""
+    import ctypes as C
+    import torch
+    from nuts_rs_amd import _lib, pooled
+    rng = np.random.default_rng(5)
+    w, nc, dim = 7, 300, 37
+    x, g = rng.normal(size=(w, nc, dim)), rng.normal(size=(w, nc, dim)) * 3 + 1
+    st = np.zeros((w, nc), dtype=N.STATS_DTYPE)
+    st["index_in_trajectory"] = rng.integers(-6, 7, size=(w, nc))
+    st["diverging"] = rng.random((w, nc)) < 0.2
+    st["chain_status"][:, ::17] = 6                                   # stopped chains
+    good = (st["chain_status"] == 0) & np.where(st["diverging"] != 0, np.abs(st["index_in_trajectory"]) > 4, st["index_in_trajectory"] != 0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).cuda()
+    tx, tg, ts = dev(x), dev(g), dev(st)
+    torch.cuda.synchronize()
+    out = pooled._partials_device(tx.view(torch.float64).reshape(w, nc, dim), tg.view(torch.float64).reshape(w, nc, dim), ts,
+                                  torch.cuda.current_stream()).cpu().numpy()
+    for k, a in enumerate((x, g)):
+        rows = a[good]
+        n_, mean_, m2_ = pooled.welford_partial(rows)
+        assert out[k, 0] == n_ == good.sum()
+        assert np.allclose(out[k, 1:1 + dim], mean_, rtol=1e-13, atol=1e-13) and np.allclose(out[k, 1 + dim:], m2_, rtol=1e-12)
