@@ -319,6 +319,9 @@ typedef struct nm_engine_config {
                                     * 0 = auto ((a) from 256 chains on, (b) whenever it applies), 1 = never, 2 = whenever it applies */
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
+    uint64_t lane_chains;          /* chains with dim <= 16: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
+                                    * Euclidean NUTS, maxdepth <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
+                                    * 0 = auto (from 16384 chains on), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 
@@ -458,6 +461,8 @@ uint64_t  nm_engine_dims_per_lane(const nm_engine* e);
 uint64_t  nm_engine_blocks_per_chain(const nm_engine* e);
 /* draw launches served by the several-chains-per-wavefront kernels so far (nm_engine_config.lane_groups) */
 uint64_t  nm_engine_group_launches(const nm_engine* e);
+/* draw launches served by the one-chain-per-lane kernels (nm_engine_config.lane_chains) */
+uint64_t  nm_engine_lane_launches(const nm_engine* e);
 /* The HIP stream the engine launches on (a hipStream_t), so callers can order their own work. */
 void*     nm_engine_stream(nm_engine* e);
 

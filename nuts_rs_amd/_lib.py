@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nm_engine_synchronize", "nm_engine_draw_to_host", "nm_host_register", "nm_host_unregister", "nm_engine_draw_ex", "nm_engine_draw_ex_async",
     "nm_engine_draw_ex_to_host", "nm_engine_get_positions", "nm_engine_get_gradients",
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
-    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_blocks_per_chain", "nm_engine_group_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
+    "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_blocks_per_chain", "nm_engine_group_launches", "nm_engine_lane_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
@@ -73,7 +73,7 @@ HOST_LOGP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTE
 class NmEngineConfig(C.Structure):
     _fields_ = [("device", C.c_int64), ("chain_id_offset", C.c_uint64), ("dims_per_lane", C.c_uint64),
                 ("waves_per_chain", C.c_uint64), ("grid_blocks", C.c_uint64), ("lane_groups", C.c_uint64),
-                ("chain_tiles", C.c_uint64), ("lowrank_max_rank", C.c_uint64)]
+                ("chain_tiles", C.c_uint64), ("lowrank_max_rank", C.c_uint64), ("lane_chains", C.c_uint64)]
 
 
 STATS_DTYPE = np.dtype([
@@ -160,6 +160,8 @@ def load():
     L.nm_engine_dims_per_lane.restype = u64
     L.nm_engine_group_launches.argtypes = [vp]
     L.nm_engine_group_launches.restype = u64
+    L.nm_engine_lane_launches.argtypes = [vp]
+    L.nm_engine_lane_launches.restype = u64
     L.nm_engine_stream.argtypes = [vp]
     L.nm_engine_stream.restype = vp
     L.nm_leapfrog_batch.argtypes = [C.POINTER(NmLogpSpec), u64, u64] + [vp] * 16 + [vp]

@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libnuts_amd.so")
 UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
          "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_host_cb.hip",
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
-         "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
+         "kern_lane.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
          "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip", "pooled_reduce.hip",
          "lowrank_host.cpp", "lowrank_host.cpp@avx2", "lowrank_dispatch.cpp"]
 # "<file>@<variant>": the same source compiled a second time (lowrank_host.cpp: plain x86-64 and -mavx2 -mfma; a run-time dispatcher picks)

@@ -1,0 +1,38 @@
+// kern_lane.hip — the one-chain-per-lane draw kernels (nuts_lane.hpp) for the built-in densities with dim <= 16.
+#include <hip/hip_runtime.h>
+#include "nuts_lane.hpp"
+namespace nm {
+namespace {
+template <class Dens, int NP>
+hipError_t launch_lane_t(int query, bool tune, const KParams& P, const lane::LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
+    if constexpr (std::is_void<typename lane::LaneDensity<Dens, NP>::type>::value) {
+        return hipErrorInvalidValue;
+    } else {
+        if (query) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, lane::nuts_lane_draw_kernel<Dens, NP, true>, 64, 0);
+        if (tune) hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
+        else hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
+        return hipGetLastError();
+    }
+}
+template <class Dens>
+hipError_t launch_lane_d(int query, bool tune, const KParams& P, const lane::LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
+    switch (lane::lane_pairs(P.dim)) {
+    case 2: return launch_lane_t<Dens, 2>(query, tune, P, LP, grid, stream, occ);
+    case 4: return launch_lane_t<Dens, 4>(query, tune, P, LP, grid, stream, occ);
+    case 5: return launch_lane_t<Dens, 5>(query, tune, P, LP, grid, stream, occ);
+    case 8: return launch_lane_t<Dens, 8>(query, tune, P, LP, grid, stream, occ);
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace
+// query = 1: *occ = resident blocks (wavefronts) per CU
+hipError_t launch_lane(uint64_t logp_kind, int query, bool tune, const KParams& P, const lane::LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
+    switch (logp_kind) {
+    case NM_LOGP_IID_NORMAL: return launch_lane_d<IidNormal>(query, tune, P, LP, grid, stream, occ);
+    case NM_LOGP_DIAG_NORMAL: return launch_lane_d<DiagNormal>(query, tune, P, LP, grid, stream, occ);
+    case NM_LOGP_FUNNEL: return launch_lane_d<Funnel>(query, tune, P, LP, grid, stream, occ);
+    case NM_LOGP_EIGHT_SCHOOLS: return P.dim == 10 ? launch_lane_t<EightSchools, 5>(query, tune, P, LP, grid, stream, occ) : hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace nm

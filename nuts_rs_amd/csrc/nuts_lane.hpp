@@ -1,0 +1,1105 @@
+// nuts_lane.hpp — ONE CHAIN PER LANE: the draw kernels for very small chains (dim <= 16), 64 chains per wavefront.
+//
+// north_star's own mapping ("one chain per wavefront lane"), where it pays: at dim 10 (BASELINE configs 1 and 4) the
+// wave-per-chain kernel executes one chain's scalar work 64 lanes wide, and the 8-lanes-per-chain kernels of nuts_group.hpp still
+// carry eight copies of it per chain (131 vector instructions per chain-leapfrog, 236-256 registers of per-lane duplicates).
+// Here a lane owns a whole chain: its vectors are 2 NP doubles in registers (NP = pairs of elements, dim <= 2 NP <= 16), the tree's
+// "scalars" are the lane's own registers, nothing is duplicated and no cross-lane operation exists.  The code below is the
+// reference's transition written once, per lane (a port of nuts_group_impl.hpp, itself a port of nuts_transition); lanes diverge
+// where their trees do, and the wavefront's doubling / leaf loops run until its last lane is done.
+//
+// Same results, bit for bit, as the other kernels (and so as the oracle):
+//   * sums over dim: the wave kernel's order for a chain of <= 16 elements is "pair partials (elements 2l, 2l + 1, from +0.0),
+//     then the xor-butterfly 1, 2, 4 over the 8 lanes that hold them" = a balanced tree over 8 pair partials; pairs beyond the
+//     dim are +0.0 and adding +0.0 to a partial sum (never -0.0: it starts at +0.0) changes nothing, so they are skipped (pair_tree);
+//   * the same exp / ln / ln_1p (the per-lane entry points), the same ChaCha8 stream (every lane generates ITS chain's blocks),
+//     the sequential ziggurat of rand_distr, the same tree, merges, adaptation;
+//   * the chain's state lives in the same pvec slots / ChainScalars records between launches (gathered into a lane-major
+//     workspace when the kernel starts and scattered back when it ends), so launches of this kernel and of the others can
+//     alternate on one engine.
+// Memory: the tree's scratch and the chain's persistent vectors are LANE-MAJOR ([slot][element][lane]): every access of a
+// wavefront is 64 consecutive doubles.  The pending-sub-tree table and the ChaCha word cache are in LDS ([..][lane]: bank =
+// lane, conflict-free).
+#pragma once
+#include <type_traits>
+#include "nuts_kernels.hpp"
+
+namespace nm {
+namespace lane {
+
+constexpr int LMAXDEPTH = 10;
+__host__ __device__ inline int lane_pairs(uint64_t dim) { return dim <= 4 ? 2 : dim <= 8 ? 4 : dim <= 10 ? 5 : dim <= 16 ? 8 : 0; }
+
+struct LaneParams {
+    double* lws;          // [grid][NUM_PSLOT][2 NP][64]  the chains' persistent vectors while the kernel runs
+    double* lsv;          // [grid][nslots][2 NP][64]     tree scratch
+    uint64_t nslots;
+};
+
+// ---- the engine's sum over a chain of <= 16 elements: balanced tree over the pair partials (see the header) ----
+template <int NP>
+NM_DEV double pair_tree(const double (&p)[NP]) {
+    constexpr int NQ = (NP + 1) / 2;
+    double q[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) q[i] = (2 * i + 1 < NP) ? p[2 * i] + p[2 * i + 1] : p[2 * i];
+    constexpr int NR = (NQ + 1) / 2;
+    double r[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r[i] = (2 * i + 1 < NQ) ? q[2 * i] + q[2 * i + 1] : q[2 * i];
+    if constexpr (NR == 2) return r[0] + r[1];
+    else return r[0];
+}
+
+// per-lane special functions (same operations, same bits as nm::dexp & co.)
+NM_DEV double lexp(double x) { return dexp_impl<false>(x); }
+NM_DEV double llog(double x) { return dlog_impl<false>(x); }
+NM_DEV double llog1p(double x) { return dlog1p_impl<false>(x); }
+NM_DEV double llogaddexp(double a, double b) {           // reference src/math/util.rs:6-19
+    if (a == b) return a + llog(2.0);
+    const double diff = a - b;
+    if (diff > 0.) return a + llog1p(lexp(-diff));
+    if (diff < 0.) return b + llog1p(lexp(diff));
+    return diff;
+}
+
+// ---- densities: lane forms of the built-in ones (same operations in the same order as the group / wave forms) ----
+template <int NP>
+struct LIidNormal {
+    static constexpr int E = 2 * NP;
+    double mu;
+    NM_DEV void init(const double* params, int) { mu = params[0]; }
+    NM_DEV double eval(const double (&x)[E], double (&gx)[E], int dim) const {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                const bool valid = d < dim;
+                const double diff = x[d] - mu;
+                const double term = -0.5 * diff * diff;
+                gx[d] = valid ? -diff : 0.0;
+                acc = acc + (valid ? term : 0.0);
+            }
+            p[l] = acc;
+        }
+        return pair_tree<NP>(p);
+    }
+};
+template <int NP>
+struct LDiagNormal {
+    static constexpr int E = 2 * NP;
+    const double* prec;
+    double norm;
+    NM_DEV void init(const double* params, int dim) {
+        prec = params;
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * l + j;
+                acc = acc + (d < dim ? llog(params[d < dim ? d : 0]) : 0.0);
+            }
+            p[l] = acc;
+        }
+        const double log_det_p = pair_tree<NP>(p);
+        norm = -0.5 * ((double)dim * llog(6.283185307179586) - log_det_p);
+    }
+    NM_DEV double eval(const double (&x)[E], double (&gx)[E], int dim) const {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                const bool valid = d < dim;
+                const double pr = valid ? prec[d] : 0.0;
+                const double px = pr * x[d];
+                gx[d] = valid ? -px : 0.0;
+                acc = acc + (valid ? x[d] * px : 0.0);
+            }
+            p[l] = acc;
+        }
+        const double quad = -0.5 * pair_tree<NP>(p);
+        return quad + norm;
+    }
+};
+template <int NP>
+struct LEightSchools {          // dim 10 (NP = 5): mu, log tau, theta~_1..8
+    static constexpr int E = 2 * NP;
+    const double* par;
+    NM_DEV void init(const double* params, int) { par = params; }
+    NM_DEV double eval(const double (&x)[E], double (&gx)[E], int) const {
+        const double mu = x[0], lt = x[1];
+        const double tau = lexp(lt);
+        const double t5 = (tau / 5.0) * (tau / 5.0);
+        const double prior_tau = lt - llog1p(t5);
+        double term[E], dr[E], drth[E];
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const bool school = d >= 2 && d < 10;
+            const int i = school ? d - 2 : 0;
+            const double th = x[d];
+            const double sg = par[8 + i];
+            const double r = (par[i] - (mu + tau * th)) / sg;
+            term[d] = -0.5 * th * th - 0.5 * r * r;
+            dr[d] = r / sg;
+            drth[d] = dr[d] * th;
+            if (!school) { term[d] = 0.0; dr[d] = 0.0; drth[d] = 0.0; }
+        }
+        double gmu = 0.0, gtl = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (2 + i < E) { gmu = gmu + dr[2 + i]; gtl = gtl + drth[2 + i]; }
+        }
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                double t = 0.0, g = 0.0;
+                if (d == 0) { t = -mu * mu / 50.0; g = -mu / 25.0 + gmu; }
+                else if (d == 1) { t = prior_tau; g = 1.0 - 2.0 * t5 / (1.0 + t5) + gtl * tau; }
+                else if (d < 10) { t = term[d]; g = -x[d] + dr[d] * tau; }
+                gx[d] = g;
+                acc = acc + t;
+            }
+            p[l] = acc;
+        }
+        return pair_tree<NP>(p);
+    }
+};
+template <int NP>
+struct LFunnel {
+    static constexpr int E = 2 * NP;
+    NM_DEV void init(const double*, int) {}
+    NM_DEV double eval(const double (&x)[E], double (&gx)[E], int dim) const {
+        const double v = x[0];
+        const double kk = (double)(dim - 1);
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                const bool in = d >= 1 && d < dim;
+                acc = acc + (in ? x[d] * x[d] : 0.0);
+            }
+            p[l] = acc;
+        }
+        const double ss = pair_tree<NP>(p);
+        const double ev = lexp(-v);
+        const double g0 = -v / 9.0 - 0.5 * kk + 0.5 * ev * ss;
+#pragma unroll
+        for (int d = 0; d < E; ++d) gx[d] = d == 0 ? g0 : (d < dim ? -ev * x[d] : 0.0);
+        return -v * v / 18.0 - 0.5 * kk * v - 0.5 * ev * ss;
+    }
+};
+template <class Dens, int NP> struct LaneDensity { using type = void; };
+template <int NP> struct LaneDensity<IidNormal, NP> { using type = LIidNormal<NP>; };
+template <int NP> struct LaneDensity<DiagNormal, NP> { using type = LDiagNormal<NP>; };
+template <int NP> struct LaneDensity<Funnel, NP> { using type = LFunnel<NP>; };
+template <> struct LaneDensity<EightSchools, 5> { using type = LEightSchools<5>; };
+
+// ---- the chain's generator: every lane produces the blocks of ITS stream; 16 words per lane in LDS ([word][lane]) ----
+struct LRng {
+    uint32_t key[8];
+    uint64_t pos, base;
+    uint32_t* cache;       // LDS, this lane's column: word w at cache[64 w]
+    NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* col) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) key[i] = k[i];
+        pos = p; base = p + 16; cache = col;
+    }
+    NM_DEV uint32_t next_u32() {
+        if (pos - base >= 16ull) {                      // (also when pos < base: the difference wraps)
+            base = pos & ~15ull;
+            uint32_t out[16];
+            chacha8_block(key, base >> 4, 0ull, out);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cache[64 * i] = out[i];
+            asm volatile("" ::: "memory");
+        }
+        const uint32_t w = cache[64 * (uint32_t)(pos - base)];
+        pos += 1;
+        return w;
+    }
+    NM_DEV uint64_t next_u64() { const uint64_t lo = next_u32(), hi = next_u32(); return (hi << 32) | lo; }   // consecutive stream words (BlockRng::next_u64)
+    NM_DEV bool random_bool_std() { return (int32_t)next_u32() < 0; }
+    NM_DEV double random_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    NM_DEV int random_bool(double p) {
+        if (!(p >= 0.0 && p < 1.0)) return p == 1.0 ? 1 : -1;
+        const uint64_t p_int = (uint64_t)(p * 18446744073709551616.0);
+        return next_u64() < p_int ? 1 : 0;
+    }
+};
+// rand_distr's StandardNormal, one sample (the sequential ziggurat: its first test is the fast path)
+NM_DEV double l_normal(LRng& rng, ZigTables T) {
+    uint64_t bits = rng.next_u64();
+    for (;;) {
+        const int i = (int)(bits & 0xff);
+        const double u = u2d((bits >> 12) | 0x4000000000000000ull) - 3.0;
+        const double x = u * T.x[i];
+        if (__builtin_fabs(x) < T.x[i + 1]) return x;
+        if (i == 0) {
+            double xx = 1.0, yy = 0.0;
+            while (-2.0 * yy < xx * xx) {
+                const double a = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
+                const double b = u2d((rng.next_u64() >> 12) | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
+                xx = llog(a) / ZIG_R;
+                yy = llog(b);
+            }
+            return u < 0.0 ? xx - ZIG_R : ZIG_R - xx;
+        }
+        if (T.f[i + 1] + (T.f[i] - T.f[i + 1]) * rng.random_f64() < lexp(-x * x / 2.0)) return x;
+        bits = rng.next_u64();
+    }
+}
+
+// AcceptanceRateCollector (src/stepsize/dual_avg.rs:112-166): the lane evaluates its exps where the reference does
+struct LAccept {
+    double initial_energy, sum, sum_sym, max_energy_error;
+    uint64_t count;
+    NM_DEV void register_init(double e0) { initial_energy = e0; sum = 0.; sum_sym = 0.; count = 0; max_energy_error = 0.; }
+    NM_DEV void register_divergent() { sum = sum + 0.; sum_sym = sum_sym + 0.; count += 1; max_energy_error = -__builtin_inf(); }
+    NM_DEV void register_ok(double end_energy) {
+        const double diff = initial_energy - end_energy;
+        const double e = lexp(fmin_rs(diff, 0.));
+        const double es = 2. * e / (1. + lexp(diff));
+        sum = sum + e;
+        sum_sym = sum_sym + es;
+        count += 1;
+        if (__builtin_fabs(diff) > __builtin_fabs(max_energy_error)) max_energy_error = diff;
+    }
+    NM_DEV double mean() const { return sum / (double)count; }
+    NM_DEV double mean_sym() const { return sum_sym / (double)count; }
+};
+
+// pending sub-trees, per level, in LDS: [level][word][lane]; words: log_size, cand_logp, cand_ke, (cand_idx, cand_slot)
+struct LPend {
+    uint64_t* base;        // this lane's column
+    NM_DEV void put(int level, double log_size, const CandRef& c) {
+        uint64_t* q = base + (size_t)level * 4 * 64;
+        q[0] = d2u(log_size); q[64] = d2u(c.logp); q[128] = d2u(c.ke);
+        q[192] = ((uint64_t)(uint32_t)(int32_t)c.idx) | ((uint64_t)(uint32_t)c.slot << 32);
+    }
+    NM_DEV void get(int level, double& log_size, CandRef& c) const {
+        const uint64_t* q = base + (size_t)level * 4 * 64;
+        log_size = u2d(q[0]); c.logp = u2d(q[64]); c.ke = u2d(q[128]);
+        const uint64_t w = q[192];
+        c.idx = (int64_t)(int32_t)(uint32_t)w; c.slot = (int)(int32_t)(uint32_t)(w >> 32);
+    }
+};
+
+template <int NP>
+struct LPt { double z[2 * NP], v[2 * NP], g[2 * NP]; double logp, ke; int64_t idx; };
+
+template <int NP, class LD>
+struct LCtx {
+    static constexpr int E = 2 * NP;
+    const KParams& P;
+    LD dens;
+    LRng rng;
+    ZigTables zig;
+    double* ws;            // lane-major persistent slots, this lane's column: slot s, element e at ws[(s E + e) 64]
+    double* sv;            // lane-major tree scratch, this lane's column
+    LPend pend;
+    ChainScalars& sc;
+    double sig[E], mu[E];
+    int dim, md;
+    __device__ LCtx(const KParams& p, ChainScalars& s) : P(p), sc(s) {}
+    NM_DEV void ldW(double (&t)[E], int slot) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) t[e] = ws[(size_t)(slot * E + e) * 64];
+    }
+    NM_DEV void stW(const double (&t)[E], int slot) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) ws[(size_t)(slot * E + e) * 64] = t[e];
+    }
+    NM_DEV void ldS(double (&t)[E], int slot) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) t[e] = sv[(size_t)(slot * E + e) * 64];
+    }
+    NM_DEV void stS(const double (&t)[E], int slot) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sv[(size_t)(slot * E + e) * 64] = t[e];
+    }
+    // main-tree edges (slot scheme of nuts_kernels.hpp): id 0 = the initial point (P_Z / STAGE_V / P_GZ), ids 1, 2 scratch
+    NM_DEV void ld_edge(LPt<NP>& p, int id) const {
+        if (id == 0) { ldW(p.z, P_Z); ldS(p.v, STAGE_V); ldW(p.g, P_GZ); }
+        else { ldS(p.z, EDGE0_Z + 3 * id); ldS(p.v, EDGE0_V + 3 * id); ldS(p.g, EDGE0_G + 3 * id); }
+    }
+    NM_DEV void ld_edge_zv(double (&z)[E], double (&v)[E], int id) const {
+        if (id == 0) { ldW(z, P_Z); ldS(v, STAGE_V); }
+        else { ldS(z, EDGE0_Z + 3 * id); ldS(v, EDGE0_V + 3 * id); }
+    }
+};
+
+template <int NP, class LD>
+NM_DEV void l_leapfrog(LCtx<NP, LD>& C, const LPt<NP>& s, LPt<NP>& o, double epsilon) {
+    constexpr int E = 2 * NP;
+    const double half = epsilon / 2.;
+    double x[E], gx[E];
+#pragma unroll
+    for (int d = 0; d < E; ++d) {
+        const double vh = __builtin_fma(half, s.g[d], s.v[d]);
+        o.v[d] = vh;
+        o.z[d] = __builtin_fma(epsilon, vh, s.z[d]);
+        const double t = o.z[d] * C.sig[d];
+        x[d] = __builtin_fma(1.0, C.mu[d], t);
+    }
+    o.logp = C.dens.eval(x, gx, C.dim);
+    double p[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * l + k;
+            o.g[d] = gx[d] * C.sig[d];
+            o.v[d] = __builtin_fma(half, o.g[d], o.v[d]);
+            acc = __builtin_fma(o.v[d], o.v[d], acc);
+        }
+        p[l] = acc;
+    }
+    o.ke = 0.5 * pair_tree<NP>(p);
+}
+
+// is_turning sums of one (start, end) pair of points over the chain: the two scalar_prods3 results
+template <int NP>
+NM_DEV void l_turn_sums(const double (&zs)[2 * NP], const double (&vs)[2 * NP], const double (&ze)[2 * NP], const double (&ve)[2 * NP],
+                        double& t1, double& t2) {
+    double p1[NP], p2[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double a1 = 0., a2 = 0.;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) turn_acc(zs[2 * l + k], vs[2 * l + k], ze[2 * l + k], ve[2 * l + k], a1, a2);
+        p1[l] = a1; p2[l] = a2;
+    }
+    t1 = pair_tree<NP>(p1); t2 = pair_tree<NP>(p2);
+}
+template <int NP>
+NM_DEV bool l_turning(const double (&az)[2 * NP], const double (&av)[2 * NP], const double (&bz)[2 * NP], const double (&bv)[2 * NP], bool fwd) {
+    double s1, s2;
+    if (fwd) l_turn_sums<NP>(az, av, bz, bv, s1, s2);
+    else l_turn_sums<NP>(bz, bv, az, av, s1, s2);
+    return (s1 < 0.) | (s2 < 0.);
+}
+
+template <int NP, class LD>
+NM_DEV bool l_merge_weights(LCtx<NP, LD>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
+    total = llogaddexp(a_log_size, b_log_size);
+    const double self_log_size = is_main ? a_log_size : total;
+    if (b_log_size >= self_log_size) return true;
+    const int b = C.rng.random_bool(lexp(b_log_size - self_log_size));
+    if (b < 0) { fatal = true; return false; }
+    return b == 1;
+}
+template <int NP, class LD>
+NM_DEV int l_cand_to_pool(LCtx<NP, LD>& C, uint32_t& used, const double (&z)[2 * NP]) {
+    const int p = (int)__builtin_ctz(~used);
+    used |= 1u << p;
+    C.stS(z, slot_C(C.md, p));
+    return p;
+}
+
+// nuts::draw for the lane's chain (reference src/nuts.rs:281-388): the port of nuts_transition / g_transition
+template <int NP, class LD>
+NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, double (&zc)[2 * NP]) {
+    constexpr int E = 2 * NP;
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const int MD = C.md;
+    LPt<NP> Ep, Op;
+#pragma unroll
+    for (int d = 0; d < E; ++d) {                    // array_gaussian: the stream order is the element order
+        const double nrm = d < C.dim ? l_normal(C.rng, C.zig) : 0.0;
+        Ep.v[d] = d < C.dim ? 1.0 * nrm : 0.0;
+    }
+    C.stS(Ep.v, STAGE_V);
+    if (sc.mm_id != sc.transform_id) {        // lazy re-whitening after the last mass-matrix update (diagonal.rs:210-221)
+        double x[E], gx[E], isig[E];
+        C.ldW(x, P_X); C.ldW(gx, P_GX); C.ldW(isig, P_ISIG);
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double t = __builtin_fma(-1.0, C.mu[d], x[d]);
+            Ep.z[d] = isig[d] * t;
+            Ep.g[d] = gx[d] * C.sig[d];
+        }
+        C.stW(Ep.z, P_Z); C.stW(Ep.g, P_GZ);
+        sc.logdet = sc.mm_logdet;
+        sc.transform_id = sc.mm_id;
+    } else {
+        C.ldW(Ep.z, P_Z);
+        C.ldW(Ep.g, P_GZ);
+    }
+    const double logdet = sc.logdet;
+    double ke_init;
+    {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc = __builtin_fma(Ep.v[2 * l + k], Ep.v[2 * l + k], acc);
+            p[l] = acc;
+        }
+        ke_init = 0.5 * pair_tree<NP>(p);
+    }
+    const double e0 = ke_init - (sc.logp + logdet);
+    R.e0 = e0;
+    col.register_init(e0);
+    int left_slot = 0, right_slot = 0;
+    bool o_is_edge = false;
+    int o_edge_sign = 0;
+    uint64_t depth = 0;
+    double log_size = 0.;
+    int64_t left_idx = 0, right_idx = 0;
+    CandRef mc = {-1, sc.logp, ke_init, 0};
+    uint32_t used = 0;
+
+    uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
+    if (s.has_target_integration_time) {
+        const double q = __builtin_ceil(s.target_integration_time / sc.step_size);
+        const uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
+        const uint64_t fl = 63 - __builtin_clzll(max_steps | 1ull);
+        const uint64_t ce = ((max_steps & (max_steps - 1)) == 0) ? fl : fl + 1;
+        mindepth = fl > s.mindepth ? fl : s.mindepth;
+        const uint64_t xd = ce > mindepth ? ce : mindepth;
+        maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
+    }
+    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false; R.has_div_end = true;
+    R.divergence_energy_error = 0.; R.div_start_idx = 0;
+    const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
+    bool fatal = false;
+    bool in_extra = false;
+    uint64_t extra_left = 0;
+    int sign = 1;
+
+    for (;;) {
+        bool check;
+        if (!in_extra) {
+            if (!(depth < maxdepth)) { R.reached_maxdepth = true; break; }
+            sign = C.rng.random_bool_std() ? 1 : -1;
+            check = (s.check_turning != 0) && !(depth < mindepth);
+        } else {
+            if (extra_left == 0) break;
+            extra_left -= 1;
+            check = false;
+        }
+        const bool fwd = sign > 0;
+        const int64_t edge_idx = fwd ? right_idx : left_idx;
+        const uint64_t nleaf = 1ull << depth;
+        const uint32_t used_before = used;
+        const double epsilon = (double)sign * sc.step_size * 1.0;
+        int stop = STOP_NONE;
+        double sub_log_size = 0.;
+        CandRef sub_cand = {-2, 0., 0., 0};
+        const bool reuse_edge = o_is_edge && o_edge_sign == sign;
+        o_is_edge = false;
+
+#define NM_L_ACCOUNT(START, PT, WOUT)                                                                      \
+        {                                                                                                 \
+            const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
+            const double err_ = energy_ - e0;                                                             \
+            if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
+                col.register_divergent();                                                                 \
+                R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
+                R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
+                if (want_div) { C.stS((START).z, slot_F(0)); C.stS((PT).z, slot_F(0) + 1); }              \
+                stop = STOP_DIVERGING;                                                                    \
+            } else {                                                                                      \
+                col.register_ok(energy_);                                                                 \
+                WOUT = -err_;                                                                             \
+            }                                                                                             \
+        }
+
+        if (depth == 0) {
+            l_leapfrog(C, Ep, Op, epsilon);
+            Op.idx = edge_idx + (int64_t)sign;
+            NM_L_ACCOUNT(Ep, Op, sub_log_size)
+            sub_cand = {-2, Op.logp, Op.ke, Op.idx};
+        } else {
+            if (!reuse_edge) C.ld_edge(Op, fwd ? right_slot : left_slot);
+            for (uint64_t n = 0; n < nleaf; n += 2) {
+                double wE = 0., wO = 0.;
+                l_leapfrog(C, Op, Ep, epsilon);
+                Ep.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
+                NM_L_ACCOUNT(Op, Ep, wE)
+                if (stop != STOP_NONE) break;
+                l_leapfrog(C, Ep, Op, epsilon);
+                Op.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
+                NM_L_ACCOUNT(Ep, Op, wO)
+                if (stop != STOP_NONE) break;
+                const uint64_t nn = n + 1;
+                const int t = (int)__builtin_ctzll(~nn);
+                uint32_t turn_bits = 0;
+                if (check) {
+                    if (l_turning<NP>(Ep.z, Ep.v, Op.z, Op.v, fwd)) turn_bits |= 2u;
+                    for (int k = 2; k <= t && turn_bits == 0; ++k) {
+                        // (A.first, B.last) (A.last, B.last) (A.first, B.first) in generation order  [src/nuts.rs:143-161]
+                        const uint64_t a_first = nn + 1 - (1ull << k);
+                        const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
+                        double az[E], av[E], lz[E], lv[E];
+                        C.ldS(az, slot_F(fa)); C.ldS(av, slot_F(fa) + 1);
+                        C.ldS(lz, slot_L(MD, k - 1)); C.ldS(lv, slot_L(MD, k - 1) + 1);
+                        bool tn = l_turning<NP>(az, av, Op.z, Op.v, fwd) | l_turning<NP>(lz, lv, Op.z, Op.v, fwd);
+                        if (k == 2) tn = tn | l_turning<NP>(az, av, Ep.z, Ep.v, fwd);
+                        else {
+                            double bz[E], bv[E];
+                            C.ldS(bz, slot_F(k - 1)); C.ldS(bv, slot_F(k - 1) + 1);
+                            tn = tn | l_turning<NP>(az, av, bz, bv, fwd);
+                        }
+                        if (tn) turn_bits |= 1u << k;
+                    }
+                }
+                {
+                    double total;
+                    const bool take = l_merge_weights(C, wE, wO, false, total, fatal);
+                    sub_cand = take ? CandRef{-2, Op.logp, Op.ke, Op.idx} : CandRef{-3, Ep.logp, Ep.ke, Ep.idx};
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if (turn_bits & 2u) { stop = STOP_TURNING; break; }
+                }
+                for (int k = 2; k <= t; ++k) {
+                    double a_log_size; CandRef ac;
+                    C.pend.get(k - 1, a_log_size, ac);
+                    double total;
+                    const bool take = l_merge_weights(C, a_log_size, sub_log_size, false, total, fatal);
+                    if (take) {
+                        used &= ~(1u << ac.slot);
+                    } else {
+                        if (sub_cand.slot >= 0) used &= ~(1u << sub_cand.slot);
+                        sub_cand = ac;
+                    }
+                    sub_log_size = total;
+                    if (fatal) { stop = STOP_FATAL; break; }
+                    if ((turn_bits >> k) & 1u) { stop = STOP_TURNING; break; }
+                }
+                if (stop != STOP_NONE) break;
+                if ((n & 3) == 0 && depth > 1) {
+                    const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
+                    C.stS(Ep.z, fs);
+                    C.stS(Ep.v, fs + 1);
+                }
+                if (n + 2 < nleaf) {
+                    C.stS(Op.z, slot_L(MD, t)); C.stS(Op.v, slot_L(MD, t) + 1);
+                    if (sub_cand.slot == -2) sub_cand.slot = l_cand_to_pool(C, used, Op.z);
+                    else if (sub_cand.slot == -3) sub_cand.slot = l_cand_to_pool(C, used, Ep.z);
+                    C.pend.put(t, sub_log_size, sub_cand);
+                }
+            }
+        }
+#undef NM_L_ACCOUNT
+        if (stop == STOP_FATAL) { fatal = true; break; }
+        if (stop == STOP_DIVERGING) { used = used_before; break; }
+        if (stop == STOP_TURNING) {
+            used = used_before;
+            if (!in_extra) { in_extra = true; extra_left = s.extra_doublings; }
+            continue;
+        }
+        // top-level U-turn tests of the finished sub-tree (last leaf O) against the main tree (src/nuts.rs:143-161)
+        bool turning = false;
+        if (check) {
+            if (depth == 0) turning = l_turning<NP>(Ep.z, Ep.v, Op.z, Op.v, fwd);
+            else {
+                double lz[E], lv[E], rz[E], rv[E], oz[E], ov[E];
+                C.ld_edge_zv(lz, lv, left_slot);
+                C.ld_edge_zv(rz, rv, right_slot);
+                if (depth == 1) {
+#pragma unroll
+                    for (int d = 0; d < E; ++d) { oz[d] = Ep.z[d]; ov[d] = Ep.v[d]; }
+                } else { C.ldS(oz, slot_F((int)depth)); C.ldS(ov, slot_F((int)depth) + 1); }
+                // fwd: (tree.left, other.right) (tree.right, other.right) (tree.left, other.left), other.right = O;
+                // else: (other.left, tree.right) (other.right, tree.right) (other.left, tree.left), other.left = O
+                if (fwd) turning = l_turning<NP>(lz, lv, Op.z, Op.v, true) | l_turning<NP>(rz, rv, Op.z, Op.v, true) | l_turning<NP>(lz, lv, oz, ov, true);
+                else turning = l_turning<NP>(rz, rv, Op.z, Op.v, false) | l_turning<NP>(rz, rv, oz, ov, false) | l_turning<NP>(lz, lv, Op.z, Op.v, false);
+            }
+        }
+        double total;
+        const bool take = l_merge_weights(C, log_size, sub_log_size, true, total, fatal);
+        if (fatal) break;
+        if (take) {
+            if (mc.slot >= 0) used &= ~(1u << mc.slot);
+            if (sub_cand.slot == -2) sub_cand.slot = l_cand_to_pool(C, used, Op.z);
+            else if (sub_cand.slot == -3) sub_cand.slot = l_cand_to_pool(C, used, Ep.z);
+            mc = sub_cand;
+        } else if (sub_cand.slot >= 0) {
+            used &= ~(1u << sub_cand.slot);
+        }
+        const bool more = in_extra ? extra_left > 0 : (turning ? s.extra_doublings > 0 : depth + 1 < maxdepth);
+        if (more) {
+            int ns = fwd ? right_slot : left_slot;
+            const int other_side = fwd ? left_slot : right_slot;
+            if (ns == 0) ns = other_side == 1 ? 2 : 1;
+            C.stS(Op.z, EDGE0_Z + 3 * ns); C.stS(Op.v, EDGE0_V + 3 * ns); C.stS(Op.g, EDGE0_G + 3 * ns);
+            if (fwd) right_slot = ns; else left_slot = ns;
+            o_is_edge = true; o_edge_sign = sign;
+        }
+        if (fwd) right_idx = Op.idx; else left_idx = Op.idx;
+        depth += 1;
+        log_size = total;
+        if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
+    }
+    R.depth = depth;
+    R.chosen = mc;
+    if (fatal) return NM_CHAIN_LOGP_FATAL;
+    if (mc.slot >= 0) C.ldS(zc, slot_C(MD, mc.slot));
+    return NM_CHAIN_OK;
+}
+
+// ---- warm-up (lane forms of the adaptation in nuts_kernels.hpp / nuts_group_impl.hpp) ----
+NM_DEV void l_stepsize_adapt_reset(ChainScalars& sc, const nm_settings& s, double initial_step) {
+    sc.log_step = llog(initial_step);
+    if (s.step_size_method == NM_STEP_ADAM) { sc.adam_m = 0.; sc.adam_v = 0.; sc.adam_t = 0; return; }
+    sc.log_step_adapted = sc.log_step;
+    sc.hbar = 0.;
+    sc.mu = llog(10. * initial_step);
+    sc.da_count = 1;
+}
+template <int NP, class LD>
+NM_DEV void l_update_stepsize(LCtx<NP, LD>& C, bool use_best_guess) {
+    const nm_settings& s = C.P.s;
+    const double step = s.step_size_method == NM_STEP_FIXED ? s.fixed_step_size
+                      : s.step_size_method == NM_STEP_ADAM ? lexp(C.sc.log_step)
+                      : (use_best_guess ? lexp(C.sc.log_step_adapted) : lexp(C.sc.log_step));
+    if (s.has_jitter) {
+        const double v12 = u2d((C.rng.next_u64() >> 12) | 0x3ff0000000000000ull);
+        const double j = (v12 - 1.0) * C.P.jitter_scale + C.P.jitter_low;
+        C.sc.step_size = step * j;
+    } else {
+        C.sc.step_size = step;
+    }
+}
+template <int NP, class LD>
+NM_DEV void l_update_estimator(LCtx<NP, LD>& C, bool late) {
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) return;
+    ChainScalars& sc = C.sc;
+    const double accept_stat = late ? sc.last_sym_mean_tree_accept : sc.last_mean_tree_accept;
+    if (s.step_size_method == NM_STEP_ADAM) {
+        const double gradient = accept_stat - s.target_accept;
+        sc.adam_t += 1;
+        sc.adam_m = s.adam_beta1 * sc.adam_m + (1.0 - s.adam_beta1) * gradient;
+        sc.adam_v = s.adam_beta2 * sc.adam_v + (1.0 - s.adam_beta2) * gradient * gradient;
+        const double m_hat = sc.adam_m / (1.0 - powi_rs(s.adam_beta1, (int32_t)sc.adam_t));
+        const double v_hat = sc.adam_v / (1.0 - powi_rs(s.adam_beta2, (int32_t)sc.adam_t));
+        sc.log_step += s.adam_learning_rate * m_hat / (__builtin_sqrt(v_hat) + s.adam_epsilon);
+        return;
+    }
+    const double w = 1. / ((double)sc.da_count + s.da_t0);
+    sc.hbar = (1. - w) * sc.hbar + w * (s.target_accept - accept_stat);
+    sc.log_step = sc.mu - sc.hbar * __builtin_sqrt((double)sc.da_count) / s.da_gamma;
+    sc.log_step = fmin_rs(sc.log_step, C.P.ln_max_step);
+    const double mk = lexp(-s.da_k * llog((double)sc.da_count));
+    sc.log_step_adapted = mk * sc.log_step + (1. - mk) * sc.log_step_adapted;
+    sc.da_count += 1;
+}
+template <int E>
+NM_DEV void l_running_variance_add(double (&mean)[E], double (&var)[E], uint64_t new_count, const double (&value)[E]) {
+    if (new_count == 1) {
+#pragma unroll
+        for (int d = 0; d < E; ++d) mean[d] = value[d];
+        return;
+    }
+    const double diff_scale = 1.0 / (double)new_count;
+#pragma unroll
+    for (int d = 0; d < E; ++d) {
+        const double diff = value[d] - mean[d];
+        mean[d] = mean[d] + diff * diff_scale;
+        var[d] = var[d] + diff * diff;
+    }
+}
+template <int NP, class LD>
+NM_DEV void l_commit_mass_matrix(LCtx<NP, LD>& C, const double (&sig)[2 * NP], const double (&isig)[2 * NP], const double (&mu)[2 * NP]) {
+    constexpr int E = 2 * NP;
+    C.stW(sig, P_SIG); C.stW(isig, P_ISIG); C.stW(mu, P_MU);
+#pragma unroll
+    for (int d = 0; d < E; ++d) { C.sig[d] = sig[d]; C.mu[d] = mu[d]; }
+    double p[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * l + k;
+            const bool valid = d < C.dim;
+            acc = acc + (valid ? llog(valid ? isig[d] : 1.0) : 0.0);
+        }
+        p[l] = acc;
+    }
+    C.sc.mm_logdet = pair_tree<NP>(p);
+    C.sc.mm_id += 1;
+}
+template <int NP, class LD>
+NM_DEV bool l_mass_matrix_adapt(LCtx<NP, LD>& C, const double (&dm)[2 * NP], const double (&dv)[2 * NP], const double (&gm)[2 * NP], const double (&gv)[2 * NP]) {
+    constexpr int E = 2 * NP;
+    if (C.sc.cnt_fg < 3) return false;
+    double sig[E], isig[E], mu[E];
+    C.ldW(isig, P_ISIG);
+    if (C.P.s.use_grad_based_estimate) {
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const bool valid = d < C.dim;
+            double val = __builtin_sqrt(dv[d] / gv[d]);
+            double sd = C.sig[d], isd = isig[d];
+            if (!(!is_finite(val) | (val == 0.0))) {
+                val = clampd(val, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            const double var = sd * sd;
+            double mean = var * gm[d];
+            mean = __builtin_fma(1.0, dm[d], mean);
+            sig[d] = valid ? sd : 0.0;
+            isig[d] = valid ? isd : 0.0;
+            mu[d] = valid ? mean : 0.0;
+        }
+    } else {
+        const double scale = 1.0 / (double)C.sc.cnt_fg;
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const bool valid = d < C.dim;
+            const double dd = dv[d] * scale;
+            double sd = C.sig[d], isd = isig[d];
+            if (!(!is_finite(dd) | (dd == 0.0))) {
+                const double val = clampd(dd, 1e-20, 1e20);
+                sd = __builtin_sqrt(val);
+                isd = __builtin_sqrt(1.0 / val);
+            }
+            sig[d] = valid ? sd : 0.0;
+            isig[d] = valid ? isd : 0.0;
+            mu[d] = valid ? dm[d] : 0.0;
+        }
+    }
+    l_commit_mass_matrix(C, sig, isig, mu);
+    return true;
+}
+// stepsize::Strategy::init (src/stepsize/adapt.rs:91-199): the step-size search at x, after the first mass-matrix update
+template <int NP, class LD>
+NM_DEV uint64_t l_stepsize_init(LCtx<NP, LD>& C, const double (&x)[2 * NP]) {
+    constexpr int E = 2 * NP;
+    const nm_settings& s = C.P.s;
+    if (s.step_size_method == NM_STEP_FIXED) { C.sc.step_size = s.fixed_step_size; return NM_CHAIN_OK; }
+    LPt<NP> st;
+    {   // Hamiltonian::init_state (transformed_hamiltonian.rs:640-661, check_all :310-324)
+        double gx[E], isig[E];
+        st.logp = C.dens.eval(x, gx, C.dim);
+        C.ldW(isig, P_ISIG);
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double t = __builtin_fma(-1.0, C.mu[d], x[d]);
+            st.z[d] = isig[d] * t;
+            st.g[d] = gx[d] * C.sig[d];
+            const bool valid = d < C.dim;
+            ok = ok && (!valid || (is_finite(st.z[d]) && is_finite(st.g[d]) && st.g[d] != 0.0 && is_finite(gx[d]) && is_finite(x[d])));
+        }
+        if (!ok) return NM_CHAIN_BAD_INIT;
+    }
+    const double logdet = C.sc.mm_logdet;
+    double ke0;
+    {
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double nrm = d < C.dim ? l_normal(C.rng, C.zig) : 0.0;
+            st.v[d] = d < C.dim ? 1.0 * nrm : 0.0;
+        }
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc = __builtin_fma(st.v[2 * l + k], st.v[2 * l + k], acc);
+            p[l] = acc;
+        }
+        ke0 = 0.5 * pair_tree<NP>(p);
+    }
+    const double e0 = ke0 - (st.logp + logdet);
+    LAccept col;
+    C.sc.step_size = s.initial_step;
+    int dir = 0;
+    for (int it = 0; it < 101; ++it) {
+        LPt<NP> o;
+        const int sign = it == 0 ? 1 : dir;
+        col.register_init(e0);
+        l_leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0);
+        const double energy = o.ke - (o.logp + logdet);
+        const double err = energy - e0;
+        if ((err > 1000.0) | !is_finite(err)) {
+            if (it > 0) C.sc.step_size = s.initial_step;
+            return NM_CHAIN_OK;
+        }
+        col.register_ok(energy);
+        const double accept = col.mean();
+        if (it == 0) { dir = accept > s.target_accept ? 1 : -1; continue; }
+        if (dir > 0) {
+            if ((accept <= s.target_accept) | (C.sc.step_size > 1e5)) { l_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size *= 2.;
+        } else {
+            if ((accept >= s.target_accept) | (C.sc.step_size < 1e-10)) { l_stepsize_adapt_reset(C.sc, s, C.sc.step_size); return NM_CHAIN_OK; }
+            C.sc.step_size /= 2.;
+        }
+    }
+    C.sc.step_size = s.initial_step;
+    return NM_CHAIN_OK;
+}
+// GlobalStrategy::adapt (src/adapt_strategy.rs:121-222); x, gx = the chosen draw
+template <bool TUNE, int NP, class LD>
+NM_DEV uint64_t l_adapt(LCtx<NP, LD>& C, LAccept& col, bool is_good, const double (&x)[2 * NP], const double (&gx)[2 * NP]) {
+    constexpr int E = 2 * NP;
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    const uint64_t draw = sc.draw_count;
+    sc.last_mean_tree_accept = col.mean();
+    sc.last_sym_mean_tree_accept = col.mean_sym();
+    sc.last_n_steps = col.count;
+    sc.last_max_energy_error = col.max_energy_error;
+    if (!TUNE || draw >= s.num_tune) {     // the sampling kernel (TUNE = false) is only launched once every chain is there
+        l_update_stepsize(C, true);
+        sc.tuning = 0;
+        return NM_CHAIN_OK;
+    }
+    if (draw < C.P.final_step_size_window) {
+        const bool is_early = draw < C.P.early_end;
+        if (!is_early && draw == C.P.early_end)
+            sc.current_window_size = sc.current_window_size > sc.cnt_bg ? sc.current_window_size : sc.cnt_bg;
+        const uint64_t switch_freq = is_early ? s.early_mass_matrix_switch_freq : sc.current_window_size;
+        double fdm[E], fdv[E], fgm[E], fgv[E], bdm[E], bdv[E], bgm[E], bgv[E];
+        C.ldW(fdm, E_DM); C.ldW(fdv, E_DV); C.ldW(fgm, E_GM); C.ldW(fgv, E_GV);
+        C.ldW(bdm, B_DM); C.ldW(bdv, B_DV); C.ldW(bgm, B_GM); C.ldW(bgv, B_GV);
+        bool dirty = false;
+        if (is_good) {
+            sc.cnt_fg += 1;
+            sc.cnt_bg += 1;
+            l_running_variance_add<E>(fdm, fdv, sc.cnt_fg, x);
+            l_running_variance_add<E>(fgm, fgv, sc.cnt_fg, gx);
+            l_running_variance_add<E>(bdm, bdv, sc.cnt_bg, x);
+            l_running_variance_add<E>(bgm, bgv, sc.cnt_bg, gx);
+            dirty = true;
+        }
+        const bool could_switch = sc.cnt_bg >= switch_freq;
+        uint64_t next_window_size;
+        if (is_early) next_window_size = s.early_mass_matrix_switch_freq;
+        else {
+            const double gv = (double)sc.current_window_size * s.mass_matrix_window_growth;
+            const double fl = __builtin_floor(gv);
+            const uint64_t grown = (uint64_t)((gv - fl >= 0.5) ? fl + 1.0 : fl);
+            next_window_size = sc.current_window_size + 1 > grown ? sc.current_window_size + 1 : grown;
+        }
+        const bool is_late = next_window_size + draw > C.P.final_step_size_window;
+        bool force_update = false;
+        if (could_switch && !is_late) {
+#pragma unroll
+            for (int d = 0; d < E; ++d) {
+                fdm[d] = bdm[d]; fdv[d] = bdv[d]; fgm[d] = bgm[d]; fgv[d] = bgv[d];
+                bdm[d] = 0.0; bdv[d] = 0.0; bgm[d] = 0.0; bgv[d] = 0.0;
+            }
+            sc.cnt_fg = sc.cnt_bg;
+            sc.cnt_bg = 0;
+            force_update = true;
+            dirty = true;
+            if (!is_early) sc.current_window_size = next_window_size;
+        }
+        if (dirty) {
+            C.stW(bdm, B_DM); C.stW(bdv, B_DV); C.stW(bgm, B_GM); C.stW(bgv, B_GV);
+            C.stW(fdm, E_DM); C.stW(fdv, E_DV); C.stW(fgm, E_GM); C.stW(fgv, E_GV);
+        }
+        bool did_change = false;
+        if (force_update | (draw - sc.last_update >= s.mass_matrix_update_freq)) did_change = l_mass_matrix_adapt(C, fdm, fdv, fgm, fgv);
+        if (did_change) sc.last_update = draw;
+        l_update_estimator(C, is_late);
+        if (did_change & (sc.has_initial_mass_matrix != 0)) {
+            sc.has_initial_mass_matrix = 0;
+            return l_stepsize_init(C, x);
+        }
+        l_update_stepsize(C, false);
+        return NM_CHAIN_OK;
+    }
+    l_update_estimator(C, true);
+    l_update_stepsize(C, draw == s.num_tune - 1);
+    return NM_CHAIN_OK;
+}
+
+template <int NP, class LD>
+NM_DEV void l_write_row(LCtx<NP, LD>& C, double* base, size_t row, const double (&t)[2 * NP]) {
+    if (!base) return;
+    double* dst = base + row;
+#pragma unroll
+    for (int d = 0; d < 2 * NP; ++d) if (d < C.dim) dst[d] = t[d];
+}
+// DivergenceInfo.{start_location, start_gradient, end_location} (transformed_hamiltonian.rs:590-604), as emit_divergence_vectors
+template <int NP, class LD>
+NM_DEV void l_emit_divergence_vectors(LCtx<NP, LD>& C, int64_t start_idx, size_t row) {
+    constexpr int E = 2 * NP;
+    const KParams& P = C.P;
+    double x[E], gx[E], zt[E];
+    if (start_idx == 0) {
+        C.ldW(x, P_X); C.ldW(gx, P_GX);
+    } else {
+        C.ldS(zt, slot_F(0));
+#pragma unroll
+        for (int d = 0; d < E; ++d) x[d] = __builtin_fma(1.0, C.mu[d], zt[d] * C.sig[d]);
+        (void)C.dens.eval(x, gx, C.dim);
+    }
+    l_write_row(C, P.out_div_start, row, x);
+    l_write_row(C, P.out_div_start_grad, row, gx);
+    C.ldS(zt, slot_F(0) + 1);
+#pragma unroll
+    for (int d = 0; d < E; ++d) x[d] = __builtin_fma(1.0, C.mu[d], zt[d] * C.sig[d]);
+    l_write_row(C, P.out_div_end, row, x);
+}
+
+// NutsChain::draw (reference src/chain.rs:151-188) + the scalar statistics of expanded_draw (:190-232)
+template <bool TUNE, int NP, class LD>
+NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
+    constexpr int E = 2 * NP;
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    LAccept col;
+    DrawResult R;
+    double x[E], gx[E], z[E], gz[E];
+    const uint64_t st = l_transition(C, col, R, z);
+    nm_draw_stats out;
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    if (st != NM_CHAIN_OK) {
+        sc.status = st;
+        if (P.out_stats) {
+            nm_draw_stats zz = {};
+            zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = st;
+            P.out_stats[t_out * P.n_chains + chain] = zz;
+        }
+        return;
+    }
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
+        l_emit_divergence_vectors(C, R.div_start_idx, row);          // before P_X / P_GX take the new draw
+    if (R.chosen.slot == -1 && !sc.px_stale) {
+        C.ldW(x, P_X); C.ldW(gx, P_GX);
+        C.ldW(z, P_Z); C.ldW(gz, P_GZ);
+    } else {
+        if (R.chosen.slot == -1) C.ldW(z, P_Z);
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double tt = z[d] * C.sig[d];
+            x[d] = __builtin_fma(1.0, C.mu[d], tt);
+        }
+        (void)C.dens.eval(x, gx, C.dim);
+#pragma unroll
+        for (int d = 0; d < E; ++d) gz[d] = gx[d] * C.sig[d];
+        const bool need_x = sc.tuning || t_out + 1 == P.n_draws || P.out_div_start || P.out_div_start_grad;
+        if (need_x) { C.stW(x, P_X); C.stW(gx, P_GX); }
+        sc.px_stale = need_x ? 0 : 1;
+        C.stW(z, P_Z); C.stW(gz, P_GZ);
+        sc.logp = R.chosen.logp;
+    }
+    const int64_t idx = R.chosen.idx;
+    l_write_row(C, P.out_positions, row, x);
+    l_write_row(C, P.out_gradient, row, gx);                     // PointStats (transformed_hamiltonian.rs:122-157)
+    l_write_row(C, P.out_tpos, row, z);
+    l_write_row(C, P.out_tgrad, row, gz);
+    double fd;
+    {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int d = 2 * l + k; acc = acc + (z[d] + gz[d]) * (z[d] + gz[d]); }
+            p[l] = acc;
+        }
+        fd = pair_tree<NP>(p);
+    }
+    const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
+    const int64_t trans_id = sc.transform_id;
+    sc.total_steps += col.count;
+    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);     // DrawGradCollector (adapt/diagonal.rs:73-83)
+    const uint64_t ast = l_adapt<TUNE>(C, col, is_good, x, gx);
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.index_in_trajectory = idx; out.transformation_index = trans_id;
+    out.step_size = sc.step_size;
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size
+                      : P.s.step_size_method == NM_STEP_ADAM ? lexp(sc.log_step) : lexp(sc.log_step_adapted);
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
+    out.chain_status = ast;
+    out.transformation_update_id = -1;
+    out.num_eigenvalues = 0;
+    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
+    if (sc.mm_id != sc.stats_last_id) {                         // DiagMassMatrix::extract_stats (transform/diagonal.rs:48-70)
+        out.transformation_update_id = sc.mm_id;
+        l_write_row(C, P.out_mm_inv, row, C.sig);
+        l_write_row(C, P.out_mm_mu, row, C.mu);
+    }
+    sc.stats_last_id = sc.mm_id;
+    if (P.out_stats) P.out_stats[t_out * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
+struct LaneShared {
+    uint32_t rng_cache[16 * 64];                          // [word][lane]
+    uint64_t pend[(LMAXDEPTH + 1) * 4 * 64];              // [level][word][lane]
+};
+
+// One block = one wavefront = 64 chains; blocks stride over the chains.  TUNE = true: the adaptation compiled in (launches that
+// start inside the warm-up).
+template <class Dens, int NP, bool TUNE>
+__global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, const LaneParams LP) {
+    using LD = typename LaneDensity<Dens, NP>::type;
+    constexpr int E = 2 * NP;
+    __shared__ LaneShared sh;
+    dm_init_lds();
+    const int l = (int)threadIdx.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < P.n_chains; base += (uint64_t)gridDim.x * 64) {
+        const uint64_t chain = base + (uint64_t)l;
+        if (chain < P.n_chains) {
+            ChainScalars sc = P.sc[chain];
+            LCtx<NP, LD> C(P, sc);
+            C.dim = (int)P.dim;
+            C.md = (int)P.s.maxdepth;
+            C.ws = LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64 + l;
+            C.sv = LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64 + l;
+            C.pend.base = sh.pend + l;
+            C.zig = {P.zig_x, P.zig_f};
+            {   // the chain's persistent vectors: pvec[chain][slot][d] -> lane-major workspace
+                const double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
+                for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) C.ws[(size_t)(s_ * E + e) * 64] = pv[(size_t)s_ * P.dpad + e];
+            }
+            C.ldW(C.sig, P_SIG); C.ldW(C.mu, P_MU);
+            C.rng.init(sc.key, sc.rng_pos, sh.rng_cache + l);
+            C.dens.init(P.logp_params, C.dim);
+            if (sc.status == NM_CHAIN_OK) {
+                for (uint64_t t = 0; t < P.n_draws; ++t) {
+                    l_chain_draw<TUNE>(C, chain, t);
+                    if (sc.status != NM_CHAIN_OK) break;
+                }
+            }
+            sc.rng_pos = C.rng.pos;
+            {
+                double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
+                for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ws[(size_t)(s_ * E + e) * 64];
+            }
+            P.sc[chain] = sc;
+        }
+    }
+}
+
+}  // namespace lane
+}  // namespace nm

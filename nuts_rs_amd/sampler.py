@@ -294,7 +294,7 @@ class ChainBatch:
 
     def __init__(self, settings: DiagNutsSettings, logp: LogpSpec, n_chains: Optional[int] = None,
                  chain_id_offset: int = 0, device: int = -1, dims_per_lane: int = 0, waves_per_chain: int = 0,
-                 grid_blocks: int = 0, lane_groups: int = 0, lowrank_max_rank: int = 0, chain_tiles: int = 0):
+                 grid_blocks: int = 0, lane_groups: int = 0, lowrank_max_rank: int = 0, chain_tiles: int = 0, lane_chains: int = 0):
         self.settings = settings
         self.logp = logp
         self.n_chains = int(n_chains if n_chains is not None else settings.num_chains)
@@ -304,7 +304,7 @@ class ChainBatch:
         L.nm_engine_config_default(C.byref(cfg))
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
         cfg.waves_per_chain, cfg.grid_blocks, cfg.lane_groups = waves_per_chain, grid_blocks, lane_groups
-        cfg.lowrank_max_rank, cfg.chain_tiles = lowrank_max_rank, chain_tiles
+        cfg.lowrank_max_rank, cfg.chain_tiles, cfg.lane_chains = lowrank_max_rank, chain_tiles, lane_chains
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()
@@ -335,6 +335,10 @@ class ChainBatch:
     def group_launches(self) -> int:
         """Draw launches served by the 8-chains-per-wavefront kernel (small chains, after warm-up)."""
         return int(_lib.load().nm_engine_group_launches(self._h))
+
+    def lane_launches(self) -> int:
+        """Draw launches served by the one-chain-per-lane kernels (dim <= 16, nuts_lane.hpp)."""
+        return int(_lib.load().nm_engine_lane_launches(self._h))
 
     def host_logp_calls(self) -> int:
         """Calls of the host density function so far (LogpSpec.host_callback)."""

@@ -19,10 +19,10 @@ def oracle_settings(O, settings: N.DiagNutsSettings):
 
 
 def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_per_lane=0, waves_per_chain=0,
-               lane_groups=0, grid_blocks=0, splits=()):
+               lane_groups=0, grid_blocks=0, splits=(), lane_chains=0):
     """`splits`: draw counts at which the run is cut into separate launches; the pieces are concatenated."""
     b = N.ChainBatch(settings, logp, n_chains, chain_id_offset=chain_id_offset, dims_per_lane=dims_per_lane,
-                     waves_per_chain=waves_per_chain, lane_groups=lane_groups, grid_blocks=grid_blocks)
+                     waves_per_chain=waves_per_chain, lane_groups=lane_groups, grid_blocks=grid_blocks, lane_chains=lane_chains)
     status = b.set_position(x0, raise_on_error=False)
     pos, st = None, None
     if (status == 0).all():
@@ -30,7 +30,7 @@ def run_engine(settings, logp, n_chains, x0, n_draws, chain_id_offset=0, dims_pe
         parts = [b.draw_many(hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
         pos, st = np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
     extra = dict(status=status, threads_per_chain=b.threads_per_chain(), dims_per_lane=b.dims_per_lane(),
-                 group_launches=b.group_launches())
+                 group_launches=b.group_launches(), lane_launches=b.lane_launches())
     if pos is not None:
         sd, mu = b.mass_matrix()
         extra.update(stds=sd, mean=mu, step_sizes=b.step_sizes(), x=b.positions(), gx=b.gradients(),

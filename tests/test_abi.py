@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.NmSettings) == 8 * len(_lib.NmSettings._fields_) == 8 * 49
     assert _lib.STATS_DTYPE.itemsize == 8 * 24
     assert C.sizeof(_lib.NmDrawOutputs) == 8 * 16
-    assert C.sizeof(_lib.NmEngineConfig) == 64 and C.sizeof(_lib.NmLogpSpec) == 64
+    assert C.sizeof(_lib.NmEngineConfig) == 72 and C.sizeof(_lib.NmLogpSpec) == 64
 
 
 def test_defaults_are_the_references():

@@ -37,12 +37,12 @@ CONFIGS = {
 }
 
 
-def run(key, draws, chains=0, lane_groups=0, chain_tiles=0):
+def run(key, draws, chains=0, lane_groups=0, chain_tiles=0, lane_chains=0):
     cfg = CONFIGS[key]
     logp = cfg["logp"]()
     C, D = chains or cfg["chains"], logp.dim
     s = N.DiagNutsSettings(num_chains=C, seed=20260928, num_tune=cfg["tune"], num_draws=draws)
-    b = N.ChainBatch(s, logp, C, lane_groups=lane_groups, chain_tiles=chain_tiles)
+    b = N.ChainBatch(s, logp, C, lane_groups=lane_groups, chain_tiles=chain_tiles, lane_chains=lane_chains)
     b.set_position(b.init_positions_uniform())
     t = time.time()
     _, st_w = b.draw_many(cfg["tune"], positions=False)
@@ -62,7 +62,7 @@ def run(key, draws, chains=0, lane_groups=0, chain_tiles=0):
     util = float((st["n_steps"].sum(axis=1) / (C * st["n_steps"].max(axis=1))).mean())
     out = {
         "config": cfg["name"], "chains": C, "dim": D, "draws": draws, "threads_per_chain": b.threads_per_chain(),
-        "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups, "chain_tiles": chain_tiles, "matrix_core_launches": b.tile_launches(),
+        "dims_per_lane": b.dims_per_lane(), "lane_groups": lane_groups, "lane_chains": lane_chains, "lane_launches": b.lane_launches(), "chain_tiles": chain_tiles, "matrix_core_launches": b.tile_launches(),
         "M1_steps_dims_per_s": steps * D / dt, "M2_draws_per_s_per_chain": draws / dt,
         "leapfrogs_per_s": steps / dt, "kernel_ms": c["kernel_ms"], "warmup_s": t_warm, "warmup_kernel_ms": warm_kernel_ms,
         "group_launches": b.group_launches(),
@@ -83,4 +83,5 @@ if __name__ == "__main__":
     for k in (["k1", "k3", "k4", "k5"] if which == "all" else [which]):
         run(k, draws, chains=int(sys.argv[sys.argv.index("--chains") + 1]) if "--chains" in sys.argv else 0,
             lane_groups=int(sys.argv[sys.argv.index("--lane-groups") + 1]) if "--lane-groups" in sys.argv else 0,
-            chain_tiles=int(sys.argv[sys.argv.index("--chain-tiles") + 1]) if "--chain-tiles" in sys.argv else 0)
+            chain_tiles=int(sys.argv[sys.argv.index("--chain-tiles") + 1]) if "--chain-tiles" in sys.argv else 0,
+            lane_chains=int(sys.argv[sys.argv.index("--lane-chains") + 1]) if "--lane-chains" in sys.argv else 0)

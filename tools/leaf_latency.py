@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--step", type=float, default=0.002)
     ap.add_argument("--chains", default="1,256,1024,8192")
     ap.add_argument("--lane-groups", type=int, default=0)
+    ap.add_argument("--lane-chains", type=int, default=0)
     ap.add_argument("--no-turn", action="store_true", help="check_turning = false: the tree without its U-turn tests")
     a = ap.parse_args()
     out = []
@@ -36,7 +37,7 @@ def main():
         s = N.DiagNutsSettings(num_chains=nc, seed=11, num_tune=1, num_draws=a.draws, maxdepth=a.maxdepth, check_turning=not a.no_turn)
         st = s.adapt_options.step_size_settings
         st.method, st.fixed_step_size, st.jitter = N.sampler.STEP_FIXED, a.step, None
-        b = N.ChainBatch(s, logp, nc, lane_groups=a.lane_groups)
+        b = N.ChainBatch(s, logp, nc, lane_groups=a.lane_groups, lane_chains=a.lane_chains)
         b.set_position(b.init_positions_uniform())
         b.draw_device(2)                      # warm the caches / code
         b.reset_counters()
@@ -46,7 +47,7 @@ def main():
         row = {"lib": os.path.basename(os.environ.get("NUTS_AMD_LIB", "libnuts_amd.so")), "no_turn": a.no_turn, "logp": a.logp, "dim": logp.dim, "chains": nc, "maxdepth": a.maxdepth, "draws": a.draws, "leapfrogs_per_chain": per_chain,
                "kernel_ms": c["kernel_ms"], "us_per_leapfrog_of_one_chain": c["kernel_ms"] * 1e3 / per_chain,
                "leapfrogs_per_s": c["total_leapfrogs"] / (c["kernel_ms"] * 1e-3), "threads_per_chain": b.threads_per_chain(),
-               "dims_per_lane": b.dims_per_lane(), "group_launches": b.group_launches()}
+               "dims_per_lane": b.dims_per_lane(), "group_launches": b.group_launches(), "lane_launches": b.lane_launches(), "lane_chains": a.lane_chains}
         b.close()
         print(json.dumps(row), flush=True)
         out.append(row)
