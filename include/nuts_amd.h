@@ -321,7 +321,7 @@ typedef struct nm_engine_config {
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
     uint64_t lane_chains;          /* chains with dim <= 16: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
                                     * Euclidean NUTS, maxdepth <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
-                                    * 0 = auto (from 16384 chains on), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
+                                    * 0 = auto (from 49152 chains on: the chip holds 65536 at a time), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 

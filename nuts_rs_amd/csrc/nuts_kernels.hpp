@@ -221,6 +221,7 @@ NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 * W + tid()) + (k & 1);
 // ---------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 // A wave-uniform int the compiler cannot second-guess.  A plain __builtin_amdgcn_readfirstlane is folded away when
 // the IR uniformity analysis already calls its input uniform, yet instruction selection may still have computed that

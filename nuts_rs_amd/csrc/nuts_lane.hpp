@@ -208,26 +208,34 @@ template <int NP> struct LaneDensity<DiagNormal, NP> { using type = LDiagNormal<
 template <int NP> struct LaneDensity<Funnel, NP> { using type = LFunnel<NP>; };
 template <> struct LaneDensity<EightSchools, 5> { using type = LEightSchools<5>; };
 
-// ---- the chain's generator: every lane produces the blocks of ITS stream; 16 words per lane in LDS ([word][lane]) ----
+// ---- the chain's generator: every lane produces the blocks of ITS stream into a ring of two 16-word blocks in LDS ([word][lane]) ----
+// The lanes' stream positions drift apart (rejections, tree shapes), so "refill when MY block is used up" makes nearly every call
+// of the wave pay a ChaCha block for somebody (1 - (15/16)^64 = 98 %; measured: the momentum refresh's 20 words cost 20 blocks).
+// Instead a refill is a wave event: when ANY active lane has run dry, EVERY active lane whose older block is used up produces
+// its next one.  After an event each participating lane holds more than 16 unread words, so events are at least 16 words apart.
 struct LRng {
     uint32_t key[8];
-    uint64_t pos, base;
-    uint32_t* cache;       // LDS, this lane's column: word w at cache[64 w]
+    uint64_t pos;          // next word of the stream
+    uint64_t filled;       // the blocks below this number have been produced; the ring holds blocks filled - 2 and filled - 1
+    uint32_t* ring;        // LDS, this lane's column: stream word w at ring[64 (w & 31)]
     NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* col) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) key[i] = k[i];
-        pos = p; base = p + 16; cache = col;
+        pos = p; filled = p >> 4; ring = col;
     }
     NM_DEV uint32_t next_u32() {
-        if (pos - base >= 16ull) {                      // (also when pos < base: the difference wraps)
-            base = pos & ~15ull;
-            uint32_t out[16];
-            chacha8_block(key, base >> 4, 0ull, out);
+        if (__any((pos >> 4) >= filled)) {
+            if (pos + 16 >= 16 * filled) {              // block filled - 2 is used up (or nothing is held yet): its half is free
+                uint32_t out[16];
+                chacha8_block(key, filled, 0ull, out);
+                uint32_t* half = ring + 64 * 16 * (uint32_t)(filled & 1);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) cache[64 * i] = out[i];
-            asm volatile("" ::: "memory");
+                for (int i = 0; i < 16; ++i) half[64 * i] = out[i];
+                filled += 1;
+                asm volatile("" ::: "memory");
+            }
         }
-        const uint32_t w = cache[64 * (uint32_t)(pos - base)];
+        const uint32_t w = ring[64 * (uint32_t)(pos & 31)];
         pos += 1;
         return w;
     }
@@ -282,21 +290,46 @@ struct LAccept {
     NM_DEV double mean_sym() const { return sum_sym / (double)count; }
 };
 
-// pending sub-trees, per level, in LDS: [level][word][lane]; words: log_size, cand_logp, cand_ke, (cand_idx, cand_slot)
+// pending sub-trees, per level (>= 1), in LDS: [level - 1][word][lane]; words: log_size, cand_logp, cand_ke, (cand_idx, cand_slot)
 struct LPend {
     uint64_t* base;        // this lane's column
     NM_DEV void put(int level, double log_size, const CandRef& c) {
-        uint64_t* q = base + (size_t)level * 4 * 64;
+        uint64_t* q = base + (size_t)(level - 1) * 4 * 64;
         q[0] = d2u(log_size); q[64] = d2u(c.logp); q[128] = d2u(c.ke);
         q[192] = ((uint64_t)(uint32_t)(int32_t)c.idx) | ((uint64_t)(uint32_t)c.slot << 32);
     }
     NM_DEV void get(int level, double& log_size, CandRef& c) const {
-        const uint64_t* q = base + (size_t)level * 4 * 64;
+        const uint64_t* q = base + (size_t)(level - 1) * 4 * 64;
         log_size = u2d(q[0]); c.logp = u2d(q[64]); c.ke = u2d(q[128]);
         const uint64_t w = q[192];
         c.idx = (int64_t)(int32_t)(uint32_t)w; c.slot = (int)(int32_t)(uint32_t)(w >> 32);
     }
 };
+
+// Development (-DNM_LANE_PROF=1, tools/prof_lane.py): the wave-level timeline of block 0.  A mark charges the shader-clock cycles
+// since the wave's previous mark (kept in LDS: ONE clock per wave, so serialised divergent paths are charged once each) to `slot`.
+#ifndef NM_LANE_STORE_GUARD
+#define NM_LANE_STORE_GUARD 1
+#endif
+#ifndef NM_LANE_PROF
+#define NM_LANE_PROF 0
+#endif
+#if NM_LANE_PROF
+#define NM_LP(C, slot)                                                                                                 \
+    do {                                                                                                               \
+        if (blockIdx.x == 0) {                                                                                         \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
+            const unsigned long long prev_ = *(C).lp_clock;                                                            \
+            if ((int)threadIdx.x == __ffsll((unsigned long long)__ballot(1)) - 1) {                                    \
+                (void)__hip_atomic_fetch_add(&(C).P.prof[slot], now_ - prev_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                (void)__hip_atomic_fetch_add(&(C).P.prof[16 + (slot)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+            }                                                                                                          \
+            *(C).lp_clock = now_;                                                                                      \
+        }                                                                                                              \
+    } while (0)
+#else
+#define NM_LP(C, slot) do {} while (0)
+#endif
 
 template <int NP>
 struct LPt { double z[2 * NP], v[2 * NP], g[2 * NP]; double logp, ke; int64_t idx; };
@@ -308,28 +341,60 @@ struct LCtx {
     LD dens;
     LRng rng;
     ZigTables zig;
-    double* ws;            // lane-major persistent slots, this lane's column: slot s, element e at ws[(s E + e) 64]
-    double* sv;            // lane-major tree scratch, this lane's column
+    // lane-major persistent slots / tree scratch of this WAVE, addressed as buffer descriptor (SGPRs) + one 32-bit byte offset
+    // ((slot E + e) 64 + lane) 8: with plain pointers the compiler keeps one 64-bit per-lane address per (slot, e) alive across the
+    // tree loop, hundreds of registers that it then spills and reloads in front of every access (round-3 asm: `scratch_load`
+    // before each `global_load`)
+    rsrc_t rw, rsv;
+    int l8;                // lane * 8
+#if NM_LANE_PROF
+    unsigned long long* lp_clock;
+#endif
+    NM_DEV static double bld(rsrc_t r, int off) {
+        const v2u q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return __hiloint2double((int)q.y, (int)q.x);
+    }
+    NM_DEV static void bst(rsrc_t r, int off, double a) {
+        v2u q; q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
+        __builtin_amdgcn_raw_buffer_store_b64(q, r, off, 0, 0);
+#if NM_LANE_STORE_GUARD
+        asm volatile("s_nop 1" ::"v"(q));
+#endif
+    }
+    NM_DEV double ldWe(int slot, int e) const { return bld(rw, l8 + (slot * E + e) * 512); }
+    NM_DEV void stWe(int slot, int e, double a) const { bst(rw, l8 + (slot * E + e) * 512, a); }
+    NM_DEV double ldSe(int slot, int e) const { return bld(rsv, l8 + (slot * E + e) * 512); }
+    NM_DEV void stSe(int slot, int e, double a) const { bst(rsv, l8 + (slot * E + e) * 512, a); }
     LPend pend;
+    double* stage;         // LDS, this lane's column of E doubles ([e][lane]); rows beyond dim stay zero
     ChainScalars& sc;
     double sig[E], mu[E];
+    // array_gaussian through LDS: ONE copy of the ziggurat (a loop over the elements) instead of 2 NP inlined ones.
+    // (A variant that staged the samples as uint64 in the pend table's idle rows and masked the rows beyond dim failed the parity
+    // sweep in the sampling kernel although the generated code read correctly — tools/probes/lane_case.py, case 12; not understood,
+    // so the staging area stays a zero-initialised array of its own.)
+    NM_DEV void draw_normals(double (&v)[E]) {
+        for (int d = 0; d < dim; ++d) stage[64 * d] = 1.0 * l_normal(rng, zig);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = stage[64 * e];
+    }
     int dim, md;
     __device__ LCtx(const KParams& p, ChainScalars& s) : P(p), sc(s) {}
     NM_DEV void ldW(double (&t)[E], int slot) const {
 #pragma unroll
-        for (int e = 0; e < E; ++e) t[e] = ws[(size_t)(slot * E + e) * 64];
+        for (int e = 0; e < E; ++e) t[e] = ldWe(slot, e);
     }
     NM_DEV void stW(const double (&t)[E], int slot) const {
 #pragma unroll
-        for (int e = 0; e < E; ++e) ws[(size_t)(slot * E + e) * 64] = t[e];
+        for (int e = 0; e < E; ++e) stWe(slot, e, t[e]);
     }
     NM_DEV void ldS(double (&t)[E], int slot) const {
 #pragma unroll
-        for (int e = 0; e < E; ++e) t[e] = sv[(size_t)(slot * E + e) * 64];
+        for (int e = 0; e < E; ++e) t[e] = ldSe(slot, e);
     }
     NM_DEV void stS(const double (&t)[E], int slot) const {
 #pragma unroll
-        for (int e = 0; e < E; ++e) sv[(size_t)(slot * E + e) * 64] = t[e];
+        for (int e = 0; e < E; ++e) stSe(slot, e, t[e]);
     }
     // main-tree edges (slot scheme of nuts_kernels.hpp): id 0 = the initial point (P_Z / STAGE_V / P_GZ), ids 1, 2 scratch
     NM_DEV void ld_edge(LPt<NP>& p, int id) const {
@@ -370,6 +435,42 @@ NM_DEV void l_leapfrog(LCtx<NP, LD>& C, const LPt<NP>& s, LPt<NP>& o, double eps
         p[l] = acc;
     }
     o.ke = 0.5 * pair_tree<NP>(p);
+}
+
+// The three is_turning tests a sub-tree merge makes (src/nuts.rs:143-161) against the just finished leaf O, streamed: operand
+// vectors are read from the lane-major scratch one PAIR of elements at a time (never a whole vector in registers), the six sums keep
+// their pair partials.  Test i is (A_i, B_i) in generation order: fwd: start = A, end = B; else start = B, end = A.
+//   za / va: slot of A.first (z, v);  zl / vl: slot of A.last;  zb / vb: slot of B.first, or -1: B.first = the point `bf`
+template <int NP, class LD>
+NM_DEV bool l_merge_turning(const LCtx<NP, LD>& C, int za, int zl, int zb, const LPt<NP>& bf, const LPt<NP>& o, bool fwd) {
+    constexpr int E = 2 * NP;
+    double p[6][NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double a[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int d = 2 * l + k;
+            const double az = C.ldSe(za, d), av = C.ldSe(za + 1, d);
+            const double lz = C.ldSe(zl, d), lv = C.ldSe(zl + 1, d);
+            const double bz = zb >= 0 ? C.ldSe(zb, d) : bf.z[d], bv = zb >= 0 ? C.ldSe(zb + 1, d) : bf.v[d];
+            if (fwd) {
+                turn_acc(az, av, o.z[d], o.v[d], a[0], a[1]);
+                turn_acc(lz, lv, o.z[d], o.v[d], a[2], a[3]);
+                turn_acc(az, av, bz, bv, a[4], a[5]);
+            } else {
+                turn_acc(o.z[d], o.v[d], az, av, a[0], a[1]);
+                turn_acc(o.z[d], o.v[d], lz, lv, a[2], a[3]);
+                turn_acc(bz, bv, az, av, a[4], a[5]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[i][l] = a[i];
+    }
+    bool turning = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) turning = turning | (pair_tree<NP>(p[i]) < 0.);
+    return turning;
 }
 
 // is_turning sums of one (start, end) pair of points over the chain: the two scalar_prods3 results
@@ -419,12 +520,6 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
     ChainScalars& sc = C.sc;
     const int MD = C.md;
     LPt<NP> Ep, Op;
-#pragma unroll
-    for (int d = 0; d < E; ++d) {                    // array_gaussian: the stream order is the element order
-        const double nrm = d < C.dim ? l_normal(C.rng, C.zig) : 0.0;
-        Ep.v[d] = d < C.dim ? 1.0 * nrm : 0.0;
-    }
-    C.stS(Ep.v, STAGE_V);
     if (sc.mm_id != sc.transform_id) {        // lazy re-whitening after the last mass-matrix update (diagonal.rs:210-221)
         double x[E], gx[E], isig[E];
         C.ldW(x, P_X); C.ldW(gx, P_GX); C.ldW(isig, P_ISIG);
@@ -441,6 +536,11 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
         C.ldW(Ep.z, P_Z);
         C.ldW(Ep.g, P_GZ);
     }
+    // array_gaussian: the stream order is the element order.  ONE copy of the ziggurat (a loop over the elements, through the
+    // staging slot; its rows beyond dim are zero since the allocation) instead of 2 NP inlined ones
+    // (staged in LDS: a store to the scratch in HBM followed by the next sample's table look-up serialises on the one memory counter)
+    C.draw_normals(Ep.v);
+    C.stS(Ep.v, STAGE_V);
     const double logdet = sc.logdet;
     double ke_init;
     {
@@ -457,6 +557,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
+    NM_LP(C, 0);
     int left_slot = 0, right_slot = 0;
     bool o_is_edge = false;
     int o_edge_sign = 0;
@@ -522,22 +623,30 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
             }                                                                                             \
         }
 
+        NM_LP(C, 1);
         if (depth == 0) {
             l_leapfrog(C, Ep, Op, epsilon);
+            NM_LP(C, 2);
             Op.idx = edge_idx + (int64_t)sign;
             NM_L_ACCOUNT(Ep, Op, sub_log_size)
             sub_cand = {-2, Op.logp, Op.ke, Op.idx};
+            NM_LP(C, 3);
         } else {
             if (!reuse_edge) C.ld_edge(Op, fwd ? right_slot : left_slot);
+            NM_LP(C, 1);
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 double wE = 0., wO = 0.;
                 l_leapfrog(C, Op, Ep, epsilon);
+                NM_LP(C, 2);
                 Ep.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_L_ACCOUNT(Op, Ep, wE)
+                NM_LP(C, 3);
                 if (stop != STOP_NONE) break;
                 l_leapfrog(C, Ep, Op, epsilon);
+                NM_LP(C, 2);
                 Op.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
                 NM_L_ACCOUNT(Ep, Op, wO)
+                NM_LP(C, 3);
                 if (stop != STOP_NONE) break;
                 const uint64_t nn = n + 1;
                 const int t = (int)__builtin_ctzll(~nn);
@@ -548,19 +657,10 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
                         // (A.first, B.last) (A.last, B.last) (A.first, B.first) in generation order  [src/nuts.rs:143-161]
                         const uint64_t a_first = nn + 1 - (1ull << k);
                         const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                        double az[E], av[E], lz[E], lv[E];
-                        C.ldS(az, slot_F(fa)); C.ldS(av, slot_F(fa) + 1);
-                        C.ldS(lz, slot_L(MD, k - 1)); C.ldS(lv, slot_L(MD, k - 1) + 1);
-                        bool tn = l_turning<NP>(az, av, Op.z, Op.v, fwd) | l_turning<NP>(lz, lv, Op.z, Op.v, fwd);
-                        if (k == 2) tn = tn | l_turning<NP>(az, av, Ep.z, Ep.v, fwd);
-                        else {
-                            double bz[E], bv[E];
-                            C.ldS(bz, slot_F(k - 1)); C.ldS(bv, slot_F(k - 1) + 1);
-                            tn = tn | l_turning<NP>(az, av, bz, bv, fwd);
-                        }
-                        if (tn) turn_bits |= 1u << k;
+                        if (l_merge_turning(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), Ep, Op, fwd)) turn_bits |= 1u << k;
                     }
                 }
+                NM_LP(C, 4);
                 {
                     double total;
                     const bool take = l_merge_weights(C, wE, wO, false, total, fatal);
@@ -584,6 +684,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
                     if (fatal) { stop = STOP_FATAL; break; }
                     if ((turn_bits >> k) & 1u) { stop = STOP_TURNING; break; }
                 }
+                NM_LP(C, 5);
                 if (stop != STOP_NONE) break;
                 if ((n & 3) == 0 && depth > 1) {
                     const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
@@ -596,6 +697,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
                     else if (sub_cand.slot == -3) sub_cand.slot = l_cand_to_pool(C, used, Ep.z);
                     C.pend.put(t, sub_log_size, sub_cand);
                 }
+                NM_LP(C, 6);
             }
         }
 #undef NM_L_ACCOUNT
@@ -648,7 +750,9 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
         depth += 1;
         log_size = total;
         if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
+        NM_LP(C, 7);
     }
+    NM_LP(C, 7);
     R.depth = depth;
     R.chosen = mc;
     if (fatal) return NM_CHAIN_LOGP_FATAL;
@@ -808,11 +912,8 @@ NM_DEV uint64_t l_stepsize_init(LCtx<NP, LD>& C, const double (&x)[2 * NP]) {
     const double logdet = C.sc.mm_logdet;
     double ke0;
     {
-#pragma unroll
-        for (int d = 0; d < E; ++d) {
-            const double nrm = d < C.dim ? l_normal(C.rng, C.zig) : 0.0;
-            st.v[d] = d < C.dim ? 1.0 * nrm : 0.0;
-        }
+        C.draw_normals(st.v);
+        C.stS(st.v, STAGE_V);
         double p[NP];
 #pragma unroll
         for (int l = 0; l < NP; ++l) {
@@ -967,7 +1068,9 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
     LAccept col;
     DrawResult R;
     double x[E], gx[E], z[E], gz[E];
+    NM_LP(C, 11);
     const uint64_t st = l_transition(C, col, R, z);
+    NM_LP(C, 7);
     nm_draw_stats out;
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
     if (st != NM_CHAIN_OK) {
@@ -1002,6 +1105,7 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
         sc.logp = R.chosen.logp;
     }
     const int64_t idx = R.chosen.idx;
+    NM_LP(C, 8);
     l_write_row(C, P.out_positions, row, x);
     l_write_row(C, P.out_gradient, row, gx);                     // PointStats (transformed_hamiltonian.rs:122-157)
     l_write_row(C, P.out_tpos, row, z);
@@ -1022,7 +1126,9 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
     const int64_t trans_id = sc.transform_id;
     sc.total_steps += col.count;
     const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);     // DrawGradCollector (adapt/diagonal.rs:73-83)
+    NM_LP(C, 9);
     const uint64_t ast = l_adapt<TUNE>(C, col, is_good, x, gx);
+    NM_LP(C, 10);
     if (ast != NM_CHAIN_OK) sc.status = ast;
     out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
     out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
@@ -1047,11 +1153,18 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
     sc.stats_last_id = sc.mm_id;
     if (P.out_stats) P.out_stats[t_out * P.n_chains + chain] = out;
     sc.draw_count += 1;
+    NM_LP(C, 11);
 }
 
+template <int NP>
 struct LaneShared {
-    uint32_t rng_cache[16 * 64];                          // [word][lane]
-    uint64_t pend[(LMAXDEPTH + 1) * 4 * 64];              // [level][word][lane]
+#if NM_LANE_PROF
+    unsigned long long lp_clock;
+#endif
+    uint32_t rng_ring[32 * 64];                           // [word & 31][lane]
+    uint64_t pend[(LMAXDEPTH - 1) * 4 * 64];              // [level - 1][word][lane]: levels 1 .. maxdepth + extra_doublings - 2 are used
+    double zig[(NP == 8 ? 1 : 2) * 257];                  // the ziggurat's x table and (where 4 blocks per CU still fit: 40 KB each) its f table
+    double stage[2 * NP * 64];                            // [element][lane]: the momentum refresh's normals
 };
 
 // One block = one wavefront = 64 chains; blocks stride over the chains.  TUNE = true: the adaptation compiled in (launches that
@@ -1060,28 +1173,42 @@ template <class Dens, int NP, bool TUNE>
 __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, const LaneParams LP) {
     using LD = typename LaneDensity<Dens, NP>::type;
     constexpr int E = 2 * NP;
-    __shared__ LaneShared sh;
+    __shared__ LaneShared<NP> sh;
+    for (int i = (int)threadIdx.x; i < 257; i += 64) {
+        sh.zig[i] = P.zig_x[i];
+        if (NP != 8) sh.zig[(NP != 8 ? 257 : 0) + i] = P.zig_f[i];
+    }
+    for (int i = (int)threadIdx.x; i < 2 * NP * 64; i += 64) sh.stage[i] = 0.0;
     dm_init_lds();
+    __syncthreads();
     const int l = (int)threadIdx.x;
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < P.n_chains; base += (uint64_t)gridDim.x * 64) {
         const uint64_t chain = base + (uint64_t)l;
         if (chain < P.n_chains) {
+            // (measured: leaving the scalars in their global record saves 74 registers and 350 B of scratch per lane, +10 % on deep trees,
+            // but the short trees of the 8-schools model pay for the uncoalesced accesses at every draw's end: K4 3.78e9 -> 3.47e9)
             ChainScalars sc = P.sc[chain];
             LCtx<NP, LD> C(P, sc);
             C.dim = (int)P.dim;
             C.md = (int)P.s.maxdepth;
-            C.ws = LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64 + l;
-            C.sv = LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64 + l;
+            C.rw = make_rsrc(LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64, (uint64_t)NUM_PSLOT * E * 512);
+            C.rsv = make_rsrc(LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64, (uint64_t)LP.nslots * E * 512);
+            C.l8 = l * 8;
+#if NM_LANE_PROF
+            C.lp_clock = &sh.lp_clock;
+            if (blockIdx.x == 0) sh.lp_clock = __builtin_amdgcn_s_memtime();
+#endif
             C.pend.base = sh.pend + l;
-            C.zig = {P.zig_x, P.zig_f};
+            C.zig = {sh.zig, NP != 8 ? sh.zig + 257 : P.zig_f};
+            C.stage = sh.stage + l;
             {   // the chain's persistent vectors: pvec[chain][slot][d] -> lane-major workspace
                 const double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
                 for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
 #pragma unroll
-                    for (int e = 0; e < E; ++e) C.ws[(size_t)(s_ * E + e) * 64] = pv[(size_t)s_ * P.dpad + e];
+                    for (int e = 0; e < E; ++e) C.stWe(s_, e, pv[(size_t)s_ * P.dpad + e]);
             }
             C.ldW(C.sig, P_SIG); C.ldW(C.mu, P_MU);
-            C.rng.init(sc.key, sc.rng_pos, sh.rng_cache + l);
+            C.rng.init(sc.key, sc.rng_pos, sh.rng_ring + l);
             C.dens.init(P.logp_params, C.dim);
             if (sc.status == NM_CHAIN_OK) {
                 for (uint64_t t = 0; t < P.n_draws; ++t) {
@@ -1094,7 +1221,7 @@ __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, 
                 double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
                 for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
 #pragma unroll
-                    for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ws[(size_t)(s_ * E + e) * 64];
+                    for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ldWe(s_, e);
             }
             P.sc[chain] = sc;
         }
