@@ -396,15 +396,10 @@ struct LCtx {
 #pragma unroll
         for (int e = 0; e < E; ++e) stSe(slot, e, t[e]);
     }
-    // main-tree edges (slot scheme of nuts_kernels.hpp): id 0 = the initial point (P_Z / STAGE_V / P_GZ), ids 1, 2 scratch
-    NM_DEV void ld_edge(LPt<NP>& p, int id) const {
-        if (id == 0) { ldW(p.z, P_Z); ldS(p.v, STAGE_V); ldW(p.g, P_GZ); }
-        else { ldS(p.z, EDGE0_Z + 3 * id); ldS(p.v, EDGE0_V + 3 * id); ldS(p.g, EDGE0_G + 3 * id); }
-    }
-    NM_DEV void ld_edge_zv(double (&z)[E], double (&v)[E], int id) const {
-        if (id == 0) { ldW(z, P_Z); ldS(v, STAGE_V); }
-        else { ldS(z, EDGE0_Z + 3 * id); ldS(v, EDGE0_V + 3 * id); }
-    }
+    // main-tree edges: ids 0 (the initial point), 1, 2 in the scratch slots EDGE<id>_Z / _V / _G.  (The wavefront kernels read edge 0
+    // from P_Z / STAGE_V / P_GZ; here the draw's start copies the initial point into EDGE0_* so that an edge is ONE address
+    // computation whatever its id — ids differ between the lanes.)
+    NM_DEV void ld_edge(LPt<NP>& p, int id) const { ldS(p.z, EDGE0_Z + 3 * id); ldS(p.v, EDGE0_V + 3 * id); ldS(p.g, EDGE0_G + 3 * id); }
 };
 
 template <int NP, class LD>
@@ -540,7 +535,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
     // staging slot; its rows beyond dim are zero since the allocation) instead of 2 NP inlined ones
     // (staged in LDS: a store to the scratch in HBM followed by the next sample's table look-up serialises on the one memory counter)
     C.draw_normals(Ep.v);
-    C.stS(Ep.v, STAGE_V);
+    C.stS(Ep.z, EDGE0_Z); C.stS(Ep.v, EDGE0_V); C.stS(Ep.g, EDGE0_G);
     const double logdet = sc.logdet;
     double ke_init;
     {
@@ -712,19 +707,10 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
         bool turning = false;
         if (check) {
             if (depth == 0) turning = l_turning<NP>(Ep.z, Ep.v, Op.z, Op.v, fwd);
-            else {
-                double lz[E], lv[E], rz[E], rv[E], oz[E], ov[E];
-                C.ld_edge_zv(lz, lv, left_slot);
-                C.ld_edge_zv(rz, rv, right_slot);
-                if (depth == 1) {
-#pragma unroll
-                    for (int d = 0; d < E; ++d) { oz[d] = Ep.z[d]; ov[d] = Ep.v[d]; }
-                } else { C.ldS(oz, slot_F((int)depth)); C.ldS(ov, slot_F((int)depth) + 1); }
-                // fwd: (tree.left, other.right) (tree.right, other.right) (tree.left, other.left), other.right = O;
-                // else: (other.left, tree.right) (other.right, tree.right) (other.left, tree.left), other.left = O
-                if (fwd) turning = l_turning<NP>(lz, lv, Op.z, Op.v, true) | l_turning<NP>(rz, rv, Op.z, Op.v, true) | l_turning<NP>(lz, lv, oz, ov, true);
-                else turning = l_turning<NP>(rz, rv, Op.z, Op.v, false) | l_turning<NP>(rz, rv, oz, ov, false) | l_turning<NP>(lz, lv, Op.z, Op.v, false);
-            }
+            else    // fwd: (tree.left, O) (tree.right, O) (tree.left, other.left); else (O, tree.right) (O, tree.left) (other.right, tree.right):
+                    // the merge tests' shape with A = the main tree (first = its far end), B.first = the sub-tree's first point
+                turning = l_merge_turning(C, EDGE0_Z + 3 * (fwd ? left_slot : right_slot), EDGE0_Z + 3 * (fwd ? right_slot : left_slot),
+                                          depth == 1 ? -1 : slot_F((int)depth), Ep, Op, fwd);
         }
         double total;
         const bool take = l_merge_weights(C, log_size, sub_log_size, true, total, fatal);
