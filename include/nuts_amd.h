@@ -320,8 +320,9 @@ typedef struct nm_engine_config {
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
     uint64_t lane_chains;          /* chains with dim <= 16: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
-                                    * Euclidean NUTS, maxdepth <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
-                                    * 0 = auto (from 49152 chains on: the chip holds 65536 at a time), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
+                                    * Euclidean NUTS, maxdepth + extra_doublings <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
+                                    * 0 = auto (dim <= 4 from 16384 chains on, dim <= 10 from 24576: the measured crossovers against the 8-lane kernels;
+                                    * never for dim 11 .. 16), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 

@@ -513,7 +513,7 @@ def test_lane_group_kernel_late_starter(oracle):
 
 
 def test_k4_full_size_one_gpu():
-    """BASELINE configs[3] at its full size on ONE GPU (65536 chains x dim 10, 8 chains per wavefront): every chain
+    """BASELINE configs[3] at its full size on ONE GPU (65536 chains x dim 10, one chain per lane = 64 chains per wavefront): every chain
     healthy, the pooled posterior where it belongs, chains statistically exchangeable (no chain-position artefacts of
     the grouping: the 8 lanes-groups of a wavefront see the same distribution)."""
     C_ = 65536
@@ -522,7 +522,7 @@ def test_k4_full_size_one_gpu():
     assert (b.set_position(b.init_positions_uniform()) == 0).all()
     b.draw_device(200)
     pos, st = b.draw_many(20)
-    assert b.group_launches() == 2
+    assert b.lane_launches() == 2 and b.group_launches() == 0        # 65536 chains of dim 10: one chain per lane (nuts_lane.hpp) is the default
     b.close()
     assert (st["chain_status"] == 0).all() and (st["tuning"] == 0).all()
     mu = pos[..., 0]
@@ -614,7 +614,7 @@ def test_baseline_configs_first_chains_match_oracle(oracle, config):
         pos_g, st_g = np.concatenate([a for a, _ in parts]), np.concatenate([q for _, q in parts])
     tpc = b.threads_per_chain()
     if config == "k4":
-        assert b.group_launches() > 0                    # the 65536-chain job runs 8 chains per wavefront
+        assert b.group_launches() + b.lane_launches() > 0      # the many-chain job runs 8 (nuts_group.hpp) or 64 (nuts_lane.hpp) chains per wavefront
     if config == "k5_diag":
         assert b.tile_launches() > 0                     # P x on the matrix cores, per-chain mass matrices
     b.close()
