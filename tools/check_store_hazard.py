@@ -2,13 +2,17 @@
 than 64 bits whose soffset is an SGPR, followed within `--window` instructions by a VALU write to one of its data VGPRs
 (nuts_kernels.hpp store_guard).  Prints every instance; exit code 1 if any.
 
-  python tools/check_store_hazard.py file.s [--window 2]"""
+  python tools/check_store_hazard.py file.s [--window 2] [--mubuf64]
+
+--mubuf64 (round 3): additionally require every 64-bit MUBUF store (buffer_store_dwordx2 ... offen: the lane kernel's scratch
+addressing, any soffset) to keep its data VGPRs unwritten for `--window` wait states — the guard of LCtx::bst."""
 import re
 import sys
 
 path = sys.argv[1]
 window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else 2
-store = re.compile(r"^\s*buffer_store_dwordx([34])\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(s\d+|\d+|0x[0-9a-f]+|off)")
+m64 = "--mubuf64" in sys.argv
+store = re.compile(r"^\s*buffer_store_dwordx(" + ("[234]" if m64 else "[34]") + r")\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(s\d+|\d+|0x[0-9a-f]+|off)")
 wr = re.compile(r"^\s*(v_\w+)\s+(v\[(\d+):(\d+)\]|v(\d+))")
 lines = [l.rstrip("\n") for l in open(path)]
 instr = [(i, l) for i, l in enumerate(lines) if re.match(r"^\s+[a-z]", l) and not l.strip().startswith((".", ";"))]
@@ -17,7 +21,7 @@ kernel = "?"
 names = {i: l.split(":")[0] for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)}
 for k, (i, l) in enumerate(instr):
     m = store.match(l)
-    if not m or not m.group(5).startswith("s"):
+    if not m or not (m.group(5).startswith("s") or m.group(1) == "2"):      # (LLVM covers > 64 bits with an immediate soffset; nothing covers 64 bits)
         continue
     lo, hi = int(m.group(2)), int(m.group(3))
     states = 0
