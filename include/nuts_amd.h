@@ -191,7 +191,7 @@ typedef int (*nm_host_logp_fn)(void* ctx, uint64_t chain, uint64_t dim, const do
 
 typedef struct nm_logp_spec {
     uint64_t      kind;
-    uint64_t      dim;
+    uint64_t      dim;           /* 0 is served for NM_LOGP_IID_NORMAL: every draw returns the initial point (src/nuts.rs:322-326) */
     uint64_t      n_params;
     const double* h_params;      /* host pointer, n_params doubles, copied at engine creation */
     const char*   module_path;   /* NM_LOGP_MODULE: path of the density module (.so); NULL otherwise */

@@ -1939,6 +1939,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     for (;;) {
         bool check;
         if (!in_extra) {
+            if (C.P.dim == 0) break;                             // src/nuts.rs:322-326: nothing to integrate, the draw is the initial point
             if (!(depth < maxdepth)) { R.reached_maxdepth = true; break; }
             sign = C.rng.random_bool_std() ? 1 : -1;             // src/nuts.rs:334, hamiltonian.rs:111-118
             check = (s.check_turning != 0) && !(depth < mindepth);

@@ -72,8 +72,8 @@ def test_argument_validation():
     L = N.load_library()
     h = C.c_void_p()
     s = N.DiagNutsSettings().to_c()
-    spec = N.LogpSpec.iid_normal(0).to_c()
-    assert L.nm_engine_create(C.byref(s), C.byref(spec), 4, None, C.byref(h)) == 1      # dim 0
+    spec = N.LogpSpec.funnel(0).to_c()
+    assert L.nm_engine_create(C.byref(s), C.byref(spec), 4, None, C.byref(h)) == 1      # dim 0 is served for the iid normal only
     spec = N.LogpSpec.iid_normal(10).to_c()
     assert L.nm_engine_create(C.byref(s), C.byref(spec), 0, None, C.byref(h)) == 1      # no chains
     s2 = N.DiagNutsSettings(maxdepth=40).to_c()

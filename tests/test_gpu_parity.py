@@ -532,6 +532,29 @@ def test_k4_full_size_one_gpu():
     assert 0.7 < st["mean_tree_accept"].mean() < 0.9 and st["diverging"].mean() < 0.02
 
 
+def test_dim_zero_draws_return_the_initial_point(oracle):
+    """src/nuts.rs:322-326: with dim == 0 `draw` returns the initial state and an info of depth 0 without touching the direction
+    stream; the rest of the chain (momentum refresh of no elements, collectors, the adaptation fed with a mean acceptance of 0 / 0)
+    runs as for any other dim.  Engine against oracle, every statistic; NaNs compare as NaNs (0 / 0 has the sign bit set on x86 and clear
+    on the GPU: the one place where this repo's bit-for-bit contract cannot hold, documented in DESIGN section 4)."""
+    n = 3
+    s = N.DiagNutsSettings(num_chains=n, seed=12, num_tune=25)
+    logp = N.LogpSpec.iid_normal(0, 3.0)
+    x0 = np.zeros((n, 0))
+    pos_g, st_g, ex = run_engine(s, logp, n, x0, 40, splits=(25,))
+    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n, x0, 40, gpu_threads=64)
+    assert failed == 0 and (ex["status"] == 0).all()
+    assert pos_g.shape == (40, n, 0) and steps == 0 and ex["counters"]["total_leapfrogs"] == 0
+    assert (st_g["depth"] == 0).all() and (st_g["n_steps"] == 0).all() and (st_g["maxdepth_reached"] == 0).all() and (st_g["diverging"] == 0).all()
+    for f in st_g.dtype.names:
+        a, b = st_g[f], st_o[f]
+        if a.dtype.kind == "f":
+            both_nan = (a != a) & (b != b)
+            assert (both_nan | (a.view(np.uint64) == b.view(np.uint64))).all(), f
+        else:
+            assert (a == b).all(), f
+
+
 def test_init_retry_loop_matches_reference_semantics(oracle):
     """The ChainProcess init loop (src/sampler.rs:1133-1147): a chain whose first initial point is rejected (BadInitGrad:
     an iid normal started exactly at its mean has a zero whitened gradient) takes its next init_position; the chains that
