@@ -432,12 +432,71 @@ NM_DEV void l_leapfrog(LCtx<NP, LD>& C, const LPt<NP>& s, LPt<NP>& o, double eps
     o.ke = 0.5 * pair_tree<NP>(p);
 }
 
-// The three is_turning tests a sub-tree merge makes (src/nuts.rs:143-161) against the just finished leaf O, streamed: operand
-// vectors are read from the lane-major scratch one PAIR of elements at a time (never a whole vector in registers), the six sums keep
-// their pair partials.  Test i is (A_i, B_i) in generation order: fwd: start = A, end = B; else start = B, end = A.
-//   za / va: slot of A.first (z, v);  zl / vl: slot of A.last;  zb / vb: slot of B.first, or -1: B.first = the point `bf`
+// The three is_turning tests a sub-tree merge makes (src/nuts.rs:143-161) against the just finished leaf O; also the top-level tests
+// of a finished doubling (A = the main tree).  Test i is (A_i, B_i) in generation order: fwd: start = A_i, end = B_i; else start = B_i,
+// end = A_i.   za: slot of A.first's z (its v is the next slot);  zl: A.last;  zb: B.first, or -1: B.first = the point `bf`.
+//
+// Shape (round 3, from the phase timeline: the first form waited for HBM once per ELEMENT — four loads, a branch on `fwd`, a wait):
+//  * no branch: the sums are always formed the forward way, s = (end_z + 0) - start_z with start = A.  Swapping start and end negates s
+//    exactly, so the backward test's two sums are the NEGATED forward sums with their roles exchanged (fma and the pair tree commute
+//    with negation; only the sign of an exact zero can differ, and the tests compare with zero): backward turning = any sum > 0;
+//  * all operand loads of a chunk (all of them up to 5 pairs, 4 pairs at a time for 8) are issued before the first use: one round trip.
 template <int NP, class LD>
 NM_DEV bool l_merge_turning(const LCtx<NP, LD>& C, int za, int zl, int zb, const LPt<NP>& bf, const LPt<NP>& o, bool fwd) {
+    constexpr int E = 2 * NP;
+#ifdef NM_LANE_TURN_CP
+    constexpr int CP = NM_LANE_TURN_CP < NP ? NM_LANE_TURN_CP : NP;
+#else
+    constexpr int CP = NP < 3 ? NP : 3;              // pairs per chunk (measured on K4: 3 -> 6.13e9, 2 -> 5.96e9, all -> 5.1e9 leapfrogs/s)
+#endif
+    const bool b_reg = zb < 0;
+    const int zbs = b_reg ? za : zb;                 // (a valid slot; what it returns is dropped when B.first is `bf`)
+    double p[6][NP];
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += CP) {
+        double az[2 * CP], av[2 * CP], lz[2 * CP], lv[2 * CP], bz[2 * CP], bv[2 * CP];
+#pragma unroll
+        for (int i = 0; i < 2 * CP; ++i) {
+            const int d = 2 * c0 + i;
+            if (d < E) {
+                az[i] = C.ldSe(za, d); av[i] = C.ldSe(za + 1, d);
+                lz[i] = C.ldSe(zl, d); lv[i] = C.ldSe(zl + 1, d);
+                bz[i] = C.ldSe(zbs, d); bv[i] = C.ldSe(zbs + 1, d);
+            }
+        }
+#pragma unroll
+        for (int l = c0; l < c0 + CP; ++l) {
+            if (l < NP) {
+                double a[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int d = 2 * l + k, i = d - 2 * c0;
+                    const double bzz = b_reg ? bf.z[d] : bz[i], bvv = b_reg ? bf.v[d] : bv[i];
+                    turn_acc(az[i], av[i], o.z[d], o.v[d], a[0], a[1]);
+                    turn_acc(lz[i], lv[i], o.z[d], o.v[d], a[2], a[3]);
+                    turn_acc(az[i], av[i], bzz, bvv, a[4], a[5]);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) p[j][l] = a[j];
+            }
+        }
+        if (CP < NP) __builtin_amdgcn_sched_barrier(0);      // the next chunk's loads stay behind this chunk's arithmetic: CP bounds the registers
+    }
+    bool turning = false;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double sj = pair_tree<NP>(p[j]);
+        turning = turning | (fwd ? (sj < 0.) : (sj > 0.));
+    }
+    return turning;
+}
+
+// The first form of the same tests: operands read one element at a time, a branch on `fwd` per element (one HBM round trip per
+// element).  Kept for the warm-up kernel (TUNE = true), whose register allocation the batched form upsets: measured on K4's 400
+// warm-up draws, 154 ms with this form against 205 ms with the batched one, while the sampling kernel gains 8 % from the batched form
+// (profiles/r03z_*).
+template <int NP, class LD>
+NM_DEV bool l_merge_turning_streamed(const LCtx<NP, LD>& C, int za, int zl, int zb, const LPt<NP>& bf, const LPt<NP>& o, bool fwd) {
     constexpr int E = 2 * NP;
     double p[6][NP];
 #pragma unroll
@@ -508,7 +567,7 @@ NM_DEV int l_cand_to_pool(LCtx<NP, LD>& C, uint32_t& used, const double (&z)[2 *
 }
 
 // nuts::draw for the lane's chain (reference src/nuts.rs:281-388): the port of nuts_transition / g_transition
-template <int NP, class LD>
+template <bool BATCHED_TESTS, int NP, class LD>
 NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, double (&zc)[2 * NP]) {
     constexpr int E = 2 * NP;
     const nm_settings& s = C.P.s;
@@ -652,7 +711,9 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
                         // (A.first, B.last) (A.last, B.last) (A.first, B.first) in generation order  [src/nuts.rs:143-161]
                         const uint64_t a_first = nn + 1 - (1ull << k);
                         const int fa = a_first == 0 ? (int)depth : (int)__builtin_ctzll(a_first);
-                        if (l_merge_turning(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), Ep, Op, fwd)) turn_bits |= 1u << k;
+                        const bool tk = BATCHED_TESTS ? l_merge_turning(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), Ep, Op, fwd)
+                                                      : l_merge_turning_streamed(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), Ep, Op, fwd);
+                        if (tk) turn_bits |= 1u << k;
                     }
                 }
                 NM_LP(C, 4);
@@ -709,8 +770,10 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
             if (depth == 0) turning = l_turning<NP>(Ep.z, Ep.v, Op.z, Op.v, fwd);
             else    // fwd: (tree.left, O) (tree.right, O) (tree.left, other.left); else (O, tree.right) (O, tree.left) (other.right, tree.right):
                     // the merge tests' shape with A = the main tree (first = its far end), B.first = the sub-tree's first point
-                turning = l_merge_turning(C, EDGE0_Z + 3 * (fwd ? left_slot : right_slot), EDGE0_Z + 3 * (fwd ? right_slot : left_slot),
-                                          depth == 1 ? -1 : slot_F((int)depth), Ep, Op, fwd);
+                turning = BATCHED_TESTS ? l_merge_turning(C, EDGE0_Z + 3 * (fwd ? left_slot : right_slot), EDGE0_Z + 3 * (fwd ? right_slot : left_slot),
+                                                          depth == 1 ? -1 : slot_F((int)depth), Ep, Op, fwd)
+                                        : l_merge_turning_streamed(C, EDGE0_Z + 3 * (fwd ? left_slot : right_slot), EDGE0_Z + 3 * (fwd ? right_slot : left_slot),
+                                                                   depth == 1 ? -1 : slot_F((int)depth), Ep, Op, fwd);
         }
         double total;
         const bool take = l_merge_weights(C, log_size, sub_log_size, true, total, fatal);
@@ -1055,7 +1118,7 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
     DrawResult R;
     double x[E], gx[E], z[E], gz[E];
     NM_LP(C, 11);
-    const uint64_t st = l_transition(C, col, R, z);
+    const uint64_t st = l_transition<!TUNE>(C, col, R, z);
     NM_LP(C, 7);
     nm_draw_stats out;
     out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
