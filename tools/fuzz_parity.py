@@ -29,7 +29,7 @@ def make_case(rng, scale=False):
     elif dens == "funnel":
         dim = int(rng.choice([2, 5, 11, 40, 101, 130, 300]))
     else:
-        dim = int(rng.choice([1, 2, 7, 33, 64, 65, 128, 129, 257, 511, 1024, 1500, 2048, 3000, 4096, 5000, 9000]))
+        dim = int(rng.choice([1, 2, 4, 7, 9, 10, 13, 16, 33, 64, 65, 128, 129, 257, 511, 1024, 1500, 2048, 3000, 4096, 5000, 9000]))
     sampler = rng.choice(["nuts", "exact", "micro", "mclmc"], p=[0.5, 0.15, 0.15, 0.2])
     if sampler in ("micro", "mclmc") and dim < 2:
         dim = 2
@@ -101,6 +101,7 @@ def make_case(rng, scale=False):
         eng.update(dims_per_lane=d, waves_per_chain=w)
     eng["lane_groups"] = int(rng.choice([0, 1, 2]))
     eng["chain_tiles"] = int(rng.choice([0, 1, 2]))
+    eng["lane_chains"] = int(rng.choice([0, 1, 2, 2]))            # one chain per lane (dim <= 16, nuts_lane.hpp) whenever it applies
     draws = kw["num_tune"] + int(rng.choice([10, 30]))
     desc = f"{dens} dim {dim} n {n} {sampler} tune {kw['num_tune']} draws {draws} eng {eng}"
     return s, logp, n, draws, eng, desc, transform
