@@ -24,49 +24,7 @@ hipError_t launch_lane_d(int query, bool tune, const KParams& P, const lane::Lan
     }
     return hipErrorInvalidValue;
 }
-// ---- chains into wavefronts by step size (a counting sort over 2048 logarithmic buckets; the order inside a bucket is whatever the
-// atomics make it: no result depends on it) ----
-__device__ inline int lane_sort_bucket(double step) {
-    const uint64_t b = d2u(step);
-    if ((b >> 63) || !(step == step)) return lane::LANE_SORT_BUCKETS - 1;
-    const int e = (int)(b >> 52) - (1023 - 40);                 // 2^-40 .. 2^23 in 64 octaves of 32 steps
-    if (e < 0) return 0;
-    if (e > 63) return lane::LANE_SORT_BUCKETS - 1;
-    return e * 32 + (int)((b >> 47) & 31);
-}
-__global__ void lane_sort_hist(const ChainScalars* sc, uint64_t n, uint32_t* hist) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) atomicAdd(&hist[lane_sort_bucket(sc[c].step_size)], 1u);
-}
-__global__ void lane_sort_scan(uint32_t* hist) {                // one block of 1024 threads, two buckets each: exclusive prefix sums in place
-    __shared__ uint32_t part[1024];
-    const int t = (int)threadIdx.x;
-    const uint32_t a = hist[2 * t], b = hist[2 * t + 1];
-    part[t] = a + b;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    const uint32_t before = part[t] - (a + b);
-    hist[2 * t] = before; hist[2 * t + 1] = before + a;
-}
-__global__ void lane_sort_scatter(const ChainScalars* sc, uint64_t n, uint32_t* offs, uint32_t* perm) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) perm[atomicAdd(&offs[lane_sort_bucket(sc[c].step_size)], 1u)] = (uint32_t)c;
-}
 }  // namespace
-hipError_t lane_sort_chains(const ChainScalars* sc, uint64_t n, uint32_t* hist, uint32_t* perm, hipStream_t stream) {
-    hipError_t err = hipMemsetAsync(hist, 0, lane::LANE_SORT_BUCKETS * sizeof(uint32_t), stream);
-    if (err != hipSuccess) return err;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(lane_sort_hist, dim3(blocks), dim3(256), 0, stream, sc, n, hist);
-    hipLaunchKernelGGL(lane_sort_scan, dim3(1), dim3(1024), 0, stream, hist);
-    hipLaunchKernelGGL(lane_sort_scatter, dim3(blocks), dim3(256), 0, stream, sc, n, hist, perm);
-    return hipGetLastError();
-}
 // query = 1: *occ = resident blocks (wavefronts) per CU
 hipError_t launch_lane(uint64_t logp_kind, int query, bool tune, const KParams& P, const lane::LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
     switch (logp_kind) {

@@ -34,10 +34,7 @@ struct LaneParams {
     double* lws;          // [grid][NUM_PSLOT][2 NP][64]  the chains' persistent vectors while the kernel runs
     double* lsv;          // [grid][nslots][2 NP][64]     tree scratch
     uint64_t nslots;
-    const uint32_t* perm; // chain of (block-strided) lane slot i, or nullptr: chain i.  Results do not depend on the lane a chain sits in;
-                          // the engine sorts the chains by step size before a launch so that the lanes of a wavefront build trees of similar depth
 };
-constexpr int LANE_SORT_BUCKETS = 2048;
 
 // ---- the engine's sum over a chain of <= 16 elements: balanced tree over the pair partials (see the header) ----
 template <int NP>
@@ -1235,9 +1232,8 @@ __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, 
     __syncthreads();
     const int l = (int)threadIdx.x;
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < P.n_chains; base += (uint64_t)gridDim.x * 64) {
-        const uint64_t slot_ = base + (uint64_t)l;
-        if (slot_ < P.n_chains) {
-            const uint64_t chain = LP.perm ? (uint64_t)LP.perm[slot_] : slot_;
+        const uint64_t chain = base + (uint64_t)l;
+        if (chain < P.n_chains) {
             // (measured: leaving the scalars in their global record saves 74 registers and 350 B of scratch per lane, +10 % on deep trees,
             // but the short trees of the 8-schools model pay for the uncoalesced accesses at every draw's end: K4 3.78e9 -> 3.47e9)
             ChainScalars sc = P.sc[chain];
