@@ -43,7 +43,7 @@ def _case(rng, i):
 
 def test_lane_kernel_sweep(oracle):
     rng = np.random.default_rng(177)
-    for i in range(int(os.environ.get("NM_LANE_SWEEP_CASES", "40"))):
+    for i in range(int(os.environ.get("NM_LANE_SWEEP_CASES", "120"))):
         dens, dim, kw, logp = _case(rng, i)
         n_chains = int(rng.choice([1, 3, 17, 64, 65, 100, 200]))
         s = N.DiagNutsSettings(num_chains=n_chains, **kw)
