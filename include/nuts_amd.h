@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 13
+#define NM_ABI_VERSION 14
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -416,6 +416,15 @@ nm_status nm_engine_set_lowrank_estimator(nm_engine* e, nm_lowrank_estimator_fn 
 int nm_lowrank_compute_update(void* unused, uint64_t dim, uint64_t n_draws, const double* draws, const double* grads,
                               double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
                               double* vals, double* vecs, double* mu_low_rank);
+/* Test hooks into the built-in estimator (host only): the two routines the reference's own unit tests exercise
+ * (`spd_mean`, `estimate_mass_matrix`: src/transform/adapt/low_rank.rs:228-290, tests :354-407), so that its vectors run
+ * against THIS implementation and not only against the oracle's LAPACK restatement.  Matrices are column-major.
+ * spd_mean: n x n inputs -> out n x n.  estimate_mass_matrix: draws / grads are (rows x n_draws) -> vals[rows] ascending,
+ * vecs rows x rows (one eigenvector per column).  force_base != 0: the baseline-ISA build even where AVX2 is available.
+ * Return 0 (Some) or 1 (None). */
+int nm_lowrank_test_spd_mean(uint64_t n, const double* cov_draws, const double* cov_grads, double* out, uint64_t force_base);
+int nm_lowrank_test_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const double* draws, const double* grads, double gamma,
+                                         double* vals, double* vecs, uint64_t force_base);
 
 /* `LowRankMassMatrix::update(stds, mean, vals, vecs, mean_low_rank)` (src/transform/low_rank.rs:155-186) for every chain,
  * from the host: the transformation version moves on and the current points are re-whitened lazily at their next

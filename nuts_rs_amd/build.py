@@ -19,10 +19,9 @@ UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lr_mvn_prec.h
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
          "kern_lane.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
          "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip", "pooled_reduce.hip",
-         "lowrank_host.cpp", "lowrank_host.cpp@avx2", "lowrank_dispatch.cpp"]
-# "<file>@<variant>": the same source compiled a second time (lowrank_host.cpp: plain x86-64 and -mavx2 -mfma; a run-time dispatcher picks)
-VARIANT_FLAGS = {"": ["-DNM_LR_IMPL_NAME=nm_lowrank_compute_update_base"],
-                 "avx2": ["-mavx2", "-mfma", "-DNM_LR_IMPL_NAME=nm_lowrank_compute_update_avx2"]}
+         "lowrank_host.cpp"]
+# (lowrank_host.cpp holds both ISA builds of the host estimator in ONE translation unit: per-function target attributes, see there)
+VARIANT_FLAGS = {"": []}
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)

@@ -70,6 +70,10 @@ __host__ __device__ inline int num_sslots(int maxdepth) { return S_DYN + 4 * (ma
 // a doubling lives in slot n mod NM_RING), behind the slots above.  The host adds NM_RING to nsslot for these tilings.
 constexpr int NM_RING = 64;
 __host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(maxdepth) + i; }
+// The depth every slot family (F, L, candidate pool, pend tables) is laid out for.  A tree that turned at depth d <= maxdepth is extended by
+// `extra_doublings` further doublings (src/nuts.rs:350-371), so sub-trees of level up to maxdepth + extra_doublings - 1 are built; with the
+// layout of `maxdepth` alone slot_L(MD, MD + 1) is slot_C(MD, 0) and the candidate pool overflows.
+__host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)(s.maxdepth + s.extra_doublings); }
 #ifndef NM_BATCH_MERGES
 #define NM_BATCH_MERGES 1        // 0: every merge evaluated where the reference evaluates it (tuning / bisecting builds)
 #endif
@@ -738,7 +742,7 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.goff = C.red.cl.member * (int)P.cl_slice;
     C.dim = (int)(P.dim - (uint64_t)C.goff < P.cl_slice ? P.dim - (uint64_t)C.goff : P.cl_slice);
 #endif
-    C.maxdepth_cfg = (int)P.s.maxdepth;
+    C.maxdepth_cfg = layout_depth(P.s);      // slots are laid out for the deepest tree a draw can grow: maxdepth + extra_doublings
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.slot_bytes = (int)(P.dpad * 8);

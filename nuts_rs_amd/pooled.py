@@ -83,6 +83,11 @@ def _merge_payloads(payloads, d):
     n, mean, m2 = payloads[0][0], payloads[0][1:1 + d], payloads[0][1 + d:]
     for p in payloads[1:]:
         nb, mb, sb = p[0], p[1:1 + d], p[1 + d:]
+        if float(nb) == 0.0:            # a rank whose chains kept no draw in this window (all stopped / diverging): nothing to merge,
+            continue                    # and 0 / 0 below would poison the mean (the device merge skips empty partials too)
+        if float(n) == 0.0:
+            n, mean, m2 = nb, mb, sb
+            continue
         tot = n + nb
         delta = mb - mean
         mean = mean + delta * (nb / tot)
@@ -121,8 +126,11 @@ def pooled_warmup(batch, num_tune, dist=None, windows=None, collective_device=No
         with torch.cuda.stream(side):
             parts = [g.to(dev) for g in gathered]
             d2 = 2 * dim + 1
-            _, mx, vx = _merge_payloads([g[:d2] for g in parts], dim)
+            cnt, mx, vx = _merge_payloads([g[:d2] for g in parts], dim)
             _, mg, vg = _merge_payloads([g[d2:] for g in parts], dim)
+            if float(cnt) < 3.0:        # fewer than three pooled draws: no estimate (a RunningVariance asserts count > 1,
+                side.synchronize()      # adapt/diagonal.rs:48; with 2 the ratio of variances is noise) — keep the current transformation
+                return
             sigma = torch.sqrt(torch.sqrt(vx / vg))
             ok = torch.isfinite(sigma) & (sigma > 0)
             sigma = torch.where(ok, torch.clamp(sigma, 1e-10, 1e10), torch.ones_like(sigma))

@@ -235,6 +235,105 @@ def test_builtin_estimator_matches_lapack_restatement(oracle):
         assert np.allclose(mu, ref[4], atol=1e-8)
 
 
+@pytest.mark.parametrize("dim,tune", [(64, 300), (128, 220)])
+def test_builtin_estimator_whole_run_vs_literal_reference_algorithm(oracle, dim, tune):
+    """A whole LowRankNutsSettings warm-up with the engine's BUILT-IN estimator (what a default run executes) against the oracle
+    with the LITERAL reference estimator (oracle/lowrank.py rank_revealing=False = adapt/low_rank.rs:73-290 on LAPACK).
+    The early windows have fewer draws than dims (10, 10, ..., 30, 50 draws at dim 64 / 128: rank deficient).  Stated tolerances
+    (tests/test_lowrank_estimator_builtin.py):
+      * up to and including the draw of the first update both sides see identical inputs: draws bit-exact;
+      * EVERY window the engine hands to its estimator: the built-in's answer against the literal algorithm on the same
+        window: sigma / mean 1e-13, the applied operator 1e-6 on full-rank windows and 0.25 (and within 2 x the LAPACK forms' own
+        spread) on rank-deficient ones, signal eigenvalues (> 2 x cutoff) equal in number and within 5 %;
+      * after the first update the two runs are different chaotic trajectories of the same sampler: the adapted step size,
+        tree sizes and the quality of the final transformation agree statistically."""
+    from oracle import lowrank as LR
+    import test_lowrank_estimator_builtin as T
+    L = _lib.load()
+    rng = np.random.default_rng(dim)
+    n = 4
+    prec, sigma = correlated_precision(rng, dim, max(3, dim // 20))
+    logp = N.LogpSpec.mvn_precision(prec)
+    s = lowrank_settings(num_chains=n, seed=13, num_tune=tune)
+    windows = []
+
+    def recording_builtin(ctx, ndim, ndraws, draws, grads, gamma, cutoff, stds, mean, n_eig, vals, vecs, mu):
+        d = np.ctypeslib.as_array(draws, shape=(ndraws, ndim)).copy()
+        g = np.ctypeslib.as_array(grads, shape=(ndraws, ndim)).copy()
+        rc = L.nm_lowrank_compute_update(None, ndim, ndraws, C.cast(draws, C.c_void_p), C.cast(grads, C.c_void_p), gamma, cutoff,
+                                         C.cast(stds, C.c_void_p), C.cast(mean, C.c_void_p), n_eig, C.cast(vals, C.c_void_p),
+                                         C.cast(vecs, C.c_void_p), C.cast(mu, C.c_void_p))
+        k = int(n_eig[0]) if rc == 0 else 0
+        res = None
+        if rc == 0:
+            res = (np.ctypeslib.as_array(stds, shape=(ndim,)).copy(), np.ctypeslib.as_array(mean, shape=(ndim,)).copy(),
+                   np.ctypeslib.as_array(vals, shape=(max(k, 1),))[:k].copy(), np.ctypeslib.as_array(vecs, shape=(max(k, 1), ndim))[:k].T.copy(),
+                   np.ctypeslib.as_array(mu, shape=(ndim,)).copy())
+        windows.append((d.T, g.T, gamma, cutoff, res))
+        return rc
+
+    cb_e = _lib.LOWRANK_ESTIMATOR_FN(recording_builtin)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_lowrank_estimator(cb_e, n_threads=1)
+    pos, st = b.draw_many(tune + 60)
+    tpc = b.threads_per_chain()
+    stds_e, _ = b.mass_matrix()
+    n_eig_e, vals_sqrt_e, vecs_e, _ = b.lowrank()
+    b.close()
+    cb_o = LR.estimator_callback(None, rank_revealing=False)
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc), n, x0, tune + 60, estimator=cb_o)
+    assert failed == 0
+    # (1) identical until the first update has been applied
+    upd = (st["transformation_update_id"][1:] >= 0).any(axis=1)     # (row 0 always reports the initial version: compared with -1)
+    first = 1 + int(np.argmax(upd))                                  # the first draw whose adapt() replaced the transformation
+    assert upd.any() and first >= 5
+    assert_bit_exact(pos[:first], st[:first], pos_o[:first], st_o[:first])
+    assert (pos[first].view(np.uint64) == pos_o[first].view(np.uint64)).all()      # (that draw itself still ran under the old one)
+    # (2) every window of the run
+    assert len(windows) >= n * 6
+    n_def = n_full = 0
+    worst = dict(full=0.0, deficient=0.0)
+    for d, g, gamma, cutoff, bi in windows:
+        lit = LR.compute_update(d, g, gamma, cutoff, rank_revealing=False)
+        assert (bi is None) == (lit is None)
+        if bi is None:
+            continue
+        deficient = d.shape[1] - 1 < dim
+        assert np.max(np.abs(bi[0] - lit[0]) / lit[0]) <= T.TOL_DIAG and np.max(np.abs(bi[1] - lit[1])) <= T.TOL_DIAG * (1.0 + np.abs(lit[1]).max())
+        a, bb = T.op_of(bi[2], bi[3]), T.op_of(lit[2], lit[3])
+        d_bi = np.linalg.norm(a - bb, 2) / np.linalg.norm(bb, 2)
+        if deficient:
+            n_def += 1
+            rr = LR.compute_update(d, g, gamma, cutoff, rank_revealing=True)
+            d_rr = np.linalg.norm(T.op_of(rr[2], rr[3]) - bb, 2) / np.linalg.norm(bb, 2)
+            assert d_bi <= T.TOL_RANK_DEFICIENT and d_bi <= 2.0 * max(d_rr, 0.02), (d.shape, d_bi, d_rr)
+            sig_bi, sig_lit = np.sort(bi[2][bi[2] > 4.0]), np.sort(lit[2][lit[2] > 4.0])
+            if not (np.abs(np.concatenate([bi[2], lit[2]]) - 4.0) < 4.0 * T.TOL_SIGNAL_EIG).any():
+                assert len(sig_bi) == len(sig_lit) and np.allclose(sig_bi, sig_lit, rtol=T.TOL_SIGNAL_EIG)
+            worst["deficient"] = max(worst["deficient"], d_bi)
+        else:
+            n_full += 1
+            assert d_bi <= T.TOL_FULL_RANK, (d.shape, d_bi)
+            worst["full"] = max(worst["full"], d_bi)
+    assert n_def >= n * 3 and (n_full >= n or dim > 64)
+    print(f"dim {dim}: {n_def} rank-deficient windows (worst operator departure {worst['deficient']:.3g}), {n_full} full-rank ({worst['full']:.3g})")
+    # (3) statistically the same sampler afterwards
+    tail, tail_o = st[tune:], st_o[tune:]
+    assert abs(np.log(tail["step_size"].mean() / tail_o["step_size"].mean())) < np.log(1.35)
+    assert abs(np.log(tail["n_steps"].mean() / tail_o["n_steps"].mean())) < np.log(1.5)
+    assert tail["diverging"].mean() < 0.02 and (st["chain_status"] == 0).all()
+    cs = []
+    for c in range(n):                       # the adapted space's conditioning of the target's covariance
+        k = int(n_eig_e[c])
+        a = np.diag(stds_e[c]) @ (np.eye(dim) + vecs_e[c, :k].T @ np.diag(vals_sqrt_e[c, :k] - 1.0) @ vecs_e[c, :k])
+        ai = np.linalg.inv(a)
+        cs.append(np.linalg.cond(ai @ sigma @ ai.T))
+    d0 = np.sqrt(np.diag(sigma))
+    assert np.median(cs) < 0.3 * np.linalg.cond(sigma / np.outer(d0, d0))
+
+
 def test_builtin_estimator_end_to_end(oracle):
     """LowRankNutsSettings with the engine's own estimator on a correlated normal: the adapted transformation shortens the
     trajectories compared with DiagNutsSettings, and the draws have the target's covariance."""
