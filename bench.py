@@ -23,6 +23,12 @@
             `frac` = `frac_moved` = achieved / 8 TB/s <= 1.  The 64 B/(step x dim) algorithmic model of SURVEY §8(d) is
             reported beside it (`frac_sec8d_model`, `algorithmic`): it is NOT a bound for this design, whose live state is
             register / LDS resident (the model's rate exceeds the HBM peak).
+  other_configs: BASELINE.json's other GPU configurations — K3 (funnel dim 101 x 8192 chains), K4 (8 schools dim 10: the whole
+            65536-chain job on one GPU, and one GPU's shard of 8192 chains) and K5 (full-Sigma normal dim 256 x 4096 chains through
+            the shared rank-256 transformation, the matrix-core kernel) — each measured by this script in the same run (one untimed
+            warm-up, one timed launch of --other-steps recorded draws, HIP-event kernel time) with its own roofline from live
+            rocprofv3 --pmc passes: HBM (FETCH_SIZE / WRITE_SIZE) for K3 / K4, f64 MFMA (SQ_VALU_MFMA_BUSY_CYCLES) for K5.
+            The headline `value` stays K2.  --other-configs none skips them.
 The state is resident in HBM before the timed region (positions are uploaded in set_position; draws stay on the
 device), so `value` contains no PCIe traffic.
 """
@@ -73,6 +79,10 @@ def parse():
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 --pmc
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     p.add_argument("--master-port", type=int, default=29511)
+    p.add_argument("--other-configs", default="k3,k4_65536,k4_8192,k5", help="comma list of OTHER_CONFIGS keys reported in `other_configs` (rank 0, N = 1); none = skip")
+    p.add_argument("--other-steps", type=int, default=100, help="timed draws of each other config")
+    p.add_argument("--other-budget", type=float, default=150.0, help="seconds the other configs (runs + counter passes) may take in all")
+    p.add_argument("--config", default="k2", help=argparse.SUPPRESS)            # with --pmc-child: which workload this child runs
     return p.parse_args()
 
 
@@ -104,24 +114,28 @@ def read_counters(db, kernel=KERNEL):
     return res
 
 
-def pmc_live(args):
-    """Re-run this workload (tune, warm-up, ONE recorded K-step launch) under rocprofv3 --pmc, one pass per counter set
-    (FETCH_SIZE and WRITE_SIZE do not fit one pass; tracing options are never combined with --pmc)."""
+def pmc_live(args, config="k2", passes=None, kernel=KERNEL, steps=None, deadline=None):
+    """Re-run a workload (tune, warm-up, ONE recorded K-step launch) under rocprofv3 --pmc, one pass per counter set
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; tracing options are never combined with --pmc).  `config`: "k2" (the
+    headline workload, this script's own arguments) or a key of OTHER_CONFIGS; counters are those of the LAST dispatch whose
+    name contains `kernel` (the timed launch)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     out = {}
-    deadline = time.time() + args.pmc_timeout
+    deadline = deadline or (time.time() + args.pmc_timeout)
     tmp = tempfile.mkdtemp(prefix="nm_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--gpus", "1", "--steps", str(args.steps),
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config, "--gpus", "1", "--steps", str(steps or args.steps),
              "--warmup", str(args.warmup), "--chains", str(args.chains), "--dim", str(args.dim),
              "--num-tune", str(args.num_tune), "--seed", str(args.seed), "--dims-per-lane", str(args.dims_per_lane)]
     if args.no_record:
         child.append("--no-record")
-    for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_COUNTERS)):
+    if passes is None:
+        passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", SQ_COUNTERS))
+    for tag, counters in passes:
         left = deadline - time.time()
         if left < 10:
             out.setdefault("skipped", []).append(tag)
@@ -137,14 +151,17 @@ def pmc_live(args):
             out.setdefault("skipped", []).append(f"{tag} (rc {r.returncode})")
             continue
         try:
-            out.update(read_counters(dbs[0]))
+            out.update(read_counters(dbs[0], kernel))
             for line in r.stdout.decode(errors="replace").splitlines():
                 if line.startswith("{") and '"pmc_child"' in line:
                     out.setdefault("child", {})[tag] = json.loads(line)
         except Exception as e:  # noqa: BLE001
             out.setdefault("skipped", []).append(f"{tag} ({e})")
+        for f in dbs:
+            os.remove(f)
     shutil.rmtree(tmp, ignore_errors=True)
-    if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+    need = [c for _, cs in passes for c in cs if c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES")]
+    if any(c not in out for c in need):
         return None, f"counter passes incomplete: {out.get('skipped')}"
     return out, None
 
@@ -233,6 +250,161 @@ def cpu_baseline(args, cores):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's other GPU configurations: measured by this script, reported inside the one JSON line
+# ------------------------------------------------------------------------------------------------------------------
+F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X dense f64 matrix peak (MI355X_MICROARCH.md): 16 FMA / cycle / SIMD x 1024 SIMDs x 2.4 GHz
+SHADER_CLOCK_HZ = 2.4e9
+N_SIMDS = 1024
+
+
+def _k5_target(dim, seed=55, rank=8, scale=100.0):
+    rng = np.random.default_rng(seed)
+    u = np.linalg.qr(rng.normal(size=(dim, rank)))[0]
+    sigma = np.eye(dim) + u @ np.diag(rng.uniform(5.0, scale, rank)) @ u.T
+    sc = np.exp(rng.normal(0, 0.5, dim))
+    sigma = np.diag(sc) @ sigma @ np.diag(sc)
+    prec = np.linalg.inv(sigma)
+    return (prec + prec.T) / 2, sigma
+
+
+OTHER_CONFIGS = {
+    "k3": dict(name="K3: Neal's funnel dim 101 x 8192 chains, DiagNutsSettings defaults, num_tune 400", chains=8192, tune=400, bound="hbm",
+               kernel="nuts_draw_kernel"),
+    "k4_65536": dict(name="K4: 8 schools non-centered dim 10, all 65536 chains of the job on ONE GPU, DiagNutsSettings defaults, num_tune 400",
+                     chains=65536, tune=400, bound="hbm", kernel="nuts_lane"),
+    "k4_8192": dict(name="K4: 8 schools non-centered dim 10, one GPU's shard (8192 chains) of the 65536-chain job, num_tune 400",
+                    chains=8192, tune=400, bound="hbm", kernel="nuts_"),
+    "k5": dict(name="K5: N(0, Sigma) full Sigma dim 256 x 4096 chains through the exact dense preconditioner = LowRankMassMatrix of rank 256 shared "
+                    "by all chains (frozen), step size adapted over 100 draws", chains=4096, tune=100, bound="mfma", kernel="nuts_tile"),
+}
+
+
+def run_other_config(key, seed, steps, warmup, record=True):
+    """One of BASELINE's other configurations on the current GPU: untimed set-up + warm-up, then ONE timed launch of `steps` recorded draws."""
+    import torch
+    import nuts_rs_amd as N
+    cfg = OTHER_CONFIGS[key]
+    C_ = cfg["chains"]
+    extra = {}
+    if key == "k3":
+        logp = N.LogpSpec.funnel(101)
+        s = N.DiagNutsSettings(num_chains=C_, seed=seed, num_tune=cfg["tune"], num_draws=steps + warmup)
+        b = N.ChainBatch(s, logp, C_)
+    elif key.startswith("k4"):
+        logp = N.LogpSpec.eight_schools()
+        s = N.DiagNutsSettings(num_chains=C_, seed=seed, num_tune=cfg["tune"], num_draws=steps + warmup)
+        b = N.ChainBatch(s, logp, C_)
+    else:
+        D = 256
+        prec, sigma = _k5_target(D)
+        w, u = np.linalg.eigh(sigma)
+        logp = N.LogpSpec.mvn_precision(prec)
+        s = N.LowRankNutsSettings(num_chains=C_, seed=seed, num_tune=cfg["tune"], num_draws=steps + warmup, freeze_transform=True)
+        b = N.ChainBatch(s, logp, C_, lowrank_max_rank=D)
+        extra["transform"] = (np.ones(D), np.zeros(D), w, np.ascontiguousarray(u.T), np.zeros(D))
+    D = logp.dim
+    assert (b.set_position(b.init_positions_uniform()) == 0).all()
+    if "transform" in extra:
+        b.set_transform(*extra["transform"])
+    t0 = time.perf_counter()
+    b.draw_device(cfg["tune"])
+    t_tune = time.perf_counter() - t0
+    c_tune = b.counters()
+    if warmup:
+        b.draw_device(warmup)
+    d_pos = torch.empty((steps, C_, D), dtype=torch.float64, device="cuda") if record else None
+    d_st = torch.zeros((steps, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    b.reset_counters()
+    t0 = time.perf_counter()
+    b.draw_device(steps, d_pos.data_ptr() if record else 0, d_st.data_ptr(), sync=False)
+    b.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = b.counters()
+    st = np.frombuffer(d_st.cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(steps, C_)
+    n_steps = int(st["n_steps"].sum())
+    ok = n_steps == c["total_leapfrogs"] and bool((st["draw"][-1] == cfg["tune"] + warmup + steps - 1).all()) and \
+        (not record or bool(torch.isfinite(d_pos[-1]).all().item()))
+    res = {"workload": cfg["name"], "chains": C_, "dim": D, "steps": steps, "value": n_steps * D / dt, "unit": "leapfrog-steps*dims/s",
+           "leapfrogs_per_s": n_steps / dt, "ms_per_step": dt / steps * 1e3, "draws_per_sec_per_chain": steps / dt,
+           "leapfrogs_per_draw": n_steps / (steps * C_), "kernel_ms_per_launch": c["kernel_ms"], "total_leapfrogs": n_steps,
+           "divergence_rate": float(st["diverging"].mean()), "mean_depth": float(st["depth"].mean()),
+           "warmup": {"draws": cfg["tune"], "seconds": t_tune, "kernel_ms": c_tune["kernel_ms"],
+                      "leapfrogs_per_s": c_tune["total_leapfrogs"] / t_tune if t_tune > 0 else None},
+           "draws_recorded": record, "recorded_buffers_verified": ok,
+           "kernels": {"lane_launches": b.lane_launches(), "group_launches": b.group_launches(), "matrix_core_launches": b.tile_launches()}}
+    b.close()
+    return res
+
+
+def other_config_roofline(args, key, res, deadline):
+    """The roofline object of one other config, from live counter passes of the same workload (separate --pmc runs)."""
+    cfg = OTHER_CONFIGS[key]
+    kern_s = res["kernel_ms_per_launch"] * 1e-3
+    n_steps, D = res["total_leapfrogs"], res["dim"]
+    cal = calibration()
+    if cfg["bound"] == "hbm":
+        algo = n_steps * D * ALGO_BYTES_PER_STEP_DIM
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": cfg["kernel"],
+                "kernel_ms_per_launch": res["kernel_ms_per_launch"],
+                "algorithmic": {"bytes_per_step_dim": ALGO_BYTES_PER_STEP_DIM, "bytes_per_launch": algo, "rate_GBps": algo / kern_s / 1e9,
+                                "frac_sec8d_model": algo / kern_s / 1e9 / HBM_PEAK_GBS}}
+        if args.pmc == "live":
+            got, why = pmc_live(args, key, (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])), cfg["kernel"], res["steps"], deadline)
+            if got:
+                child_steps = (got.get("child", {}).get("fetch") or {}).get("steps") or n_steps
+                fetch_b = got["FETCH_SIZE"] * 1024.0 * cal["fetch_factor"]
+                write_b = got["WRITE_SIZE"] * 1024.0 * cal["write_factor"]
+                traffic = (fetch_b + write_b) / child_steps * n_steps
+                roof.update(traffic=traffic, achieved=traffic / kern_s / 1e9, frac=traffic / kern_s / 1e9 / HBM_PEAK_GBS,
+                            traffic_source="live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload",
+                            hbm_bytes_per_leapfrog=(fetch_b + write_b) / child_steps, moved_over_algorithmic=traffic / algo)
+            else:
+                roof["pmc_failed"] = why
+        return roof
+    flop = 2.0 * (4 * D * D + D * D)        # per chain-leapfrog: U'v and U s for x and for g_z (rank = dim), P x for the density
+    useful = n_steps * flop / kern_s / 1e12
+    roof = {"bound": "mfma", "achieved": useful, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": useful / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": cfg["kernel"], "kernel_ms_per_launch": res["kernel_ms_per_launch"],
+            "flop_per_chain_leapfrog": flop, "note": "achieved = USEFUL f64 flop of the five dense products per chain-leapfrog / launch time; "
+            "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.4 GHz) also counts the products of idle columns"}
+    if args.pmc == "live":
+        got, why = pmc_live(args, key, (("mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE"]),), cfg["kernel"], res["steps"], deadline)
+        if got:
+            child = (got.get("child", {}).get("mfma") or {})
+            ck = (child.get("kernel_ms") or res["kernel_ms_per_launch"]) * 1e-3
+            roof["mfma_busy"] = got["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMDS * ck * SHADER_CLOCK_HZ)
+            if got.get("GRBM_GUI_ACTIVE"):
+                roof["mfma_busy_of_gui_active"] = got["SQ_VALU_MFMA_BUSY_CYCLES"] / (got["GRBM_GUI_ACTIVE"] / 8.0 * N_SIMDS)
+            if got.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
+                roof["mfma_issued_TFLOPs"] = got["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / ck / 1e12
+        else:
+            roof["pmc_failed"] = why
+    return roof
+
+
+def other_configs(args):
+    keys = [k for k in args.other_configs.split(",") if k and k != "none"]
+    out, deadline = [], time.time() + args.other_budget
+    for k in keys:
+        if k not in OTHER_CONFIGS:
+            out.append({"workload": k, "error": "unknown config"})
+            continue
+        if time.time() > deadline - 15:
+            out.append({"workload": OTHER_CONFIGS[k]["name"], "skipped": "time budget of --other-budget spent"})
+            continue
+        try:
+            res = run_other_config(k, args.seed, args.other_steps, args.warmup, record=not args.no_record)
+            res["roofline"] = other_config_roofline(args, k, res, deadline)
+            res["key"] = k
+            out.append(res)
+        except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
+            out.append({"workload": OTHER_CONFIGS[k]["name"], "key": k, "error": f"{type(e).__name__}: {e}"})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
     import torch
@@ -284,6 +456,11 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.pmc_child and args.config != "k2":       # a counter pass over one of the other configs
+        r = run_other_config(args.config, args.seed, args.steps, args.warmup, record=not args.no_record)
+        print(json.dumps({"pmc_child": True, "config": args.config, "steps": r["total_leapfrogs"], "kernel_ms": r["kernel_ms_per_launch"]}))
+        return
 
     C_, D = args.chains, args.dim
     settings = N.DiagNutsSettings(num_chains=C_ * world, seed=args.seed, num_tune=args.num_tune,
@@ -427,6 +604,12 @@ def main():
                                                  "stay in registers / LDS, HBM carries the tree's end points instead"},
                          "pmc": pmc_detail},
         }
+        if world == 1 and args.other_configs != "none":
+            batch.close()                                    # (K2's 1.5 GB of chain state and the record buffers go first)
+            batch = None
+            del d_pos, d_st
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(args)
         if world == 1 and not args.no_cpu_baseline:
             cores, cores_note = usable_cores()
             try:
@@ -436,7 +619,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "leapfrog-steps*dims/s", "cores": cores, "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out))
-    batch.close()
+    if batch is not None:
+        batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

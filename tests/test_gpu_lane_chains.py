@@ -64,6 +64,25 @@ def test_lane_kernel_sweep(oracle):
             raise AssertionError(f"case {i} ({dens}, dim {dim}, {n_chains} chains, grid {grid}, {kw}): {e}") from None
 
 
+@pytest.mark.parametrize("maxdepth,extra", [(3, 4), (2, 3), (5, 5), (1, 6), (7, 3)])
+def test_extra_doublings_beyond_two_lane_and_group_kernels(oracle, maxdepth, extra):
+    """extra_doublings >= 3 (src/nuts.rs:350-371): sub-trees of level > maxdepth are built, so every slot family must be laid
+    out for maxdepth + extra_doublings levels (with the layout of maxdepth alone the L[] slots ran into the candidate
+    pool and draws were silently wrong).  One chain per lane and 8 lanes per chain, against the oracle."""
+    n, dim = 70, 9
+    s = N.DiagNutsSettings(num_chains=n, seed=500 + 10 * maxdepth + extra, num_tune=50, maxdepth=maxdepth, extra_doublings=extra)
+    logp = N.LogpSpec.diag_normal(np.exp(np.random.default_rng(maxdepth).uniform(-2, 2, dim)))
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n, x0, 90, gpu_threads=64)
+    assert failed == 0
+    assert st_o["depth"].max() > maxdepth                    # the extra doublings really extend trees beyond maxdepth
+    for kw, field in ((dict(lane_chains=2), "lane_launches"), (dict(lane_chains=1, lane_groups=2), "group_launches")):
+        pos_g, st_g, ex = run_engine(s, logp, n, x0, 90, splits=(50,), **kw)
+        assert ex[field] == 2, (kw, ex)
+        assert_bit_exact(pos_g, st_g, pos_o, st_o)
+        assert ex["counters"]["total_leapfrogs"] == steps
+
+
 def test_lane_kernel_k4_many_chains_equals_the_other_kernels(oracle):
     """K4's shape at scale: 20000 chains of the 8-schools model.  The lane kernel, the 8-lanes-per-chain kernel and the wave kernel
     give the same draws (whole run, every chain); sampled chains against the oracle; the state the host reads back agrees too."""
