@@ -440,6 +440,12 @@ nm_status nm_engine_get_lowrank(nm_engine* e, uint64_t* h_n_eig, double* h_vals_
 uint64_t  nm_engine_lowrank_max_rank(const nm_engine* e);
 /* draw launches served by the 16-chains-per-block matrix-core kernel so far (nm_engine_config.chain_tiles) */
 uint64_t  nm_engine_tile_launches(const nm_engine* e);
+/* ... of which by its LOCKSTEP form (nuts_lockstep.hpp: the 16 chains of a block advance together, draws not synchronised) */
+uint64_t  nm_engine_lockstep_launches(const nm_engine* e);
+/* The order in which this engine's draws sum over dim, for callers that compare with the CPU oracle bit for bit: 0 = the wave
+ * kernels' (threads_per_chain), 1 = the matrix-core tile kernel (the same, low-rank products as sequential dots), 2 = the lockstep
+ * kernel's stripe order from nm_engine_set_transform on.  Fixed when the shared transformation is set. */
+uint64_t  nm_engine_reduce_order(const nm_engine* e);
 /* calls of the host density function so far (NM_LOGP_HOST_CALLBACK) */
 uint64_t  nm_engine_host_logp_calls(const nm_engine* e);
 

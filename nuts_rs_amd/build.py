@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnuts_amd.so")
 # (the slowest translation units first: the build is as long as its longest chain of jobs on the available cores)
-UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
+UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lockstep.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
          "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_host_cb.hip",
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
          "kern_lane.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",

@@ -7,8 +7,7 @@ namespace nm {
 // the same block shape for chains with their own (adapting) diagonal transformation: one product per density evaluation
 hipError_t launch_tile_mvn_diag(int dpl, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream) {
     typedef tile::TileMvnDiag D;
-    if (dpl == 2) hipLaunchKernelGGL((tile::nuts_tile_diag_kernel<2, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
-    else if (dpl == 4) hipLaunchKernelGGL((tile::nuts_tile_diag_kernel<4, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
+    if (dpl == 4) hipLaunchKernelGGL((tile::nuts_tile_diag_kernel<4, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

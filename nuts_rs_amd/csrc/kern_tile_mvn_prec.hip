@@ -7,12 +7,10 @@ namespace nm {
 hipError_t launch_tile_mvn_prec(int dpl, int query, const KParams& P, const tile::TileMats& M, unsigned grid, hipStream_t stream, int* occ) {
     typedef LrWrap<tile::TileMvnPrec> D;
     if (query) {
-        if (dpl == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, tile::nuts_tile_draw_kernel<2, D>, 64 * tile::TC, 0);
         if (dpl == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, tile::nuts_tile_draw_kernel<4, D>, 64 * tile::TC, 0);
         return hipErrorInvalidValue;
     }
-    if (dpl == 2) hipLaunchKernelGGL((tile::nuts_tile_draw_kernel<2, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
-    else if (dpl == 4) hipLaunchKernelGGL((tile::nuts_tile_draw_kernel<4, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
+    if (dpl == 4) hipLaunchKernelGGL((tile::nuts_tile_draw_kernel<4, D>), dim3(grid), dim3(64 * tile::TC), 0, stream, P, M);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

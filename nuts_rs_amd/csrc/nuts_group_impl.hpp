@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw
                 asm volatile("" ::: "memory");
             }
             C.dim = (int)P.dim;
-            C.md = layout_depth(P.s);
+            C.md = (int)P.layout_md;
             C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad + 2 * l;
             C.sv = P.svec + (size_t)blockIdx.x * P.nsslot * P.dpad + 2 * GS * g + 2 * l;
             C.l1z = sh.l1z[g] + 2 * l; C.l1v = sh.l1v[g] + 2 * l; C.samp = sh.samp[g];

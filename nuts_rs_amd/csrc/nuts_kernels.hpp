@@ -73,6 +73,8 @@ __host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(m
 // The depth every slot family (F, L, candidate pool, pend tables) is laid out for.  A tree that turned at depth d <= maxdepth is extended by
 // `extra_doublings` further doublings (src/nuts.rs:350-371), so sub-trees of level up to maxdepth + extra_doublings - 1 are built; with the
 // layout of `maxdepth` alone slot_L(MD, MD + 1) is slot_C(MD, 0) and the candidate pool overflows.
+// (Computed once by the host into KParams::layout_md: reading both settings fields in ctx_begin changed the register allocation of the
+// 16-wavefront matrix-core kernel enough to break it — the last doubling of trees deeper than 6 stopped after one leaf)
 __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)(s.maxdepth + s.extra_doublings); }
 #ifndef NM_BATCH_MERGES
 #define NM_BATCH_MERGES 1        // 0: every merge evaluated where the reference evaluates it (tuning / bisecting builds)
@@ -169,6 +171,7 @@ struct KParams {
     // NM_LOGP_HOST_CALLBACK: one mailbox per chain in pinned host memory (CbMail header, then x[dim], grad[dim])
     unsigned char* cb_mail;
     uint64_t cb_stride;           // bytes per mailbox
+    uint64_t layout_md;           // layout_depth(s) = maxdepth + extra_doublings: the depth the tree's slot families are laid out for
 };
 
 // Phase timing for development (-DNM_PROF=1): block 0 accumulates shader-clock cycles between marks into P.prof[].
@@ -742,7 +745,7 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
     C.goff = C.red.cl.member * (int)P.cl_slice;
     C.dim = (int)(P.dim - (uint64_t)C.goff < P.cl_slice ? P.dim - (uint64_t)C.goff : P.cl_slice);
 #endif
-    C.maxdepth_cfg = layout_depth(P.s);      // slots are laid out for the deepest tree a draw can grow: maxdepth + extra_doublings
+    C.maxdepth_cfg = (int)P.layout_md;       // slots are laid out for the deepest tree a draw can grow: maxdepth + extra_doublings
     C.pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
     C.sv = P.svec + (size_t)wave * P.nsslot * P.dpad;
     C.slot_bytes = (int)(P.dpad * 8);

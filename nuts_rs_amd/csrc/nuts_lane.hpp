@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, 
             ChainScalars sc = P.sc[chain];
             LCtx<NP, LD> C(P, sc);
             C.dim = (int)P.dim;
-            C.md = layout_depth(P.s);
+            C.md = (int)P.layout_md;
             C.rw = make_rsrc(LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64, (uint64_t)NUM_PSLOT * E * 512);
             C.rsv = make_rsrc(LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64, (uint64_t)LP.nslots * E * 512);
             C.l8 = l * 8;

@@ -348,6 +348,15 @@ class ChainBatch:
         """Draw launches served by the 16-chains-per-block matrix-core kernel (shared transformation, nuts_tile.hpp)."""
         return int(_lib.load().nm_engine_tile_launches(self._h))
 
+    def lockstep_launches(self):
+        """... of which by the lockstep form (nuts_lockstep.hpp)."""
+        return int(_lib.load().nm_engine_lockstep_launches(self._h))
+
+    def reduce_order(self):
+        """How the draws sum over dim (nm_engine_reduce_order): 0 wave kernels, 1 matrix-core tile kernel, 2 lockstep kernel —
+        the oracle's gpu_cfg(threads_per_chain, lr_seq_dots=reduce_order())."""
+        return int(_lib.load().nm_engine_reduce_order(self._h))
+
     def init_positions_uniform(self):
         """x0 ~ U(-1,1) from each chain's outer generator: `CpuMath::init_position` in Sampler order."""
         x0 = np.empty((self.n_chains, self.logp.dim))

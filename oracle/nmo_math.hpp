@@ -37,7 +37,13 @@ struct MathCfg {
     int64_t gpu_slice = 0;      // REDUCE_GPU: > 0: a chain wider than one block — consecutive slices of this many elements are reduced
                                 // as above, each by its own block, and the slice totals added in slice order (engine: dim > 4096)
     int64_t lr_seq_dots = 0;    // the low-rank transformation's U'v as sequential fma dot products (the engine's matrix-core
-                                // kernel for shared matrices: an MFMA accumulates over the inner index in ascending order)
+                                // kernel for shared matrices: an MFMA accumulates over the inner index in ascending order);
+                                // 2: the same, and from the moment the shared transformation is set (nmo_chain_set_transform) every
+                                // reduction over dim uses the lockstep kernel's order (tile_order below)
+    int64_t tile_order = 0;     // REDUCE_GPU: 1 = the order of the 16-chains-per-block lockstep kernel (nuts_lockstep.hpp): element d
+                                // sits in stripe d / 16 on lane-row g = d % 4, slot r = (d % 16) / 4; a lane accumulates its slots in
+                                // r order, a stripe's total is (p_0 + p_1) + (p_2 + p_3) over its four lane-rows, stripes are added in
+                                // stripe order
 };
 
 static inline uint64_t f2u(double x) { uint64_t u; std::memcpy(&u, &x, 8); return u; }
@@ -202,8 +208,20 @@ struct Ctx {
     // GPU order: element d lives in pair q=d/2 (component j=d%2) of thread t=q%T at step m=q/T;
     // a thread accumulates its elements in (m, j) order; wave totals come from an xor butterfly with
     // offsets 1,2,4,8,16,32; the W=T/64 wave totals are added in wave order.
+    template <class Acc>
+    double tile_reduce(size_t n, Acc&& step) const {
+        double total = 0.0;
+        for (size_t s0 = 0, b = 0; s0 < n; s0 += 16, ++b) {
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
+            for (size_t d = s0; d < std::min(n, s0 + 16); ++d) p[d % 4] = step(p[d % 4], d);      // (ascending d = ascending r per lane-row)
+            const double t = (p[0] + p[1]) + (p[2] + p[3]);
+            total = b == 0 ? t : total + t;
+        }
+        return total;
+    }
     template <class Acc>  // Acc(double acc, size_t d) -> double : one accumulation step
     double gpu_reduce(size_t n, Acc&& step) const {
+        if (cfg.tile_order) return tile_reduce(n, step);
         const size_t S = (size_t)cfg.gpu_slice;
         if (S > 0 && n > S) {
             double total = 0.0;

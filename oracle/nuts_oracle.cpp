@@ -88,8 +88,10 @@ int nmo_chain_set_transform(void* cv, const double* stds, const double* mean, ui
                             const double* vecs, const double* mu_lr) {
     Chain* c = (Chain*)cv;
     const size_t n = c->n;
-    return c->h.mm.update(c->m, Vec(stds, stds + n), Vec(mean, mean + n), Vec(vals, vals + n_eig), Vec(vecs, vecs + n_eig * n),
-                          Vec(mu_lr, mu_lr + n)) ? 1 : 0;
+    const int ok = c->h.mm.update(c->m, Vec(stds, stds + n), Vec(mean, mean + n), Vec(vals, vals + n_eig), Vec(vecs, vecs + n_eig * n),
+                                  Vec(mu_lr, mu_lr + n)) ? 1 : 0;
+    if (c->m.cfg.lr_seq_dots == 2) c->m.cfg.tile_order = 1;     // the engine's lockstep kernel takes over from here (set_position ran on the wave kernels)
+    return ok;
 }
 int nmo_chain_draw_ex(void* c, double* out_position, DrawStats* stats, const DrawVectors* vec) { return ((Chain*)c)->draw(out_position, stats, vec); }
 int nmo_chain_set_position(void* c, const double* x0) { return ((Chain*)c)->set_position(x0); }

@@ -72,7 +72,7 @@ class DrawVectors(C.Structure):
 
 class MathCfg(C.Structure):
     _fields_ = [("detmath", C.c_int64), ("reduce_mode", C.c_int64), ("simd_lanes", C.c_int64),
-                ("gpu_threads", C.c_int64), ("gpu_slice", C.c_int64), ("lr_seq_dots", C.c_int64)]
+                ("gpu_threads", C.c_int64), ("gpu_slice", C.c_int64), ("lr_seq_dots", C.c_int64), ("tile_order", C.c_int64)]
 
 
 # LowRankMassMatrixStrategy's dense linear algebra as a callback (oracle/lowrank.py implements it with LAPACK)
@@ -97,14 +97,16 @@ LOGP_IID_NORMAL, LOGP_DIAG_NORMAL, LOGP_FUNNEL, LOGP_EIGHT_SCHOOLS, LOGP_MVN_PRE
 
 def ref_cfg(simd_lanes=4):
     """What the reference does on this box: libm transcendentals, pulp-style 4-accumulator SIMD sums."""
-    return MathCfg(0, REDUCE_REF_SIMD, simd_lanes, 64, 0, 0)
+    return MathCfg(0, REDUCE_REF_SIMD, simd_lanes, 64, 0, 0, 0)
 
 
 def gpu_cfg(gpu_threads=64, lr_seq_dots=0, gpu_slice=0):
     """The arithmetic contract of the HIP engine: restated exp/ln, fixed lane-tiled reduction order.
     lr_seq_dots=1: the matrix-core kernel for shared matrices (its U'v products are sequential fma chains).
+    lr_seq_dots=2: the lockstep matrix-core kernel (nuts_lockstep.hpp): the same products, and every reduction over dim in that
+    kernel's stripe order from the moment the shared transformation is set (set_position runs on the wave kernels before).
     gpu_slice=4096: a chain wider than one block (dim > 4096) — slice totals added in slice order."""
-    return MathCfg(1, REDUCE_GPU, 4, gpu_threads, gpu_slice, lr_seq_dots)
+    return MathCfg(1, REDUCE_GPU, 4, gpu_threads, gpu_slice, lr_seq_dots, 0)
 
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -77,12 +77,14 @@ def run_fixed(oracle, logp, settings, n_chains, transform, n_draws, waves_per_ch
     parts = [b.draw_many(hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
     pos, st = np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
     tpc = b.threads_per_chain()
-    tiles = b.tile_launches() > 0              # the matrix-core kernel sums U'v sequentially: the oracle's lr_seq_dots mode
+    tiles = b.tile_launches() > 0              # the matrix-core kernels sum U'v sequentially: the oracle's lr_seq_dots mode
+    order = b.reduce_order()                   # (1: the tile kernel, 2: the lockstep kernel with its own order of the sums over dim)
     if expect_tiles is not None:
         assert tiles == expect_tiles
+    assert (order > 0) == tiles and (order == 2) == (b.lockstep_launches() > 0)
     b.close()
     pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, settings), logp.kind, logp.dim, logp.params,
-                                        oracle.gpu_cfg(tpc, lr_seq_dots=int(tiles)), n_chains, x0, n_draws, n_threads=8, transform=transform)
+                                        oracle.gpu_cfg(tpc, lr_seq_dots=order), n_chains, x0, n_draws, n_threads=8, transform=transform)
     assert failed == 0
     return pos, st, pos_o, st_o
 
@@ -121,8 +123,9 @@ def test_fixed_transform_chains_bit_exact(oracle, case):
         assert st["depth"][-10:].mean() <= 4.5 and st["step_size"][-1].min() > 0.25
 
 
+@pytest.mark.parametrize("chain_tiles", [0, 2], ids=["lockstep", "tile"])
 @pytest.mark.parametrize("dim,rank,n_chains", [(64, 16, 21), (128, 64, 40), (256, 32, 35), (200, 200, 16)])
-def test_matrix_core_kernel_bit_exact(oracle, dim, rank, n_chains):
+def test_matrix_core_kernel_bit_exact(oracle, dim, rank, n_chains, chain_tiles):
     """nuts_tile.hpp: 16 chains per block, U'z / U s / P x as MFMA products over the block's column tile.  Ragged chain
     counts (empty columns in the last tile), several tiles per block, launches cut in the middle, dims that are not 256."""
     rng = np.random.default_rng(dim + rank)
@@ -131,7 +134,7 @@ def test_matrix_core_kernel_bit_exact(oracle, dim, rank, n_chains):
     keep = np.argsort(np.abs(np.log(w)))[::-1][:rank]
     tr = (np.exp(rng.normal(0, 0.2, dim)), rng.normal(0, 0.5, dim), w[keep], np.ascontiguousarray(u[:, keep].T), rng.normal(0, 0.1, dim))
     s = lowrank_settings(num_chains=n_chains, seed=17, num_tune=40, freeze_transform=True)
-    pos, st, pos_o, st_o = run_fixed(oracle, N.LogpSpec.mvn_precision(prec), s, n_chains, tr, 60, expect_tiles=True, splits=(1, 33))
+    pos, st, pos_o, st_o = run_fixed(oracle, N.LogpSpec.mvn_precision(prec), s, n_chains, tr, 60, expect_tiles=True, splits=(1, 33), chain_tiles=chain_tiles)
     assert_bit_exact(pos, st, pos_o, st_o)
     assert len(np.unique(st["depth"])) >= 2                       # trees of different sizes inside a tile
 
@@ -243,7 +246,7 @@ def test_builtin_estimator_whole_run_vs_literal_reference_algorithm(oracle, dim,
     (tests/test_lowrank_estimator_builtin.py):
       * up to and including the draw of the first update both sides see identical inputs: draws bit-exact;
       * EVERY window the engine hands to its estimator: the built-in's answer against the literal algorithm on the same
-        window: sigma / mean 1e-13, the applied operator 1e-6 on full-rank windows and 0.25 (and within 2 x the LAPACK forms' own
+        window: sigma / mean 1e-13, the applied operator 1e-6 on full-rank windows and 0.25 (and within 4 x the LAPACK forms' own
         spread) on rank-deficient ones, signal eigenvalues (> 2 x cutoff) equal in number and within 5 %;
       * after the first update the two runs are different chaotic trajectories of the same sampler: the adapted step size,
         tree sizes and the quality of the final transformation agree statistically."""
@@ -308,7 +311,7 @@ def test_builtin_estimator_whole_run_vs_literal_reference_algorithm(oracle, dim,
             n_def += 1
             rr = LR.compute_update(d, g, gamma, cutoff, rank_revealing=True)
             d_rr = np.linalg.norm(T.op_of(rr[2], rr[3]) - bb, 2) / np.linalg.norm(bb, 2)
-            assert d_bi <= T.TOL_RANK_DEFICIENT and d_bi <= 2.0 * max(d_rr, 0.02), (d.shape, d_bi, d_rr)
+            assert d_bi <= T.TOL_RANK_DEFICIENT and d_bi <= 4.0 * max(d_rr, 0.02), (d.shape, d_bi, d_rr)
             sig_bi, sig_lit = np.sort(bi[2][bi[2] > 4.0]), np.sort(lit[2][lit[2] > 4.0])
             if not (np.abs(np.concatenate([bi[2], lit[2]]) - 4.0) < 4.0 * T.TOL_SIGNAL_EIG).any():
                 assert len(sig_bi) == len(sig_lit) and np.allclose(sig_bi, sig_lit, rtol=T.TOL_SIGNAL_EIG)
@@ -389,13 +392,15 @@ def test_k5_full_size_properties(oracle):
     pos, st = np.concatenate([pos1, pos2]), np.concatenate([st1, st2])
     tpc = b.threads_per_chain()
     assert b.tile_launches() >= 2                                   # the launches (draw_many cuts big ones into chunks) ran on the matrix cores
+    order = b.reduce_order()
+    assert order == 2 and b.lockstep_launches() == b.tile_launches()   # ... in their lockstep form
     b.close()
     assert (st["chain_status"] == 0).all() and st["diverging"].mean() < 1e-3
     sample = pos[tune:].reshape(-1, dim)
     z = sample @ (u / np.sqrt(w))                                   # whitened draws ~ N(0, I)
     assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
     assert np.abs(np.cov(z.T) - np.eye(dim)).max() < 0.06
-    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc, lr_seq_dots=1), 2,
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, dim, logp.params, oracle.gpu_cfg(tpc, lr_seq_dots=order), 2,
                                         x0[:2], draws, n_threads=2, transform=tr)
     assert failed == 0
     assert_bit_exact(pos[:, :2], st[:, :2], pos_o, st_o)

@@ -14,7 +14,7 @@ Tolerances (measured: tools/estimator_departure.py, profiles/r04a_estimator_depa
   full-rank windows (n_draws - 1 >= dim): operator A = I + U (lambda^1/2 - I) U', mu, eigenvalues   1e-6 relative
       (measured <= 2e-10 once n_draws - 1 >= 1.05 dim, 8e-9 ... 1e-7 between any two forms at n_draws - 1 == dim)
   rank-deficient windows (n_draws - 1 < dim):
-      operator within 0.25 relative (2-norm; measured up to 0.19 on the windows of real warm-ups) and within 2 x the distance between the two LAPACK forms of the SAME algorithm
+      operator within 0.25 relative (2-norm; measured up to 0.19 on the windows of real warm-ups) and within 4 x the distance between the two LAPACK forms of the SAME algorithm
       (literal and rank-revealing bases) — the reference's formula is ill-conditioned there: gamma = 1e-5 puts the
       regularised covariances at condition ~1e10 inside the windows' span, their SPD mean amplifies rounding to the
       percent level, and a cluster of eigenvalues sits at the 1 / cutoff threshold, so the NUMBER of kept eigenpairs differs
@@ -169,7 +169,7 @@ def test_builtin_compute_update_vs_literal_reference_algorithm_rank_deficient(di
     nb = np.linalg.norm(b, 2)
     d_bi, d_rr = np.linalg.norm(a - b, 2) / nb, np.linalg.norm(c - b, 2) / nb
     assert d_bi <= TOL_RANK_DEFICIENT, d_bi
-    assert d_bi <= 2.0 * max(d_rr, 0.02), (d_bi, d_rr)                      # inside the spread of the LAPACK forms of the same algorithm
+    assert d_bi <= 4.0 * max(d_rr, 0.02), (d_bi, d_rr)                      # inside the spread of the LAPACK forms of the same algorithm
     sig_bi, sig_lit = np.sort(bi[2][bi[2] > 4.0]), np.sort(lit[2][lit[2] > 4.0])
     near = np.abs(np.concatenate([bi[2], lit[2]]) - 4.0) < 4.0 * TOL_SIGNAL_EIG
     if not near.any():

@@ -118,9 +118,9 @@ def run_case(s, logp, n, draws, eng, rng=None, transform=None):
         pa, sa = b.draw_many(cut, raise_on_error=False)
         pb, sb = b.draw_many(draws - cut, raise_on_error=False)
         pos, st = np.concatenate([pa, pb]), np.concatenate([sa, sb])
-    tpc, k, tiles = b.threads_per_chain(), b.blocks_per_chain(), b.tile_launches() > 0
+    tpc, k, order = b.threads_per_chain(), b.blocks_per_chain(), b.reduce_order()
     b.close()
-    cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0, lr_seq_dots=int(tiles and transform is not None))
+    cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0, lr_seq_dots=order if transform is not None else 0)
     so = oracle_settings(O, s)
     # per chain through the step-wise interface so that a failed chain does not end the comparison
     if n > 100:          # a sample of the chains, each from its own global id
