@@ -166,6 +166,57 @@ def pmc_live(args, config="k2", passes=None, kernel=KERNEL, steps=None, deadline
     return out, None
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# A roofline that is a BOUND: t_min = max(necessary HBM bytes / 8 TB/s, necessary VALU cycles / (SIMDs x clock))
+# ------------------------------------------------------------------------------------------------------------------
+# f64 vector operations per (leapfrog step x element) that ANY evaluation of this tree needs (iid normal, diagonal mass matrix):
+#   leapfrog 11 (v half step fma, z' fma, z' sigma mul, + mu fma, x - mu0, two muls of -diff^2/2, the logp sum's add, g = gx sigma mul,
+#                v second half fma, kinetic fma);
+#   U-turn tests 12 per closed sub-tree level (3 pairs x (difference: add + sub, two fmas)) x (1 level per leaf on average over a
+#                balanced doubling + the top-level test of each of the ~ depth doublings: 12 x (1 + depth / leaves));
+#   candidate bookkeeping / accounting: none per element.
+NEC_VALU_LEAPFROG = 11.0
+NEC_VALU_PER_TEST_LEVEL = 12.0
+SHADER_HZ, N_SIMD, F64_VALU_CYCLES_PER_WAVE_INSTR = 2.4e9, 1024, 4.0
+
+
+def bound_model(st, D, kern_s, traffic):
+    """st: the statistics rows of a timed launch ([steps][chains]).  Necessary bytes from the per-depth table of
+    tools/necessary_traffic.py (Belady MIN over the draw's vector access trace at the kernel's on-chip capacity per chain)."""
+    tbl = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_necessary_traffic_k2.json"))):
+        try:
+            tbl = json.load(open(f)); src = os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    if tbl is None or tbl.get("dim") != D:
+        return {"note": "profiles/r*_necessary_traffic_k2.json missing or for another dim: python tools/necessary_traffic.py --dim D --out ..."}
+    depth = st["depth"].ravel().astype(np.int64)
+    n_steps = st["n_steps"].ravel().astype(np.float64)
+    io = float(tbl["io_bytes_per_draw"])
+    per = {int(k): float(v["necessary_bytes_per_draw"]) for k, v in tbl["per_depth"].items()}
+    nec_bytes = float(sum(per.get(int(d), io) * cnt for d, cnt in zip(*np.unique(depth, return_counts=True))))
+    levels = n_steps.sum() * 1.0 + depth.sum()            # sub-tree levels closed (one per leaf on average) + one top-level test per doubling
+    nec_ops_elem = NEC_VALU_LEAPFROG * n_steps.sum() + NEC_VALU_PER_TEST_LEVEL * levels
+    nec_cycles = nec_ops_elem * (D / 64.0) * F64_VALU_CYCLES_PER_WAVE_INSTR
+    t_hbm = nec_bytes / (HBM_PEAK_GBS * 1e9)
+    t_valu = nec_cycles / (N_SIMD * SHADER_HZ)
+    t_min = max(t_hbm, t_valu)
+    return {"frac": t_min / kern_s, "t_min_ms": t_min * 1e3, "t_kernel_ms": kern_s * 1e3, "binding": "valu" if t_valu >= t_hbm else "hbm",
+            "hbm": {"necessary_bytes": nec_bytes, "t_ms": t_hbm * 1e3, "frac": t_hbm / kern_s,
+                    "necessary_bytes_per_chain_draw": nec_bytes / max(1, depth.size),
+                    "moved_over_necessary": (traffic / nec_bytes) if traffic else None,
+                    "enumeration": "per draw: read z, g_z, sigma, mu + write z, g_z + position row (7 vectors) + 192 B statistics; tree end points only "
+                                   "where Belady's MIN over the draw's vector trace cannot keep them in the chain's on-chip share "
+                                   f"({tbl['capacity_vectors']['for_tree_end_points']} vectors beside the leapfrog's working set: {src})"},
+            "valu": {"necessary_wave_cycles": nec_cycles, "t_ms": t_valu * 1e3, "frac": t_valu / kern_s,
+                     "f64_ops_per_element_step": nec_ops_elem / max(1.0, n_steps.sum()),
+                     "enumeration": "11 f64 operations per (leapfrog x element) + 12 per (closed sub-tree level x element), 4 cycles per 64-lane f64 instruction, "
+                                    "1024 SIMDs at 2.4 GHz"},
+            "definition": "t_min = max(necessary HBM bytes / 8 TB/s, necessary VALU cycles / (1024 SIMDs x 2.4 GHz)); frac = t_min / t_kernel <= 1 by "
+                          "construction; moving more bytes cannot raise it"}
+
+
 def pmc_profile(steps_dims):
     """Fallback: the latest committed profile's bytes per (leapfrog-step x dim), scaled to this run's steps x dims."""
     best = None
@@ -275,7 +326,7 @@ OTHER_CONFIGS = {
     "k4_8192": dict(name="K4: 8 schools non-centered dim 10, one GPU's shard (8192 chains) of the 65536-chain job, num_tune 400",
                     chains=8192, tune=400, bound="hbm", kernel="nuts_"),
     "k5": dict(name="K5: N(0, Sigma) full Sigma dim 256 x 4096 chains through the exact dense preconditioner = LowRankMassMatrix of rank 256 shared "
-                    "by all chains (frozen), step size adapted over 100 draws", chains=4096, tune=100, bound="mfma", kernel="nuts_tile"),
+                    "by all chains (frozen), step size adapted over 100 draws", chains=4096, tune=100, bound="mfma", kernel="nuts_lockstep"),
 }
 
 
@@ -525,8 +576,10 @@ def main():
         return
 
     recorded_ok = None
+    st_all = None
     if record and rank == 0:     # the last repeat's buffers hold real draws: finite positions, the right draw indices
-        st_host = np.frombuffer(d_st[-1].cpu().numpy().tobytes(), dtype=N.STATS_DTYPE)
+        st_all = np.frombuffer(d_st.cpu().numpy().tobytes(), dtype=N.STATS_DTYPE).reshape(args.steps, C_)
+        st_host = st_all[-1]
         first_draw = args.num_tune + args.warmup + (R - 1) * args.steps
         recorded_ok = bool(torch.isfinite(d_pos[-1]).all().item()) and bool((st_host["draw"] == first_draw + args.steps - 1).all()) \
             and bool((st_host["n_steps"] > 0).all())
@@ -593,6 +646,7 @@ def main():
                          "frac_definition": "frac = frac_moved = HBM bytes the kernel moved (PMC) / launch time / 8 TB/s (<= 1: a utilisation "
                                             "of bytes the design chose to move); frac_sec8d_model = 64 B x steps x dims / launch time / 8 TB/s "
                                             "(SURVEY 8(d)'s streaming model; exceeds 1 because live points, sigma, mu never leave the CU)",
+                         "bound_model": bound_model(st_all, D, kern_s, traffic) if st_all is not None else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL, "kernel_ms_per_launch": kern_ms, "launches": 1,
                          "frac_of_measured_copy": (achieved / (cal.get("copy_GBps") or HBM_COPY_GBS)) if achieved else None,

@@ -39,7 +39,10 @@ using lane::LRng;
 using lane::LAccept;
 
 constexpr int LC = 16;             // chains per block = columns of the MFMA
-constexpr int LS = 16;             // wavefronts per block = 16-row stripes
+constexpr int LS = 16;             // 16-row stripes of a column tile
+constexpr int SPW = 2;             // stripes per wavefront: 8 wavefronts per block = 2 per SIMD = 256 registers each (with one stripe per
+                                   // wavefront and 128 registers the first build spilled 245 of them around every product)
+constexpr int LWV = LS / SPW;      // wavefronts per block
 constexpr int LROWS = 256;         // rows of a column tile (dim, rank <= 256)
 constexpr int NRED = 32;           // partial-sum slots per (stripe, chain) and reduction pass
 constexpr int GROUPS_PER_PASS = 4; // U-turn test groups (6 sums each) per pass
@@ -48,6 +51,17 @@ constexpr int MAX_GROUPS = LOCK_MAXDEPTH + 1;
 constexpr int NSUM = 8 + 6 * MAX_GROUPS;
 constexpr int NUNIT = 4;           // momentum-refresh units (wavefronts 1 .. NUNIT)
 constexpr int RF_P = 4;            // passes of the bulk ziggurat per chunk (256 cells)
+
+// Development (-DNM_LOCK_PROF=1, tools/bench_k5.py): shader-clock cycles of wavefront 0 of block 0 between the phase marks of a round,
+// summed into P.prof[0 .. 7] (logic, unit hand-out, P3, products, P1 + reductions) and the rounds into P.prof[8]
+#ifndef NM_LOCK_PROF
+#define NM_LOCK_PROF 0
+#endif
+#if NM_LOCK_PROF
+#define NM_LKP(slot) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lkp_acc[slot] += n_ - lkp_t; lkp_t = n_; }
+#else
+#define NM_LKP(slot)
+#endif
 
 enum Mode : int { M_IDLE = 0, M_LEAF = 1, M_RECOMP = 2, M_KEEP = 3, M_WHITEN = 4, M_START = 5 };
 // M_RECOMP: the chosen point's (x, g_x, g_z) from its z;  M_KEEP: the initial point was chosen and P_X / P_GX hold it (no density
@@ -131,39 +145,102 @@ struct Vec4 { double a[4]; };
 // one stripe of a product on the matrix cores: acc += M[16 s .. 16 s + 15][:] B, inner index ascending.
 // The A operands of 8 k-pairs (4 KiB per wavefront) are requested ahead of the MFMAs that use them.
 // ---------------------------------------------------------------------------------------------
-NM_DEV v4d gemm_stripe(const double* packed, int s, int kpairs, const double* b, v4d acc) {
+// acc[h] += M[stripe w SPW + h][:] B for the wavefront's SPW stripes; `nst` = stripes the matrix has (beyond: nothing to do).
+// Software-pipelined by hand: the A operands of chunk k + 1 (4 k-pairs x 2 stripes = 8 x 16 B per lane) are REQUESTED before the 16 MFMAs
+// of chunk k are issued, through a buffer descriptor (one per-lane offset, the chunk's position in an SGPR) and with scheduling barriers
+// around the groups — left to itself the compiler rotates the loop so that every chunk waits for its own loads (first build: the
+// products ran at half the matrix cores' rate with loads, LDS reads and spills all out of the way).  Requesting a product's FIRST chunk
+// before the barrier in front of it (gemm_prefetch; the A operands do not depend on what the barrier guards) was measured and not
+// kept: the requests queue in front of P3's own loads and the epilogues' registers — 75 -> 84 us per round.
+constexpr int GCH = 4;                    // k-pairs per chunk
+struct GemmA { double2 a0[SPW][GCH]; };
+NM_DEV void gemm_prefetch(GemmA& G, const double* packed, int w, int nst, int kpairs) {
+    if (w * SPW >= nst || kpairs < GCH) return;
+    const rsrc_t ra = make_rsrc(packed, (uint64_t)nst * (uint64_t)kpairs * 1024);
+    const int lv = lane_id() * 16;
+#pragma unroll
+    for (int h = 0; h < SPW; ++h) {
+        const int st = w * SPW + h;
+        const int sb = (st < nst ? st : 0) * kpairs * 1024;
+#pragma unroll
+        for (int i = 0; i < GCH; ++i) G.a0[h][i] = buf_load2(ra, lv, sb + i * 1024);
+    }
+}
+NM_DEV void gemm_stripes(GemmA& G, const double* packed, int w, int nst, int kpairs, const double* b, v4d (&acc)[SPW]) {
     const int l = lane_id(), kk = l >> 4, c = l & 15;
-    const double2* ap = reinterpret_cast<const double2*>(packed) + (size_t)s * (size_t)kpairs * 64 + l;
-    constexpr int CH = 4;
-    double2 a0[CH], a1[CH];
+    bool on[SPW];
+    int sbase[SPW];                       // byte offset of my stripes' operands (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < CH; ++i) a0[i] = i < kpairs ? ap[(size_t)i * 64] : double2{0.0, 0.0};
-    for (int q0 = 0; q0 < kpairs; q0 += 2 * CH) {
+    for (int h = 0; h < SPW; ++h) {
+        const int st = w * SPW + h;
+        on[h] = st < nst;
+        sbase[h] = (on[h] ? st : 0) * kpairs * 1024;
+    }
+    if (!on[0]) return;                   // (stripes are handed out in order: none of mine exists)
+    const v4d last_init = acc[SPW - 1];
+    const rsrc_t ra = make_rsrc(packed, (uint64_t)nst * (uint64_t)kpairs * 1024);
+    const int lv = l * 16;
+    constexpr int CH = GCH;
+    const int nfull = kpairs / CH;
+    double2 a1[SPW][CH];
+    auto request = [&](double2 (&a)[SPW][CH], int qq) {           // the A operands of the chunk that starts at k-pair qq
 #pragma unroll
-        for (int i = 0; i < CH; ++i) a1[i] = q0 + CH + i < kpairs ? ap[(size_t)(q0 + CH + i) * 64] : double2{0.0, 0.0};
+        for (int h = 0; h < SPW; ++h)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) a[h][i] = buf_load2(ra, lv, sbase[h] + (qq + i) * 1024);
+    };
+    auto chunk = [&](const double2 (&a)[SPW][CH], int qq) {       // its 16 MFMAs; the B operand of a k-step is read once for both stripes,
+        double bv[2 * CH];                                        // and all eight of the chunk are requested before its first MFMA
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            if (q0 + i < kpairs) {
-                const int r0 = 8 * (q0 + i) + kk;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i].x, b[taddr(r0, c)], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i].y, b[taddr(r0 + 4, c)], acc, 0, 0, 0);
-            }
+            const int r0 = 8 * (qq + i) + kk;
+            bv[2 * i] = b[taddr(r0, c)];
+            bv[2 * i + 1] = b[taddr(r0 + 4, c)];
         }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) a0[i] = q0 + 2 * CH + i < kpairs ? ap[(size_t)(q0 + 2 * CH + i) * 64] : double2{0.0, 0.0};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            if (q0 + CH + i < kpairs) {
-                const int r0 = 8 * (q0 + CH + i) + kk;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i].x, b[taddr(r0, c)], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i].y, b[taddr(r0 + 4, c)], acc, 0, 0, 0);
-            }
+#pragma unroll
+            for (int h = 0; h < SPW; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][i].x, bv[2 * i], acc[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < SPW; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][i].y, bv[2 * i + 1], acc[h], 0, 0, 0);
+        }
+    };
+    const int qlast = nfull > 0 ? (nfull - 1) * CH : 0;           // (requests beyond the last chunk re-request it: no branch around loads)
+    if (nfull > 0) request(G.a0, 0);
+    int q = 0;
+    for (int ch = 0; ch < nfull; ch += 2) {                       // two chunks per trip: the buffers swap roles, nothing is copied
+        request(a1, q + CH <= qlast ? q + CH : qlast);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk(G.a0, q);
+        __builtin_amdgcn_sched_barrier(0);
+        request(G.a0, q + 2 * CH <= qlast ? q + 2 * CH : qlast);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nfull) chunk(a1, q + CH);
+        __builtin_amdgcn_sched_barrier(0);
+        q += 2 * CH;
+    }
+    q = nfull * CH;
+    for (; q < kpairs; ++q) {                                     // kpairs not a multiple of the chunk (dim or rank not a multiple of 32)
+        const int r0 = 8 * q + kk;
+        const double b0 = b[taddr(r0, c)], b1 = b[taddr(r0 + 4, c)];
+#pragma unroll
+        for (int h = 0; h < SPW; ++h) {
+            const double2 a = buf_load2(ra, lv, sbase[h] + q * 1024);
+            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc[h], 0, 0, 0);
+            acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc[h], 0, 0, 0);
         }
     }
-    return acc;
+    if (!on[SPW - 1]) {                                           // (a matrix with an odd number of stripes: the last wavefront's second one)
+#pragma unroll
+        for (int h = 1; h < SPW; ++h) if (!on[h]) acc[h] = last_init;   // (SPW == 2: only the last stripe can be missing on its own)
+    }
 }
 
-NM_DEV void blk_barrier() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// The block's wavefronts talk through LDS only (the tree scratch in HBM is private to a lane, output rows are read by nobody): a barrier
+// has to wait for the wavefront's LDS operations, NOT for its global loads and stores — a workgroup release fence would (s_waitcnt vmcnt(0)),
+// and with it for the A operands requested ahead for the next product.
+NM_DEV void blk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // the wavefront's stripe of a chain vector <-> a column tile in LDS
 NM_DEV void put_stripe(double* t, int s, const Vec4& v) {
@@ -172,10 +249,19 @@ NM_DEV void put_stripe(double* t, int s, const Vec4& v) {
     for (int r = 0; r < 4; ++r) t[taddr(16 * s + g + 4 * r, c)] = v.a[r];
 }
 
-// wavefront total of a partial over the four lane-rows of a stripe: (p0 + p1) + (p2 + p3), in every lane of the column
+// wavefront total of a partial over the four lane-rows of a stripe: (p0 + p1) + (p2 + p3), in every lane of the column.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange rows of 16 / halves of 32 lanes between two registers on the VALU: with the
+// same value in both, the two results are "my row pair's even row" and "its odd row" (resp. the two halves) — their sum is x + xor16(x)
+// (resp. x + xor32(x)) without the LDS crossbar round trip a ds_bpermute shuffle costs (two per sum, five to thirty sums per round).
 NM_DEV double stripe_sum(double p) {
-    const double q = p + __shfl_xor(p, 16);
-    return q + __shfl_xor(q, 32);
+    int lo = __double2loint(p), hi = __double2hiint(p);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double q = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = __double2loint(q); hi = __double2hiint(q);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,11 +611,45 @@ struct Logic {
     }
 };
 
+// Out-of-line entry points: the state machines run on wavefront 0 only and the refreshes on wavefronts 1 .. NUNIT; inlined, their
+// register needs (the generator's block function, the statistics row, exp / ln) would be charged to the products' loops of every
+// wavefront (first build: 361 registers spilled inside the kernel's hot path).
+__device__ __attribute__((noinline)) void logic_round(const KParams& P, LockShared& S, int l, int round_mode, int jitter_words) {
+    LkChain& K = S.ch[l];
+    if (K.start_draw) { S.unit_busy[K.v_unit] = 0; K.v_unit = -1; K.v_ready = 0; }      // P3 took the normals
+    K.finish = 0; K.start_draw = 0;
+    if (!K.live) return;
+    Logic L(P, S, l);
+    L.rng_begin();
+    if (round_mode == M_LEAF) L.leaf_done();
+    else if (round_mode == M_RECOMP || round_mode == M_KEEP) L.draw_done();
+    else if (round_mode == M_WHITEN) {
+        ChainScalars& q = S.sc[l];
+        q.logdet = q.mm_logdet; q.transform_id = q.mm_id;
+        K.mode = M_START;
+    }
+    L.rng_end();
+    // where the NEXT draw's momentum refresh starts in the stream: behind this draw's step-size jitter
+    if (K.v_unit < 0) {
+        if (K.mode == M_START) K.v_pos_start = K.rng_pos;
+        else if (K.mode == M_RECOMP || K.mode == M_KEEP) K.v_pos_start = K.rng_pos + (uint64_t)jitter_words;
+    }
+}
+__device__ __attribute__((noinline)) void logic_start(const KParams& P, LockShared& S, int l) {
+    LkChain& K = S.ch[l];
+    Logic L(P, S, l);
+    K.rng_pos = K.v_pos_after; K.rng_filled = K.v_pos_after >> 4;
+    L.rng_begin();
+    L.tree_begin();
+    L.rng_end();
+    K.start_draw = 1;                                             // P3 takes the normals out of the unit
+}
+
 // ---------------------------------------------------------------------------------------------
 // momentum refresh: one wavefront produces `dim` standard normals of a chain's stream, in stream order, into samp[0 .. dim)
 // (fill_standard_normals_bulk: the sequential ziggurat's samples and final stream position, bit for bit)
 // ---------------------------------------------------------------------------------------------
-NM_DEV void refresh_unit(const KParams& P, LockShared& S, int u) {
+__device__ __attribute__((noinline)) void refresh_unit(const KParams& P, LockShared& S, int u) {
     const int c = S.unit_chain[u];
     if (c < 0) return;
     LkChain& K = S.ch[c];
@@ -603,36 +723,40 @@ __global__ __launch_bounds__(64) void lock_commit_kernel(const KParams P) {
     }
 }
 
-__global__ __launch_bounds__(64 * LS, LS / 4) void nuts_lockstep_kernel(const KParams P, const TileMats M) {
+__global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const KParams P, const TileMats M) {
     __shared__ LockShared S;
     dm_init_lds();
-    const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // my stripe
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // my wavefront: stripes w SPW .. w SPW + SPW - 1
     const int l = lane_id(), g = l >> 4, c = l & 15;
     const int dim = (int)P.dim;
     const int MD = (int)P.layout_md;
-    for (int i = (int)threadIdx.x; i < 257; i += 64 * LS) { S.zig[i] = P.zig_x[i]; S.zig[257 + i] = P.zig_f[i]; }
+    constexpr int NT = 64 * LWV;
+    for (int i = (int)threadIdx.x; i < 257; i += NT) { S.zig[i] = P.zig_x[i]; S.zig[257 + i] = P.zig_f[i]; }
     const uint64_t n_tiles = (P.n_chains + LC - 1) / LC;
     const int jitter_words = P.s.has_jitter ? 2 : 0;
+    // the block's tree scratch through a buffer descriptor: [chain][slot][256], a lane's 4 rows of a stripe are 32 contiguous bytes
+    const rsrc_t rscr = make_rsrc(P.svec + (size_t)blockIdx.x * LC * (size_t)P.nsslot * LROWS, (uint64_t)LC * P.nsslot * LROWS * 8);
+    const int nss = (int)P.nsslot;
     for (uint64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
         __syncthreads();
         // ---- the tile's shared data and the chains' records
         {
             const uint64_t c0 = tile_i * LC;
             const double* lv = P.lrval + (size_t)c0 * 2 * P.lr_rmax;
-            for (int i = (int)threadIdx.x; i < 2 * LROWS; i += 64 * LS) {
+            for (int i = (int)threadIdx.x; i < 2 * LROWS; i += NT) {
                 const int which = i / LROWS, k = i % LROWS;
                 S.scale[which][k] = k < M.rank ? lv[(size_t)which * P.lr_rmax + k] - 1.0 : 0.0;
             }
             const double* pv = P.pvec + (size_t)c0 * NUM_PSLOT * P.dpad;
             const double* mlr = P.lrvec + (size_t)c0 * (1 + P.lr_rmax) * P.dpad;
-            for (int i = (int)threadIdx.x; i < LROWS; i += 64 * LS) {
+            for (int i = (int)threadIdx.x; i < LROWS; i += NT) {
                 const bool in = i < (int)P.dpad;
                 S.sig[i] = in ? pv[(size_t)P_SIG * P.dpad + i] : 0.0;
                 S.isig[i] = in ? pv[(size_t)P_ISIG * P.dpad + i] : 0.0;
                 S.mu[i] = in ? pv[(size_t)P_MU * P.dpad + i] : 0.0;
                 S.mul[i] = in ? mlr[i] : 0.0;
             }
-            for (int i = (int)threadIdx.x; i < 2 * LROWS * LC; i += 64 * LS) S.t[0][i] = 0.0;
+            for (int i = (int)threadIdx.x; i < 2 * LROWS * LC; i += NT) S.t[0][i] = 0.0;
             if (threadIdx.x < LC) {
                 const int cc = (int)threadIdx.x;
                 const uint64_t chain = c0 + (uint64_t)cc;
@@ -657,68 +781,46 @@ __global__ __launch_bounds__(64 * LS, LS / 4) void nuts_lockstep_kernel(const KP
         }
         __syncthreads();
         const uint64_t my_chain = S.ch[c].chain < P.n_chains ? S.ch[c].chain : 0;
-        double* const my_scr = P.svec + ((size_t)blockIdx.x * LC + (size_t)c) * (size_t)P.nsslot * LROWS + sidx(s, g);      // (dpad == 256: the engine checks)
-        auto slot_ptr = [&](int slot) { return my_scr + (size_t)slot * LROWS; };
         double* const my_pv = P.pvec + (size_t)my_chain * NUM_PSLOT * P.dpad;
-        bool rowv[4];
+        // byte offset of (slot, stripe h) of my chain in the block's scratch
+        auto soff = [&](int slot, int h) { return ((c * nss + slot) * LROWS + sidx(w * SPW + h, g)) * 8; };
+        auto ldS = [&](Vec4& v, int slot, int h) {
+            const int o = soff(slot, h);
+            const double2 a = buf_load2(rscr, o, 0), b = buf_load2(rscr, o + 16, 0);
+            v.a[0] = a.x; v.a[1] = a.y; v.a[2] = b.x; v.a[3] = b.y;
+        };
+        auto stS = [&](const Vec4& v, int slot, int h) {
+            const int o = soff(slot, h);
+            buf_store2(rscr, o, 0, v.a[0], v.a[1]); buf_store2(rscr, o + 16, 0, v.a[2], v.a[3]);
+        };
+        Vec4 cz[SPW], cv[SPW], cg[SPW], pz[SPW], pvv[SPW], zin[SPW], vh[SPW], fx[SPW], fgx[SPW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowv[r] = 16 * s + g + 4 * r < dim;
-        Pt4 cur, prev;
-        Vec4 zin, vh;
+        for (int h = 0; h < SPW; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { cur.z.a[r] = cur.v.a[r] = cur.g.a[r] = prev.z.a[r] = prev.v.a[r] = prev.g.a[r] = 0.; zin.a[r] = vh.a[r] = 0.; }
-        // the chain's current point (z, g_z) from its persistent slots (chains that must re-whiten first read x, g_x in their whitening round)
-        if (S.ch[c].live && S.ch[c].mode != M_WHITEN) { ld_nat(cur.z, my_pv + (size_t)P_Z * P.dpad, s, g, dim); ld_nat(cur.g, my_pv + (size_t)P_GZ * P.dpad, s, g, dim); }
+            for (int r = 0; r < 4; ++r) { cz[h].a[r] = cv[h].a[r] = cg[h].a[r] = pz[h].a[r] = pvv[h].a[r] = zin[h].a[r] = vh[h].a[r] = fx[h].a[r] = fgx[h].a[r] = 0.; }
         int round_mode = M_IDLE;          // what my column submitted in the round in flight
-        Vec4 fx, fgx;                     // the finished draw's x, g_x (between P1 and the next P3)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { fx.a[r] = 0.; fgx.a[r] = 0.; }
-
+#if NM_LOCK_PROF
+        unsigned long long lkp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lkp_t = __builtin_amdgcn_s_memtime(), lkp_rounds = 0;
+#endif
         for (;;) {
             // =====================================================================================================
-            // P2 (wavefront 0: the chains' state machines; wavefronts 1 .. NUNIT: momentum refreshes)
+            // P2 (wavefronts 0 .. 3: the state machines of four chains each; wavefronts 4 .. 7: momentum refreshes)
             // =====================================================================================================
-            if (s == 0) {
-                if (l < LC) {
-                    LkChain& K = S.ch[l];
-                    if (K.start_draw) { S.unit_busy[K.v_unit] = 0; K.v_unit = -1; K.v_ready = 0; }      // P3 took the normals
-                    K.finish = 0; K.start_draw = 0;
-                    if (K.live) {
-                        Logic L(P, S, l);
-                        L.rng_begin();
-                        if (round_mode == M_LEAF) L.leaf_done();
-                        else if (round_mode == M_RECOMP || round_mode == M_KEEP) L.draw_done();
-                        else if (round_mode == M_WHITEN) {
-                            ChainScalars& q = S.sc[l];
-                            q.logdet = q.mm_logdet; q.transform_id = q.mm_id;
-                            K.mode = M_START;
-                        }
-                        L.rng_end();
-                        // where the NEXT draw's momentum refresh starts in the stream: behind this draw's step-size jitter
-                        if (K.v_unit < 0) {
-                            if (K.mode == M_START) K.v_pos_start = K.rng_pos;
-                            else if (K.mode == M_RECOMP || K.mode == M_KEEP) K.v_pos_start = K.rng_pos + (uint64_t)jitter_words;
-                        }
-                    }
-                }
-            } else if (s <= NUNIT) {
-                refresh_unit(P, S, s - 1);
+            if (w < 4) {                                           // (lane = chain, as everywhere: the chain's ring column and record)
+                if (l < LC && (l >> 2) == w) logic_round(P, S, l, round_mode, jitter_words);
+            } else if (w < 4 + NUNIT) {
+                refresh_unit(P, S, w - 4);
             }
+            NM_LKP(0)
             blk_barrier();
+            NM_LKP(1)
             // ---- P2b (wavefront 0): chains whose normals are ready begin their tree; free refresh units are handed out
-            if (s == 0) {
+            if (w == 0) {
                 if (l < NUNIT && S.unit_chain[l] >= 0) S.unit_chain[l] = -1;       // served in the phase above
                 int want = 0;
                 if (l < LC) {
                     LkChain& K = S.ch[l];
-                    if (K.live && K.mode == M_START && K.v_unit >= 0 && K.v_ready) {
-                        Logic L(P, S, l);
-                        K.rng_pos = K.v_pos_after; K.rng_filled = K.v_pos_after >> 4;
-                        L.rng_begin();
-                        L.tree_begin();
-                        L.rng_end();
-                        K.start_draw = 1;                          // P3 takes the normals out of the unit
-                    }
+                    if (K.live && K.mode == M_START && K.v_unit >= 0 && K.v_ready) logic_start(P, S, l);
                     const bool more_draws = S.sc[l].draw_count + 1 < P.draw_end;
                     want = (K.live && K.v_unit < 0 && (K.mode == M_START || K.mode == M_WHITEN || ((K.mode == M_RECOMP || K.mode == M_KEEP) && more_draws))) ? 1 : 0;
                 }
@@ -738,186 +840,216 @@ __global__ __launch_bounds__(64 * LS, LS / 4) void nuts_lockstep_kernel(const KP
                 }
             }
             blk_barrier();
+            NM_LKP(2)
             if (S.all_idle) break;
             // =====================================================================================================
-            // P3 (every stripe): the stores the state machines asked for, the finished draws' rows, the next input column
+            // P3 (every wavefront, its stripes): the stores the state machines asked for, the finished draws' rows, the next input column
             // =====================================================================================================
+            GemmA G;
             {
                 const LkChain& K = S.ch[c];
-                if (round_mode == M_LEAF) {
-                    if (K.st_F_prev >= 0) { st_vec(prev.z, slot_ptr(K.st_F_prev)); st_vec(prev.v, slot_ptr(K.st_F_prev + 1)); }
-                    if (K.st_L_cur >= 0) { st_vec(cur.z, slot_ptr(K.st_L_cur)); st_vec(cur.v, slot_ptr(K.st_L_cur + 1)); }
-                    if (K.st_cand_cur >= 0) st_vec(cur.z, slot_ptr(K.st_cand_cur));
-                    if (K.st_cand_prev >= 0) st_vec(prev.z, slot_ptr(K.st_cand_prev));
-                    if (K.st_edge_cur >= 0) {
-                        st_vec(cur.z, slot_ptr(EDGE0_Z + 3 * K.st_edge_cur)); st_vec(cur.v, slot_ptr(EDGE0_V + 3 * K.st_edge_cur));
-                        st_vec(cur.g, slot_ptr(EDGE0_G + 3 * K.st_edge_cur));
-                    }
-                }
-                if (K.finish) {                                    // the draw: fx, fgx, cur.z, cur.g
-                    const size_t row = (size_t)(K.finish_row * P.n_chains + my_chain) * P.dim;
-                    if (P.out_positions) st_nat(fx, P.out_positions + row, s, g, dim);
-                    if (P.out_gradient) st_nat(fgx, P.out_gradient + row, s, g, dim);
-                    if (P.out_tpos) st_nat(cur.z, P.out_tpos + row, s, g, dim);
-                    if (P.out_tgrad) st_nat(cur.g, P.out_tgrad + row, s, g, dim);
-                    if (round_mode == M_RECOMP) {
-                        st_nat(fx, my_pv + (size_t)P_X * P.dpad, s, g, dim); st_nat(fgx, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
-                        st_nat(cur.z, my_pv + (size_t)P_Z * P.dpad, s, g, dim); st_nat(cur.g, my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
-                    }
-                }
-                if (round_mode == M_WHITEN) {                      // the re-whitened point is the chain's current point from now on
-                    st_nat(cur.z, my_pv + (size_t)P_Z * P.dpad, s, g, dim); st_nat(cur.g, my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
-                }
-                if (K.start_draw) {                                // initialize_trajectory: fresh momentum, the initial point is edge 0
-                    const double* samp = S.rf_samp[K.v_unit];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cur.v.a[r] = rowv[r] ? 1.0 * samp[16 * s + g + 4 * r] : 0.0;
-                    st_vec(cur.z, slot_ptr(EDGE0_Z)); st_vec(cur.v, slot_ptr(EDGE0_V)); st_vec(cur.g, slot_ptr(EDGE0_G));
-                }
                 const int mode = K.mode;
-                int which = 0;
+                const int st_F = K.st_F_prev, st_L = K.st_L_cur, st_cc = K.st_cand_cur, st_cp = K.st_cand_prev, st_e = K.st_edge_cur;
+                const int fin = K.finish, sd = K.start_draw, le = K.load_edge, vunit = K.v_unit, rsrc_ = K.rc_src, rslot = K.rc_slot;
+                const double eps = K.eps, half = eps / 2.;
+                const size_t row = (size_t)(K.finish_row * P.n_chains + my_chain) * P.dim;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zin.a[r] = 0.0;
-                if (mode == M_LEAF) {
-                    if (K.load_edge >= 0) {
-                        ld_vec(cur.z, slot_ptr(EDGE0_Z + 3 * K.load_edge)); ld_vec(cur.v, slot_ptr(EDGE0_V + 3 * K.load_edge));
-                        ld_vec(cur.g, slot_ptr(EDGE0_G + 3 * K.load_edge));
+                for (int h = 0; h < SPW; ++h) {
+                    const int s = w * SPW + h;
+                    if (round_mode == M_LEAF) {
+                        if (st_F >= 0) { stS(pz[h], st_F, h); stS(pvv[h], st_F + 1, h); }
+                        if (st_L >= 0) { stS(cz[h], st_L, h); stS(cv[h], st_L + 1, h); }
+                        if (st_cc >= 0) stS(cz[h], st_cc, h);
+                        if (st_cp >= 0) stS(pz[h], st_cp, h);
+                        if (st_e >= 0) { stS(cz[h], EDGE0_Z + 3 * st_e, h); stS(cv[h], EDGE0_V + 3 * st_e, h); stS(cg[h], EDGE0_G + 3 * st_e, h); }
                     }
-                    const double eps = K.eps, half = eps / 2.;
+                    if (fin) {                                     // the draw: fx, fgx, cz, cg
+                        if (P.out_positions) st_nat(fx[h], P.out_positions + row, s, g, dim);
+                        if (P.out_gradient) st_nat(fgx[h], P.out_gradient + row, s, g, dim);
+                        if (P.out_tpos) st_nat(cz[h], P.out_tpos + row, s, g, dim);
+                        if (P.out_tgrad) st_nat(cg[h], P.out_tgrad + row, s, g, dim);
+                        if (round_mode == M_RECOMP) {
+                            st_nat(fx[h], my_pv + (size_t)P_X * P.dpad, s, g, dim); st_nat(fgx[h], my_pv + (size_t)P_GX * P.dpad, s, g, dim);
+                            st_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); st_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+                        }
+                    }
+                    if (round_mode == M_WHITEN) {                  // the re-whitened point is the chain's current point from now on
+                        st_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); st_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+                    }
+                    if (sd) {                                      // initialize_trajectory: fresh momentum, the initial point is edge 0
+                        const double* samp = S.rf_samp[vunit];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        vh.a[r] = __builtin_fma(half, cur.g.a[r], cur.v.a[r]);
-                        zin.a[r] = __builtin_fma(eps, vh.a[r], cur.z.a[r]);
+                        for (int r = 0; r < 4; ++r) { const int d = 16 * s + g + 4 * r; cv[h].a[r] = d < dim ? 1.0 * samp[d] : 0.0; }
+                        // (the chain's current point comes from its persistent slots, not from registers kept alive across its waiting rounds)
+                        ld_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); ld_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+                        stS(cz[h], EDGE0_Z, h); stS(cv[h], EDGE0_V, h); stS(cg[h], EDGE0_G, h);
                     }
-                } else if (mode == M_RECOMP) {
-                    if (K.rc_src == RC_POOL) ld_vec(zin, slot_ptr(K.rc_slot));
-                    else ld_nat(zin, my_pv + (size_t)P_Z * P.dpad, s, g, dim);
-                } else if (mode == M_WHITEN) {                     // compute_transformed_position's diagonal part (low_rank.rs:325-347)
-                    Vec4 x0;
-                    ld_nat(x0, my_pv + (size_t)P_X * P.dpad, s, g, dim);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int d = 16 * s + g + 4 * r;
-                        const double t = __builtin_fma(-1.0, S.mu[d], x0.a[r]);
-                        const double zz = S.isig[d] * t;
-                        zin.a[r] = rowv[r] ? __builtin_fma(-1.0, S.mul[d], zz) : 0.0;
+                    for (int r = 0; r < 4; ++r) zin[h].a[r] = 0.0;
+                    if (mode == M_LEAF) {
+                        if (le >= 0) { ldS(cz[h], EDGE0_Z + 3 * le, h); ldS(cv[h], EDGE0_V + 3 * le, h); ldS(cg[h], EDGE0_G + 3 * le, h); }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            vh[h].a[r] = __builtin_fma(half, cg[h].a[r], cv[h].a[r]);
+                            zin[h].a[r] = __builtin_fma(eps, vh[h].a[r], cz[h].a[r]);
+                        }
+                    } else if (mode == M_RECOMP) {
+                        if (rsrc_ == RC_POOL) ldS(zin[h], rslot, h);
+                        else ld_nat(zin[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim);
+                    } else if (mode == M_WHITEN) {                 // compute_transformed_position's diagonal part (low_rank.rs:325-347)
+                        Vec4 x0;
+                        ld_nat(x0, my_pv + (size_t)P_X * P.dpad, s, g, dim);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int d = 16 * s + g + 4 * r;
+                            const double t = __builtin_fma(-1.0, S.mu[d], x0.a[r]);
+                            const double zz = S.isig[d] * t;
+                            zin[h].a[r] = d < dim ? __builtin_fma(-1.0, S.mul[d], zz) : 0.0;
+                        }
                     }
-                    which = 1;
+                    put_stripe(S.t[0], s, zin[h]);
                 }
-                if (s == 0 && g == 0) S.which[c] = which;
+                if (w == 0 && g == 0) S.which[c] = mode == M_WHITEN ? 1 : 0;
                 round_mode = mode;
             }
-            put_stripe(S.t[0], s, zin);
+            NM_LKP(3)
             blk_barrier();
+            NM_LKP(4)
             // =====================================================================================================
             // the five products
             // =====================================================================================================
+            v4d acc[SPW];
             {   // S = U' zin, scaled (lambda^w - 1) on its way out
-                v4d acc = {0.0, 0.0, 0.0, 0.0};
-                if (s < M.rank_st) acc = gemm_stripe(M.ut, s, M.dim_kp, S.t[0], acc);
+#pragma unroll
+                for (int h = 0; h < SPW; ++h) acc[h] = v4d{0.0, 0.0, 0.0, 0.0};
+                gemm_stripes(G, M.ut, w, M.rank_st, M.dim_kp, S.t[0], acc);
                 const double* scl = S.scale[S.which[c] & 1];
-                Vec4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o.a[r] = acc[r] * scl[16 * s + g + 4 * r];
-                put_stripe(S.t[1], s, o);
-            }
-            blk_barrier();
-            Vec4 x, y;
-            {   // xt = zin + U S ; x = sigma (xt + mu_lr) + mean  (compute_untransformed_position: low_rank.rs:349-375, diagonal.rs:248-257)
-                v4d acc = {zin.a[0], zin.a[1], zin.a[2], zin.a[3]};
-                if (s < M.dim_st) acc = gemm_stripe(M.u, s, M.rank_kp, S.t[1], acc);
-                Vec4 xs;
+                for (int h = 0; h < SPW; ++h) {
+                    Vec4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 16 * s + g + 4 * r;
-                    if (round_mode == M_WHITEN) zin.a[r] = acc[r];         // the whitened z itself
-                    const double t = __builtin_fma(1.0, S.mul[d], acc[r]);
-                    x.a[r] = __builtin_fma(1.0, S.mu[d], t * S.sig[d]);
-                    xs.a[r] = (rowv[r] && (round_mode == M_LEAF || round_mode == M_RECOMP)) ? x.a[r] : 0.0;
+                    for (int r = 0; r < 4; ++r) o.a[r] = acc[h][r] * scl[16 * (w * SPW + h) + g + 4 * r];
+                    put_stripe(S.t[1], w * SPW + h, o);
                 }
-                put_stripe(S.t[0], s, xs);                         // (every stripe has passed the barrier behind the first product: tile A is free)
             }
             blk_barrier();
-            {   // y = P x ; t3 = sigma (-y)
-                v4d acc = {0.0, 0.0, 0.0, 0.0};
-                if (s < M.dim_st) acc = gemm_stripe(M.p, s, M.dim_kp, S.t[0], acc);
+            Vec4 x[SPW], y[SPW];
+            {   // xt = zin + U S ; x = sigma (xt + mu_lr) + mean  (compute_untransformed_position: low_rank.rs:349-375, diagonal.rs:248-257)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y.a[r] = acc[r];
+                for (int h = 0; h < SPW; ++h) acc[h] = v4d{zin[h].a[0], zin[h].a[1], zin[h].a[2], zin[h].a[3]};
+                gemm_stripes(G, M.u, w, M.dim_st, M.rank_kp, S.t[1], acc);
+#pragma unroll
+                for (int h = 0; h < SPW; ++h) {
+                    Vec4 xs;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = 16 * (w * SPW + h) + g + 4 * r;
+                        if (round_mode == M_WHITEN) zin[h].a[r] = acc[h][r];       // the whitened z itself
+                        const double t = __builtin_fma(1.0, S.mul[d], acc[h][r]);
+                        x[h].a[r] = __builtin_fma(1.0, S.mu[d], t * S.sig[d]);
+                        xs.a[r] = (d < dim && (round_mode == M_LEAF || round_mode == M_RECOMP)) ? x[h].a[r] : 0.0;
+                    }
+                    put_stripe(S.t[0], w * SPW + h, xs);           // (every wavefront has passed the barrier behind the first product: tile A is free)
+                }
             }
-            Vec4 t3, gx;
+            blk_barrier();
+            {   // y = P x
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { gx.a[r] = 0.0; t3.a[r] = 0.0; }
-            if (round_mode == M_WHITEN) {
-                Vec4 g0;
-                ld_nat(g0, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
+                for (int h = 0; h < SPW; ++h) acc[h] = v4d{0.0, 0.0, 0.0, 0.0};
+                gemm_stripes(G, M.p, w, M.dim_st, M.dim_kp, S.t[0], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t3.a[r] = g0.a[r] * S.sig[16 * s + g + 4 * r];
-            } else if (round_mode == M_LEAF || round_mode == M_RECOMP) {
+                for (int h = 0; h < SPW; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { gx.a[r] = rowv[r] ? -y.a[r] : 0.0; t3.a[r] = gx.a[r] * S.sig[16 * s + g + 4 * r]; }
+                    for (int r = 0; r < 4; ++r) y[h].a[r] = acc[h][r];
             }
-            put_stripe(S.t[1], s, t3);
+            Vec4 t3[SPW], gx[SPW];
+#pragma unroll
+            for (int h = 0; h < SPW; ++h) {
+                const int s = w * SPW + h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { gx[h].a[r] = 0.0; t3[h].a[r] = 0.0; }
+                if (round_mode == M_WHITEN) {
+                    Vec4 g0;
+                    ld_nat(g0, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t3[h].a[r] = g0.a[r] * S.sig[16 * s + g + 4 * r];
+                } else if (round_mode == M_LEAF || round_mode == M_RECOMP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int d = 16 * s + g + 4 * r; gx[h].a[r] = d < dim ? -y[h].a[r] : 0.0; t3[h].a[r] = gx[h].a[r] * S.sig[d]; }
+                }
+                put_stripe(S.t[1], s, t3[h]);
+            }
             blk_barrier();
             {   // S' = U' t3, scaled with lambda^(1/2) - 1 (the gradient's application, every mode)
-                v4d acc = {0.0, 0.0, 0.0, 0.0};
-                if (s < M.rank_st) acc = gemm_stripe(M.ut, s, M.dim_kp, S.t[1], acc);
-                Vec4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o.a[r] = acc[r] * S.scale[0][16 * s + g + 4 * r];
-                put_stripe(S.t[0], s, o);
+                for (int h = 0; h < SPW; ++h) acc[h] = v4d{0.0, 0.0, 0.0, 0.0};
+                gemm_stripes(G, M.ut, w, M.rank_st, M.dim_kp, S.t[1], acc);
+#pragma unroll
+                for (int h = 0; h < SPW; ++h) {
+                    Vec4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.a[r] = acc[h][r] * S.scale[0][16 * (w * SPW + h) + g + 4 * r];
+                    put_stripe(S.t[0], w * SPW + h, o);
+                }
             }
             blk_barrier();
-            Vec4 gz;
+            Vec4 gz[SPW];
             {   // g_z = t3 + U S'
-                v4d acc = {t3.a[0], t3.a[1], t3.a[2], t3.a[3]};
-                if (s < M.dim_st) acc = gemm_stripe(M.u, s, M.rank_kp, S.t[0], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gz.a[r] = acc[r];
+                for (int h = 0; h < SPW; ++h) acc[h] = v4d{t3[h].a[0], t3[h].a[1], t3[h].a[2], t3[h].a[3]};
+                gemm_stripes(G, M.u, w, M.dim_st, M.rank_kp, S.t[0], acc);
+#pragma unroll
+                for (int h = 0; h < SPW; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gz[h].a[r] = acc[h][r];
             }
             blk_barrier();                                         // the tiles become the partial-sum buffer
+            NM_LKP(5)
             // =====================================================================================================
-            // P1 (every stripe): finish the leapfrog, partial sums of the round (passes of NRED slots)
+            // P1 (every wavefront, its stripes): finish the leapfrog, partial sums of the round (passes of NRED slots)
             // =====================================================================================================
             double* const red = S.t[0];                            // [stripe][slot][chain]: 16 x 32 x 16 doubles = both tiles
-            auto emit = [&](int j, double p) {
+            auto emit = [&](int s, int j, double p) {
                 const double tot = stripe_sum(p);
                 if (g == 0) red[((size_t)s * NRED + j) * LC + c] = tot;
             };
             const LkChain& K1 = S.ch[c];
+            const int k_n = K1.n, k_depth = K1.depth, k_fwd = K1.fwd, k_check = K1.check, k_ls = K1.left_slot, k_rs = K1.right_slot;
+            const double half1 = K1.eps / 2.;
             int ngroups = 0;                                       // U-turn test groups of my column's leaf
-            prev = cur;
-            if (round_mode == M_LEAF) {
-                const double half = K1.eps / 2.;
-                double ke = 0., xy = 0., ki = 0., t1 = 0., t2 = 0.;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cur.z.a[r] = zin.a[r];
-                    cur.g.a[r] = gz.a[r];
-                    cur.v.a[r] = __builtin_fma(half, gz.a[r], vh.a[r]);
-                    ke = __builtin_fma(cur.v.a[r], cur.v.a[r], ke);
-                    xy = xy + (rowv[r] ? x.a[r] * y.a[r] : 0.0);
-                    ki = __builtin_fma(prev.v.a[r], prev.v.a[r], ki);
-                    turn_acc(prev.z.a[r], prev.v.a[r], cur.z.a[r], cur.v.a[r], t1, t2);
-                }
-                emit(0, ke); emit(1, xy); emit(2, ki); emit(4, t1); emit(5, t2);
-                if (K1.check && (K1.n & 1)) {
-                    const int t = (int)__builtin_ctz(~(unsigned)K1.n);
-                    ngroups = t - 1;                               // levels 2 .. t
-                    if ((K1.n + 1) == (1 << K1.depth)) ngroups += 1;   // + the top-level tests of the finished doubling
-                }
-            } else if (round_mode == M_RECOMP || round_mode == M_WHITEN) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cur.z.a[r] = zin.a[r]; cur.g.a[r] = gz.a[r]; }
-                fx = x; fgx = gx;
-            } else if (round_mode == M_KEEP) {                     // the stored point
-                ld_nat(fx, my_pv + (size_t)P_X * P.dpad, s, g, dim); ld_nat(fgx, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
-                ld_nat(cur.z, my_pv + (size_t)P_Z * P.dpad, s, g, dim); ld_nat(cur.g, my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+            if (round_mode == M_LEAF && k_check && (k_n & 1)) {
+                const int t = (int)__builtin_ctz(~(unsigned)k_n);
+                ngroups = t - 1;                                   // levels 2 .. t
+                if ((k_n + 1) == (1 << k_depth)) ngroups += 1;     // + the top-level tests of the finished doubling
             }
-            if (round_mode == M_RECOMP || round_mode == M_KEEP) {
-                double fd = 0.;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) fd = fd + (cur.z.a[r] + cur.g.a[r]) * (cur.z.a[r] + cur.g.a[r]);
-                emit(0, fd);
+            for (int h = 0; h < SPW; ++h) {
+                const int s = w * SPW + h;
+                pz[h] = cz[h]; pvv[h] = cv[h];
+                cz[h] = zin[h]; cg[h] = gz[h];                     // every column: nothing of the old point stays live across the products
+                fx[h] = x[h]; fgx[h] = gx[h];
+                if (round_mode == M_LEAF) {
+                    double ke = 0., xy = 0., ki = 0., t1 = 0., t2 = 0.;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = 16 * s + g + 4 * r;
+                        cv[h].a[r] = __builtin_fma(half1, gz[h].a[r], vh[h].a[r]);
+                        ke = __builtin_fma(cv[h].a[r], cv[h].a[r], ke);
+                        xy = xy + (d < dim ? x[h].a[r] * y[h].a[r] : 0.0);
+                        ki = __builtin_fma(pvv[h].a[r], pvv[h].a[r], ki);
+                        turn_acc(pz[h].a[r], pvv[h].a[r], cz[h].a[r], cv[h].a[r], t1, t2);
+                    }
+                    emit(s, 0, ke); emit(s, 1, xy); emit(s, 2, ki); emit(s, 4, t1); emit(s, 5, t2);
+                } else if (round_mode == M_KEEP) {                 // the stored point
+                    ld_nat(fx[h], my_pv + (size_t)P_X * P.dpad, s, g, dim); ld_nat(fgx[h], my_pv + (size_t)P_GX * P.dpad, s, g, dim);
+                    ld_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); ld_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+                }
+                if (round_mode == M_RECOMP || round_mode == M_KEEP) {
+                    double fd = 0.;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fd = fd + (cz[h].a[r] + cg[h].a[r]) * (cz[h].a[r] + cg[h].a[r]);
+                    emit(s, 0, fd);
+                }
             }
             int npass = (ngroups + GROUPS_PER_PASS - 1) / GROUPS_PER_PASS;
             for (int o = 1; o < 64; o <<= 1) { const int q = __shfl_xor(npass, o); npass = q > npass ? q : npass; }
@@ -925,51 +1057,61 @@ __global__ __launch_bounds__(64 * LS, LS / 4) void nuts_lockstep_kernel(const KP
             npass = __builtin_amdgcn_readfirstlane(npass);
             for (int pass = 0; pass < npass; ++pass) {
                 // the groups of this pass: group i (0-based over the leaf's list) = level k = i + 2 for i < t - 1, then the top level
-                if (round_mode == M_LEAF && ngroups > pass * GROUPS_PER_PASS) {
-                    const int n = K1.n, depth = K1.depth, fwd = K1.fwd;
-                    const int t = (int)__builtin_ctz(~(unsigned)n);
+                if (ngroups > pass * GROUPS_PER_PASS) {
+                    const int t = (int)__builtin_ctz(~(unsigned)k_n);
                     for (int gi = 0; gi < GROUPS_PER_PASS; ++gi) {
                         const int i = pass * GROUPS_PER_PASS + gi;
                         if (i < ngroups) {
                             int za, zl, zb;
                             if (i < t - 1) {                       // sub-tree merge of level k (src/nuts.rs:143-161; nuts_lane.hpp l_transition)
                                 const int k = i + 2;
-                                const unsigned a_first = (unsigned)n + 1u - (1u << k);
-                                za = slot_F(a_first == 0 ? depth : (int)__builtin_ctz(a_first));
+                                const unsigned a_first = (unsigned)k_n + 1u - (1u << k);
+                                za = slot_F(a_first == 0 ? k_depth : (int)__builtin_ctz(a_first));
                                 zl = slot_L(MD, k - 1);
                                 zb = k == 2 ? -1 : slot_F(k - 1);
                             } else {                               // the main tree against the finished sub-tree
-                                const int ls = K1.left_slot, rs = K1.right_slot;
-                                za = EDGE0_Z + 3 * (fwd ? ls : rs);
-                                zl = EDGE0_Z + 3 * (fwd ? rs : ls);
-                                zb = depth == 1 ? -1 : slot_F(depth);
+                                za = EDGE0_Z + 3 * (k_fwd ? k_ls : k_rs);
+                                zl = EDGE0_Z + 3 * (k_fwd ? k_rs : k_ls);
+                                zb = k_depth == 1 ? -1 : slot_F(k_depth);
                             }
-                            Vec4 az, av, lz, lvv, bz, bv;
-                            ld_vec(az, slot_ptr(za)); ld_vec(av, slot_ptr(za + 1));
-                            ld_vec(lz, slot_ptr(zl)); ld_vec(lvv, slot_ptr(zl + 1));
-                            if (zb >= 0) { ld_vec(bz, slot_ptr(zb)); ld_vec(bv, slot_ptr(zb + 1)); } else { bz = prev.z; bv = prev.v; }
-                            double a6[6];
-                            turn_group(az, av, lz, lvv, bz, bv, cur.z, cur.v, a6);
 #pragma unroll
-                            for (int j = 0; j < 6; ++j) emit(8 + 6 * gi + j, a6[j]);
+                            for (int h = 0; h < SPW; ++h) {
+                                Vec4 az, av, lz, lvv, bz, bv;
+                                ldS(az, za, h); ldS(av, za + 1, h);
+                                ldS(lz, zl, h); ldS(lvv, zl + 1, h);
+                                if (zb >= 0) { ldS(bz, zb, h); ldS(bv, zb + 1, h); } else { bz = pz[h]; bv = pvv[h]; }
+                                double a6[6];
+                                turn_group(az, av, lz, lvv, bz, bv, cz[h], cv[h], a6);
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) emit(w * SPW + h, 8 + 6 * gi + j, a6[j]);
+                            }
                         }
                     }
                 }
                 blk_barrier();
                 {   // thread (slot j, chain cc) adds the 16 stripes in stripe order
                     const int T = (int)threadIdx.x;
-                    if (T < NRED * LC) {
-                        const int j = T / LC, cc = T % LC;
-                        double tot = red[(size_t)j * LC + cc];
+                    static_assert(NT == NRED * LC, "one thread per (slot, chain)");
+                    const int j = T / LC, cc = T % LC;
+                    double tot = red[(size_t)j * LC + cc];
 #pragma unroll
-                        for (int st = 1; st < LS; ++st) tot = tot + red[((size_t)st * NRED + j) * LC + cc];
-                        const int dst = j < 8 ? (pass == 0 ? j : -1) : 8 + 6 * GROUPS_PER_PASS * pass + (j - 8);
-                        if (dst >= 0 && dst < NSUM) S.sums[cc][dst] = tot;
-                    }
+                    for (int st = 1; st < LS; ++st) tot = tot + red[((size_t)st * NRED + j) * LC + cc];
+                    const int dst = j < 8 ? (pass == 0 ? j : -1) : 8 + 6 * GROUPS_PER_PASS * pass + (j - 8);
+                    if (dst >= 0 && dst < NSUM) S.sums[cc][dst] = tot;
                 }
                 blk_barrier();
             }
+            NM_LKP(6)
+#if NM_LOCK_PROF
+            lkp_rounds += 1;
+#endif
         }
+#if NM_LOCK_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int i = 0; i < 8; ++i) (void)__hip_atomic_fetch_add(&P.prof[i], lkp_acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&P.prof[8], lkp_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         // ---- the tile is done: the chains' records go back
         __syncthreads();
         if (threadIdx.x < LC) {

@@ -90,6 +90,19 @@ def main():
                             "chain_code_frac": chain_ / tot, "barrier_wait_frac": wait_ / tot, "matrix_product_frac": mma_ / tot,
                             "idle_column_between_rounds_frac": idle_ / tot, "rendezvous_of_wave0": rounds_,
                             "cycles_per_wave_round": tot / max(rounds_, 1.0) / 16.0}
+    if os.environ.get("NM_LOCK_PROF"):     # a -DNM_LOCK_PROF=1 build of kern_lockstep.hip: where does a round of wavefront 0, block 0 go?
+        import ctypes as Ct
+        from nuts_rs_amd import _lib
+        L = _lib.load()
+        L.nm_debug_read_prof.argtypes = [Ct.c_void_p, Ct.c_void_p]
+        buf = np.zeros(32, dtype=np.uint64)
+        L.nm_debug_read_prof(b._h, buf.ctypes.data)
+        names = ["logic (P2) / refresh", "wait: barrier behind P2", "unit hand-out + barrier", "P3", "wait: barrier before the products", "five products", "P1 + stripe reductions"]
+        tot = float(buf[:7].sum())
+        rounds = float(buf[8]) or 1.0
+        out["lock_prof"] = {"rounds_block0": rounds, "cycles_per_round": tot / rounds, "note": "s_memtime ticks = shader cycles (2.4 GHz) of wavefront 0 of block 0, both launches",
+                            "us_per_round": tot / rounds / 2400.0,
+                            "phases": {n: float(buf[i]) / tot for i, n in enumerate(names)}}
     print(json.dumps(out))
     b.close()
 

@@ -14,6 +14,6 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT -o write -- python tools/bench_k5.py "$@" > $
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT -o tcc -- python tools/bench_k5.py "$@" > $OUT/tcc_stdout.log 2>&1
 D=$(dirname $(find $OUT -name trace_results.db | head -1))
 python tools/rocprof_summary.py trace $D/trace_results.db $OUT/kernel_trace.txt > /dev/null
-python tools/rocprof_summary.py k5 $D $OUT/pmc_k5.json "${KSUB:-nuts_tile_draw_kernel}" $OUT
+python tools/rocprof_summary.py k5 $D $OUT/pmc_k5.json "${KSUB:-nuts_lockstep_kernel}" $OUT
 cat $OUT/bench.json
 find $OUT -name "*_results.db" -delete   # the summaries are what travels back (gpurun merges at most 64 MiB)
