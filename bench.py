@@ -82,7 +82,9 @@ def parse():
     p.add_argument("--other-configs", default="k3,k4_65536,k4_8192,k5", help="comma list of OTHER_CONFIGS keys reported in `other_configs` (rank 0, N = 1); none = skip")
     p.add_argument("--other-steps", type=int, default=100, help="timed draws of each other config")
     p.add_argument("--other-budget", type=float, default=150.0, help="seconds the other configs (runs + counter passes) may take in all")
-    p.add_argument("--config", default="k2", help=argparse.SUPPRESS)            # with --pmc-child: which workload this child runs
+    p.add_argument("--config", default="k2", help="k2 (the headline line; default) | k4: BASELINE's 8-schools configuration, 65536 chains sharded over the "
+                                                  "ranks (strong scaling), with --pooled the opt-in pooled adaptation: ONE RCCL all_gather per window")
+    p.add_argument("--pooled", action="store_true", help="--config k4: warm up with the cross-chain pooled Welford reduction (nuts_rs_amd/pooled.py)")
     return p.parse_args()
 
 
@@ -470,6 +472,76 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def main_k4(args, N, torch, dist, rank, world, device_index, red_dev, barrier):
+    """BASELINE configs[3]: hierarchical 8 schools (non-centered, dim 10), 65536 chains sharded over the ranks, RCCL only for the
+    cross-chain adaptation reduction.  Strong scaling: the job's 65536 chains are split, `value` = all ranks' steps x dims / max time.
+    --pooled: the warm-up pools the chains' Welford statistics over ALL ranks, one all_gather per window (not reference behaviour:
+    every reference chain adapts alone; opt-in)."""
+    total = 65536
+    C_ = total // world
+    logp = N.LogpSpec.eight_schools()
+    D = logp.dim
+    n_draws = args.steps * max(1, args.repeats) + args.warmup
+    if args.pooled:
+        from nuts_rs_amd import pooled
+        settings = N.LowRankNutsSettings(num_chains=total, seed=args.seed, num_tune=args.num_tune, num_draws=n_draws, freeze_transform=True)
+    else:
+        settings = N.DiagNutsSettings(num_chains=total, seed=args.seed, num_tune=args.num_tune, num_draws=n_draws)
+    batch = N.ChainBatch(settings, logp, C_, chain_id_offset=rank * C_, device=device_index)
+    assert (batch.set_position(batch.init_positions_uniform()) == 0).all()
+    barrier()
+    t0 = time.perf_counter()
+    n_updates = 0
+    if args.pooled:
+        n_updates = len(pooled.pooled_warmup(batch, args.num_tune, dist=dist, collective_device=None if args.dist_backend == "nccl" else "cpu"))
+    else:
+        batch.draw_device(args.num_tune)
+    barrier()
+    t_tune = time.perf_counter() - t0
+    if args.warmup:
+        batch.draw_device(args.warmup)
+    d_pos = torch.empty((args.steps, C_, D), dtype=torch.float64, device=f"cuda:{device_index}")
+    d_st = torch.zeros((args.steps, C_, N.STATS_DTYPE.itemsize), dtype=torch.uint8, device=f"cuda:{device_index}")
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        batch.reset_counters()
+        barrier()
+        t0 = time.perf_counter()
+        batch.draw_device(args.steps, d_pos.data_ptr(), d_st.data_ptr(), sync=False)
+        batch.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        steps_local = float(batch.counters()["total_leapfrogs"])
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sv = torch.tensor([steps_local], dtype=torch.float64, device=red_dev); dist.all_reduce(sv, op=dist.ReduceOp.SUM)
+            reps.append((float(t.item()), float(sv.item())))
+        else:
+            reps.append((el, steps_local))
+    if rank == 0:
+        rates = [sv * D / el for el, sv in reps]
+        mid = int(np.argsort(rates)[len(rates) // 2])
+        el, sv = reps[mid]
+        print(json.dumps({
+            "metric": "leapfrog-steps*dims/sec at 65536 chains x dim 10 (8 schools, post-warm-up NUTS draws)", "value": rates[mid],
+            "unit": "leapfrog-steps*dims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"K4: hierarchical 8 schools non-centered dim 10, 65536 chains sharded x{world} ({C_} per GPU), "
+                                   f"{'pooled cross-chain adaptation: one RCCL all_gather per window' if args.pooled else 'per-chain DiagNutsSettings adaptation, no collective'}, "
+                                   f"num_tune {args.num_tune}, seed {args.seed}",
+                       "chains_per_gpu": C_, "dim": D, "pooled": bool(args.pooled), "pooled_updates": n_updates, "backend": args.dist_backend,
+                       "kernels": {"lane_launches": batch.lane_launches(), "group_launches": batch.group_launches()}},
+            "leapfrogs_per_s": sv / el, "leapfrogs_per_draw": sv / (args.steps * total),
+            "repeats": {"n": len(reps), "reported": "median", "values": rates},
+            "adaptation": {"draws": args.num_tune, "seconds": t_tune},
+            "roofline": None, "cpu_baseline": None}))
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -512,6 +584,9 @@ def main():
         r = run_other_config(args.config, args.seed, args.steps, args.warmup, record=not args.no_record)
         print(json.dumps({"pmc_child": True, "config": args.config, "steps": r["total_leapfrogs"], "kernel_ms": r["kernel_ms_per_launch"]}))
         return
+
+    if args.config == "k4":
+        return main_k4(args, N, torch, dist, rank, world, device_index, red_dev, barrier)
 
     C_, D = args.chains, args.dim
     settings = N.DiagNutsSettings(num_chains=C_ * world, seed=args.seed, num_tune=args.num_tune,

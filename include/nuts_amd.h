@@ -603,6 +603,15 @@ nm_status nm_probe_bandwidth(uint64_t kind, uint64_t bytes_per_array, uint64_t i
  * ------------------------------------------------------------------------------------------- */
 nm_status nm_pooled_partials(uint64_t n_rows, uint64_t dim, const double* d_positions, const double* d_gradients,
                              const nm_draw_stats* d_stats, double* d_out, void* stream);
+/* The exchange and the merge of the pooled adaptation, for callers that do not go through nuts_rs_amd/pooled.py (a Rust host with
+ * its own RCCL communicator).  nm_pooled_exchange: one all_gather of the rank's payload d_payload[2][1 + 2 dim] into
+ * d_gathered[world][2][1 + 2 dim] over `rccl_comm` (an ncclComm_t; librccl is resolved at run time) on `stream`; with world == 1 or a
+ * null communicator the payload is copied.  nm_pooled_finish: merges the gathered partials in RANK ORDER (Chan; empty partials are
+ * skipped) and writes the pooled diagonal transformation — d_sigma[dim] = (var draws / var grads)^(1/4) clamped to [1e-10, 1e10]
+ * (1 where that is not finite and positive), d_mean[dim] = mean draws + sigma^2 mean grads, *d_count = pooled draws — what the
+ * caller hands to nm_engine_set_transform (n_eig = 0) when the count is at least 3.  Both asynchronous on `stream`. */
+nm_status nm_pooled_exchange(void* rccl_comm, uint64_t world, uint64_t dim, const double* d_payload, double* d_gathered, void* stream);
+nm_status nm_pooled_finish(uint64_t world, uint64_t dim, const double* d_gathered, double* d_sigma, double* d_mean, double* d_count, void* stream);
 const char* nm_pooled_last_error(void);
 
 const char* nm_last_error(void);

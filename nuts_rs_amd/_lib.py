@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_lowrank_test_spd_mean", "nm_lowrank_test_estimate_mass_matrix", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
-    "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_lockstep_launches", "nm_engine_reduce_order", "nm_engine_host_logp_calls", "nm_pooled_partials", "nm_pooled_last_error",
+    "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_lockstep_launches", "nm_engine_reduce_order", "nm_engine_host_logp_calls", "nm_pooled_partials", "nm_pooled_exchange", "nm_pooled_finish", "nm_pooled_last_error",
     # the per-vector `Math` seam
     "nm_math_create", "nm_math_destroy", "nm_math_dim", "nm_math_threads", "nm_math_last_error", "nm_vec_new", "nm_vec_free", "nm_vec_read_from_slice", "nm_vec_write_to_slice", "nm_vec_copy_into", "nm_vec_fill_array", "nm_vec_array_recip", "nm_vec_axpy_out", "nm_vec_axpy", "nm_vec_array_mult", "nm_vec_array_vector_dot", "nm_vec_scalar_prods3", "nm_vec_array_gaussian", "nm_vec_array_update_variance", "nm_vec_array_update_var_inv_std_draw_grad", "nm_vec_array_update_var_inv_std_grad", "nm_vec_array_update_var_inv_std_draw", "nm_vec_array_sum_ln", "nm_vec_array_all_finite", "nm_vec_logp_array", "nm_vec_sq_norm_sum", "nm_vec_std_norm_flow", "nm_vec_std_norm_grad_flow", "nm_vec_esh_momentum_update", "nm_vec_array_normalize",
 ]
@@ -227,6 +227,8 @@ def load():
     L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
     L.nm_pooled_partials.argtypes = [u64, u64, vp, vp, vp, vp, vp]
+    L.nm_pooled_exchange.argtypes = [vp, u64, u64, vp, vp, vp]
+    L.nm_pooled_finish.argtypes = [u64, u64, vp, vp, vp, vp, vp]
     L.nm_pooled_last_error.restype = C.c_char_p
     L.nm_last_error.restype = C.c_char_p
     L.nm_abi_version.restype = u64

@@ -8,7 +8,12 @@ hipError_t launch_lane_t(int query, bool tune, const KParams& P, const lane::Lan
     if constexpr (std::is_void<typename lane::LaneDensity<Dens, NP>::type>::value) {
         return hipErrorInvalidValue;
     } else {
-        if (query) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, lane::nuts_lane_draw_kernel<Dens, NP, true>, 64, 0);
+        if (query == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, lane::nuts_lane_draw_kernel<Dens, NP, true>, 64, 0);
+        if (query == 2) {                 // unsynchronised draws (l_run_rounds)
+            if (tune) hipLaunchKernelGGL((lane::nuts_lane_rounds_kernel<Dens, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
+            else hipLaunchKernelGGL((lane::nuts_lane_rounds_kernel<Dens, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
+            return hipGetLastError();
+        }
         if (tune) hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
         else hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
         return hipGetLastError();
@@ -25,7 +30,7 @@ hipError_t launch_lane_d(int query, bool tune, const KParams& P, const lane::Lan
     return hipErrorInvalidValue;
 }
 }  // namespace
-// query = 1: *occ = resident blocks (wavefronts) per CU
+// query = 1: *occ = resident blocks (wavefronts) per CU; 2: launch the kernel with unsynchronised draws; 0: the synchronised one
 hipError_t launch_lane(uint64_t logp_kind, int query, bool tune, const KParams& P, const lane::LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
     switch (logp_kind) {
     case NM_LOGP_IID_NORMAL: return launch_lane_d<IidNormal>(query, tune, P, LP, grid, stream, occ);

@@ -1205,6 +1205,386 @@ NM_DEV void l_chain_draw(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out) {
     NM_LP(C, 11);
 }
 
+// =================================================================================================================
+// UNSYNCHRONISED DRAWS (round 4).  In nuts_lane_draw_kernel the 64 chains of a wavefront start every draw together:
+// a lane whose tree has ended idles until the wavefront's longest tree of that draw is done — in the warm-up, where step sizes and so
+// tree depths differ most, two thirds of the leapfrog slots are idle (23 slots per draw for a mean of 7.7 leaves per lane).
+// Here a lane's transition is a STATE MACHINE around ONE leapfrog site: every round each lane that is inside a tree takes one leapfrog
+// of ITS tree (whatever doubling, direction or leaf it is at) and advances its own bookkeeping.  Draws begin and end at EPOCH boundaries
+// (every NM_LANE_EPOCH rounds): the begin / end phases — momentum refresh, the chosen point's recomputation, adaptation, the statistics
+// row: as long as several leaves — run once per epoch for all lanes that are ready instead of once per round for whoever is ready.
+// Same arithmetic per chain, same generator stream per chain: the same bits as every other kernel.
+// =================================================================================================================
+#ifndef NM_LANE_EPOCH
+#define NM_LANE_EPOCH 4
+#endif
+enum LanePhase : int { LP_BEGIN = 0, LP_LEAF = 1, LP_END = 2, LP_DONE = 3 };
+
+template <int NP>
+struct LTree {                       // the locals of l_transition, kept across rounds
+    double e0, logdet, log_size, sub_log_size, wE, eps;
+    double E_logp, E_ke; int64_t E_idx;
+    int left_slot, right_slot, o_edge_sign, sign, stop;
+    bool o_is_edge, in_extra, check, fwd;
+    int64_t left_idx, right_idx, edge_idx;
+    uint64_t depth, mindepth, maxdepth, extra_left, n, nleaf;
+    CandRef mc, sub_cand;
+    uint32_t used, used_before;
+};
+
+// head of the doubling loop (src/nuts.rs:330-348); returns false when the tree is complete
+template <int NP, class LD>
+NM_DEV bool l_doubling_begin(LCtx<NP, LD>& C, LTree<NP>& T, DrawResult& R, LPt<NP>& cur) {
+    const nm_settings& s = C.P.s;
+    if (!T.in_extra) {
+        if (!(T.depth < T.maxdepth)) { R.reached_maxdepth = true; return false; }
+        T.sign = C.rng.random_bool_std() ? 1 : -1;
+        T.check = (s.check_turning != 0) && !(T.depth < T.mindepth);
+    } else {
+        if (T.extra_left == 0) return false;
+        T.extra_left -= 1;
+        T.check = false;
+    }
+    T.fwd = T.sign > 0;
+    T.edge_idx = T.fwd ? T.right_idx : T.left_idx;
+    T.nleaf = 1ull << T.depth;
+    T.n = 0;
+    T.used_before = T.used;
+    T.eps = (double)T.sign * C.sc.step_size * 1.0;
+    T.stop = STOP_NONE;
+    T.sub_log_size = 0.;
+    T.sub_cand = CandRef{-2, 0., 0., 0};
+    const bool reuse_edge = T.o_is_edge && T.o_edge_sign == T.sign;
+    T.o_is_edge = false;
+    if (T.depth > 0 && !reuse_edge) C.ld_edge(cur, T.fwd ? T.right_slot : T.left_slot);     // (depth 0: cur is the initial point)
+    return true;
+}
+
+// the start of a draw (the prologue of l_transition)
+template <int NP, class LD>
+NM_DEV void l_draw_begin(LCtx<NP, LD>& C, LTree<NP>& T, LAccept& col, DrawResult& R, LPt<NP>& cur) {
+    constexpr int E = 2 * NP;
+    const nm_settings& s = C.P.s;
+    ChainScalars& sc = C.sc;
+    if (sc.mm_id != sc.transform_id) {        // lazy re-whitening after the last mass-matrix update (diagonal.rs:210-221)
+        double x[E], gx[E], isig[E];
+        C.ldW(x, P_X); C.ldW(gx, P_GX); C.ldW(isig, P_ISIG);
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double t = __builtin_fma(-1.0, C.mu[d], x[d]);
+            cur.z[d] = isig[d] * t;
+            cur.g[d] = gx[d] * C.sig[d];
+        }
+        C.stW(cur.z, P_Z); C.stW(cur.g, P_GZ);
+        sc.logdet = sc.mm_logdet;
+        sc.transform_id = sc.mm_id;
+    } else {
+        C.ldW(cur.z, P_Z);
+        C.ldW(cur.g, P_GZ);
+    }
+    C.draw_normals(cur.v);
+    C.stS(cur.z, EDGE0_Z); C.stS(cur.v, EDGE0_V); C.stS(cur.g, EDGE0_G);
+    T.logdet = sc.logdet;
+    double ke_init;
+    {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc = __builtin_fma(cur.v[2 * l + k], cur.v[2 * l + k], acc);
+            p[l] = acc;
+        }
+        ke_init = 0.5 * pair_tree<NP>(p);
+    }
+    T.e0 = ke_init - (sc.logp + T.logdet);
+    R.e0 = T.e0;
+    col.register_init(T.e0);
+    T.left_slot = 0; T.right_slot = 0; T.o_is_edge = false; T.o_edge_sign = 0;
+    T.depth = 0; T.log_size = 0.; T.left_idx = 0; T.right_idx = 0;
+    T.mc = CandRef{-1, sc.logp, ke_init, 0};
+    T.used = 0;
+    uint64_t mindepth = s.mindepth, maxdepth = s.maxdepth;
+    if (s.has_target_integration_time) {
+        const double q = __builtin_ceil(s.target_integration_time / sc.step_size);
+        const uint64_t max_steps = q >= 18446744073709551616.0 ? ~0ull : (q > 0 ? (uint64_t)q : 0ull);
+        const uint64_t fl = 63 - __builtin_clzll(max_steps | 1ull);
+        const uint64_t ce = ((max_steps & (max_steps - 1)) == 0) ? fl : fl + 1;
+        mindepth = fl > s.mindepth ? fl : s.mindepth;
+        const uint64_t xd = ce > mindepth ? ce : mindepth;
+        maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
+    }
+    T.mindepth = mindepth; T.maxdepth = maxdepth;
+    R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false; R.has_div_end = true;
+    R.divergence_energy_error = 0.; R.div_start_idx = 0;
+    T.in_extra = false; T.extra_left = 0; T.sign = 1;
+}
+
+// One leaf of the lane's tree has been integrated: prv -> cur.  Its accounting, the sub-tree merges it completes, the end of its
+// doubling, the head of the next one.  Returns false when the tree has ended (R.chosen is set; `fatal`: the chain stops).
+template <bool BATCHED_TESTS, int NP, class LD>
+NM_DEV bool l_leaf_done(LCtx<NP, LD>& C, LTree<NP>& T, LAccept& col, DrawResult& R, LPt<NP>& prv, LPt<NP>& cur, bool& fatal) {
+    const nm_settings& s = C.P.s;
+    const int MD = C.md;
+    const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
+    const uint64_t n = T.n;
+    cur.idx = T.edge_idx + (int64_t)T.sign * (int64_t)(n + 1);
+    double w = 0.;
+    {
+        const double energy_ = cur.ke - (cur.logp + T.logdet);
+        const double err_ = energy_ - T.e0;
+        if ((err_ > s.max_energy_error) | !is_finite(err_)) {
+            col.register_divergent();
+            R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_;
+            R.div_start_idx = cur.idx - (int64_t)T.sign;
+            if (want_div) { C.stS(prv.z, slot_F(0)); C.stS(cur.z, slot_F(0) + 1); }
+            T.stop = STOP_DIVERGING;
+        } else {
+            col.register_ok(energy_);
+            w = -err_;
+        }
+    }
+    bool over = false;                 // the doubling is over (stopped, or its last leaf is done)
+    if (T.depth == 0) {
+        if (T.stop == STOP_NONE) { T.sub_log_size = w; T.sub_cand = CandRef{-2, cur.logp, cur.ke, cur.idx}; }
+        over = true;
+    } else if ((n & 1) == 0) {
+        T.wE = w; T.E_logp = cur.logp; T.E_ke = cur.ke; T.E_idx = cur.idx;
+        if (T.stop == STOP_NONE) { T.n = n + 1; return true; }
+        over = true;
+    } else {
+        if (T.stop == STOP_NONE) {
+            const uint64_t nn = n;
+            const int t = (int)__builtin_ctzll(~nn);
+            uint32_t turn_bits = 0;
+            if (T.check) {
+                if (l_turning<NP>(prv.z, prv.v, cur.z, cur.v, T.fwd)) turn_bits |= 2u;
+                for (int k = 2; k <= t && turn_bits == 0; ++k) {
+                    const uint64_t a_first = nn + 1 - (1ull << k);
+                    const int fa = a_first == 0 ? (int)T.depth : (int)__builtin_ctzll(a_first);
+                    const bool tk = BATCHED_TESTS ? l_merge_turning(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), prv, cur, T.fwd)
+                                                  : l_merge_turning_streamed(C, slot_F(fa), slot_L(MD, k - 1), k == 2 ? -1 : slot_F(k - 1), prv, cur, T.fwd);
+                    if (tk) turn_bits |= 1u << k;
+                }
+            }
+            {
+                double total;
+                const bool take = l_merge_weights(C, T.wE, w, false, total, fatal);
+                T.sub_cand = take ? CandRef{-2, cur.logp, cur.ke, cur.idx} : CandRef{-3, T.E_logp, T.E_ke, T.E_idx};
+                T.sub_log_size = total;
+                if (fatal) T.stop = STOP_FATAL;
+                else if (turn_bits & 2u) T.stop = STOP_TURNING;
+            }
+            for (int k = 2; k <= t && T.stop == STOP_NONE; ++k) {
+                double a_log_size; CandRef ac;
+                C.pend.get(k - 1, a_log_size, ac);
+                double total;
+                const bool take = l_merge_weights(C, a_log_size, T.sub_log_size, false, total, fatal);
+                if (take) {
+                    T.used &= ~(1u << ac.slot);
+                } else {
+                    if (T.sub_cand.slot >= 0) T.used &= ~(1u << T.sub_cand.slot);
+                    T.sub_cand = ac;
+                }
+                T.sub_log_size = total;
+                if (fatal) T.stop = STOP_FATAL;
+                else if ((turn_bits >> k) & 1u) T.stop = STOP_TURNING;
+            }
+            if (T.stop == STOP_NONE) {
+                const uint64_t ne = n - 1;
+                if ((ne & 3) == 0 && T.depth > 1) {
+                    const int fs = slot_F(ne == 0 ? (int)T.depth : (int)__builtin_ctzll(ne));
+                    C.stS(prv.z, fs);
+                    C.stS(prv.v, fs + 1);
+                }
+                if (n + 1 < T.nleaf) {
+                    C.stS(cur.z, slot_L(MD, t)); C.stS(cur.v, slot_L(MD, t) + 1);
+                    if (T.sub_cand.slot == -2) T.sub_cand.slot = l_cand_to_pool(C, T.used, cur.z);
+                    else if (T.sub_cand.slot == -3) T.sub_cand.slot = l_cand_to_pool(C, T.used, prv.z);
+                    C.pend.put(t, T.sub_log_size, T.sub_cand);
+                    T.n = n + 1;
+                    return true;                                  // the doubling goes on
+                }
+            }
+        }
+        over = true;
+    }
+    (void)over;
+    // ---- the doubling is over
+    if (T.stop == STOP_FATAL || fatal) { fatal = true; R.depth = T.depth; R.chosen = T.mc; return false; }
+    if (T.stop == STOP_DIVERGING) { T.used = T.used_before; R.depth = T.depth; R.chosen = T.mc; return false; }
+    if (T.stop == STOP_TURNING) {
+        T.used = T.used_before;
+        if (!T.in_extra) { T.in_extra = true; T.extra_left = s.extra_doublings; }
+    } else {
+        // top-level U-turn tests of the finished sub-tree (last leaf cur) against the main tree (src/nuts.rs:143-161)
+        bool turning = false;
+        if (T.check) {
+            if (T.depth == 0) turning = l_turning<NP>(prv.z, prv.v, cur.z, cur.v, T.fwd);
+            else
+                turning = BATCHED_TESTS ? l_merge_turning(C, EDGE0_Z + 3 * (T.fwd ? T.left_slot : T.right_slot), EDGE0_Z + 3 * (T.fwd ? T.right_slot : T.left_slot),
+                                                          T.depth == 1 ? -1 : slot_F((int)T.depth), prv, cur, T.fwd)
+                                        : l_merge_turning_streamed(C, EDGE0_Z + 3 * (T.fwd ? T.left_slot : T.right_slot), EDGE0_Z + 3 * (T.fwd ? T.right_slot : T.left_slot),
+                                                                   T.depth == 1 ? -1 : slot_F((int)T.depth), prv, cur, T.fwd);
+        }
+        double total;
+        const bool take = l_merge_weights(C, T.log_size, T.sub_log_size, true, total, fatal);
+        if (fatal) { R.depth = T.depth; R.chosen = T.mc; return false; }
+        if (take) {
+            if (T.mc.slot >= 0) T.used &= ~(1u << T.mc.slot);
+            if (T.sub_cand.slot == -2) T.sub_cand.slot = l_cand_to_pool(C, T.used, cur.z);
+            else if (T.sub_cand.slot == -3) T.sub_cand.slot = l_cand_to_pool(C, T.used, prv.z);
+            T.mc = T.sub_cand;
+        } else if (T.sub_cand.slot >= 0) {
+            T.used &= ~(1u << T.sub_cand.slot);
+        }
+        const bool more = T.in_extra ? T.extra_left > 0 : (turning ? s.extra_doublings > 0 : T.depth + 1 < T.maxdepth);
+        if (more) {
+            int ns = T.fwd ? T.right_slot : T.left_slot;
+            const int other_side = T.fwd ? T.left_slot : T.right_slot;
+            if (ns == 0) ns = other_side == 1 ? 2 : 1;
+            C.stS(cur.z, EDGE0_Z + 3 * ns); C.stS(cur.v, EDGE0_V + 3 * ns); C.stS(cur.g, EDGE0_G + 3 * ns);
+            if (T.fwd) T.right_slot = ns; else T.left_slot = ns;
+            T.o_is_edge = true; T.o_edge_sign = T.sign;
+        }
+        if (T.fwd) T.right_idx = cur.idx; else T.left_idx = cur.idx;
+        T.depth += 1;
+        T.log_size = total;
+        if (turning && !T.in_extra) { T.in_extra = true; T.extra_left = s.extra_doublings; }
+    }
+    if (!l_doubling_begin(C, T, R, cur)) { R.depth = T.depth; R.chosen = T.mc; return false; }
+    return true;
+}
+
+// the end of a draw: l_chain_draw behind its transition
+template <bool TUNE, int NP, class LD>
+NM_DEV void l_draw_end(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out, LAccept& col, const DrawResult& R, bool fatal) {
+    constexpr int E = 2 * NP;
+    const KParams& P = C.P;
+    ChainScalars& sc = C.sc;
+    nm_draw_stats out;
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    if (fatal) {
+        sc.status = NM_CHAIN_LOGP_FATAL;
+        if (P.out_stats) {
+            nm_draw_stats zz = {};
+            zz.draw = sc.draw_count; zz.chain = P.chain_id_offset + chain; zz.chain_status = NM_CHAIN_LOGP_FATAL;
+            P.out_stats[t_out * P.n_chains + chain] = zz;
+        }
+        return;
+    }
+    double x[E], gx[E], z[E], gz[E];
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    if (R.diverging && (P.out_div_start || P.out_div_start_grad || P.out_div_end))
+        l_emit_divergence_vectors(C, R.div_start_idx, row);          // before P_X / P_GX take the new draw
+    if (R.chosen.slot == -1 && !sc.px_stale) {
+        C.ldW(x, P_X); C.ldW(gx, P_GX);
+        C.ldW(z, P_Z); C.ldW(gz, P_GZ);
+    } else {
+        if (R.chosen.slot == -1) C.ldW(z, P_Z);
+        else C.ldS(z, slot_C(C.md, R.chosen.slot));
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double tt = z[d] * C.sig[d];
+            x[d] = __builtin_fma(1.0, C.mu[d], tt);
+        }
+        (void)C.dens.eval(x, gx, C.dim);
+#pragma unroll
+        for (int d = 0; d < E; ++d) gz[d] = gx[d] * C.sig[d];
+        const bool need_x = sc.tuning || t_out + 1 == P.n_draws || P.out_div_start || P.out_div_start_grad;
+        if (need_x) { C.stW(x, P_X); C.stW(gx, P_GX); }
+        sc.px_stale = need_x ? 0 : 1;
+        C.stW(z, P_Z); C.stW(gz, P_GZ);
+        sc.logp = R.chosen.logp;
+    }
+    const int64_t idx = R.chosen.idx;
+    l_write_row(C, P.out_positions, row, x);
+    l_write_row(C, P.out_gradient, row, gx);
+    l_write_row(C, P.out_tpos, row, z);
+    l_write_row(C, P.out_tgrad, row, gz);
+    double fd;
+    {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int d = 2 * l + k; acc = acc + (z[d] + gz[d]) * (z[d] + gz[d]); }
+            p[l] = acc;
+        }
+        fd = pair_tree<NP>(p);
+    }
+    const double energy = R.chosen.ke - (R.chosen.logp + sc.logdet);
+    const int64_t trans_id = sc.transform_id;
+    sc.total_steps += col.count;
+    const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
+    const uint64_t ast = l_adapt<TUNE>(C, col, is_good, x, gx);
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    out.depth = R.depth; out.maxdepth_reached = R.reached_maxdepth; out.diverging = R.diverging;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.index_in_trajectory = idx; out.transformation_index = trans_id;
+    out.step_size = sc.step_size;
+    out.step_size_bar = P.s.step_size_method == NM_STEP_FIXED ? P.s.fixed_step_size
+                      : P.s.step_size_method == NM_STEP_ADAM ? lexp(sc.log_step) : lexp(sc.log_step_adapted);
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.logp = R.chosen.logp; out.energy = energy; out.energy_error = energy - R.e0;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (R.diverging && R.has_divergence_energy_error) ? R.divergence_energy_error : __builtin_nan("");
+    out.chain_status = ast;
+    out.transformation_update_id = -1;
+    out.num_eigenvalues = 0;
+    out.energy_change = __builtin_nan(""); out.average_step_size = __builtin_nan("");
+    if (sc.mm_id != sc.stats_last_id) {
+        out.transformation_update_id = sc.mm_id;
+        l_write_row(C, P.out_mm_inv, row, C.sig);
+        l_write_row(C, P.out_mm_mu, row, C.mu);
+    }
+    sc.stats_last_id = sc.mm_id;
+    if (P.out_stats) P.out_stats[t_out * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
+// all draws of the launch for the lane's chain, unsynchronised with the other lanes of the wavefront
+template <bool TUNE, int NP, class LD>
+NM_DEV void l_run_rounds(LCtx<NP, LD>& C, uint64_t chain, bool present) {
+    const KParams& P = C.P;
+    int phase = (present && C.sc.status == NM_CHAIN_OK && P.n_draws > 0) ? LP_BEGIN : LP_DONE;
+    uint64_t t_out = 0;
+    LTree<NP> T;
+    LAccept col;
+    DrawResult R;
+    LPt<NP> cur, prv;
+    bool fatal = false;
+    for (;;) {
+        // ---- epoch boundary
+        if (__any(phase == LP_END)) {
+            if (phase == LP_END) {
+                l_draw_end<TUNE>(C, chain, t_out, col, R, fatal);
+                t_out += 1;
+                phase = (!fatal && C.sc.status == NM_CHAIN_OK && t_out < P.n_draws) ? LP_BEGIN : LP_DONE;
+            }
+        }
+        if (__any(phase == LP_BEGIN)) {
+            if (phase == LP_BEGIN) {
+                l_draw_begin(C, T, col, R, cur);
+                phase = LP_LEAF;
+                if (!l_doubling_begin(C, T, R, cur)) { R.depth = T.depth; R.chosen = T.mc; phase = LP_END; }
+            }
+        }
+        if (!__any(phase == LP_LEAF || phase == LP_END)) break;
+        // ---- the epoch's leapfrog rounds
+        for (int r = 0; r < NM_LANE_EPOCH; ++r) {
+            if (phase == LP_LEAF) {
+                prv = cur;
+                l_leapfrog(C, prv, cur, T.eps);
+                if (!l_leaf_done<!TUNE>(C, T, col, R, prv, cur, fatal)) phase = LP_END;
+            }
+            if (!__any(phase == LP_LEAF)) break;
+        }
+    }
+}
+
 template <int NP>
 struct LaneShared {
 #if NM_LANE_PROF
@@ -1272,6 +1652,54 @@ __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, 
 #pragma unroll
                     for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ldWe(s_, e);
             }
+            P.sc[chain] = sc;
+        }
+    }
+}
+
+// the same launch shape with unsynchronised draws (l_run_rounds)
+template <class Dens, int NP, bool TUNE>
+__global__ __launch_bounds__(64, 1) void nuts_lane_rounds_kernel(const KParams P, const LaneParams LP) {
+    using LD = typename LaneDensity<Dens, NP>::type;
+    constexpr int E = 2 * NP;
+    __shared__ LaneShared<NP> sh;
+    for (int i = (int)threadIdx.x; i < 257; i += 64) {
+        sh.zig[i] = P.zig_x[i];
+        if (NP != 8) sh.zig[(NP != 8 ? 257 : 0) + i] = P.zig_f[i];
+    }
+    for (int i = (int)threadIdx.x; i < 2 * NP * 64; i += 64) sh.stage[i] = 0.0;
+    dm_init_lds();
+    __syncthreads();
+    const int l = (int)threadIdx.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < P.n_chains; base += (uint64_t)gridDim.x * 64) {
+        const uint64_t chain = base + (uint64_t)l;
+        const bool present = chain < P.n_chains;
+        ChainScalars sc = P.sc[present ? chain : base];
+        LCtx<NP, LD> C(P, sc);
+        C.dim = (int)P.dim;
+        C.md = (int)P.layout_md;
+        C.rw = make_rsrc(LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64, (uint64_t)NUM_PSLOT * E * 512);
+        C.rsv = make_rsrc(LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64, (uint64_t)LP.nslots * E * 512);
+        C.l8 = l * 8;
+        C.pend.base = sh.pend + l;
+        C.zig = {sh.zig, NP != 8 ? sh.zig + 257 : P.zig_f};
+        C.stage = sh.stage + l;
+        if (present) {
+            const double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
+            for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
+#pragma unroll
+                for (int e = 0; e < E; ++e) C.stWe(s_, e, pv[(size_t)s_ * P.dpad + e]);
+        }
+        C.ldW(C.sig, P_SIG); C.ldW(C.mu, P_MU);
+        C.rng.init(sc.key, sc.rng_pos, sh.rng_ring + l);
+        C.dens.init(P.logp_params, C.dim);
+        l_run_rounds<TUNE>(C, chain, present);
+        if (present) {
+            sc.rng_pos = C.rng.pos;
+            double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
+            for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
+#pragma unroll
+                for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ldWe(s_, e);
             P.sc[chain] = sc;
         }
     }

@@ -9,6 +9,7 @@
 // Deterministic: fixed chunks of rows, each reduced by one thread per dimension in row order (Welford), chunk partials merged in
 // chunk order — the same rows give the same bits whatever else runs on the device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cstdint>
 #include <string>
 #include "../../include/nuts_amd.h"
@@ -70,8 +71,70 @@ __global__ __launch_bounds__(128) void pooled_merge_kernel(uint64_t chunks, uint
     if (d == 0) o[0] = n;
     if (d < dim) { o[1 + d] = mean; o[1 + dim + d] = m2; }
 }
+// the ranks' gathered partials [world][2][1 + 2 dim] -> the pooled diagonal transformation (pooled.py's _merge_payloads + finish)
+__global__ __launch_bounds__(128) void pooled_finish_kernel(uint64_t world, uint64_t dim, const double* gathered, double* sigma, double* mean_out, double* count) {
+    const uint64_t d = (uint64_t)blockIdx.x * 128u + threadIdx.x;
+    const uint64_t stride = 2 * (1 + 2 * dim);
+    double n[2] = {0.0, 0.0}, mean[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
+    for (int z = 0; z < 2; ++z)
+        for (uint64_t r = 0; r < world; ++r) {                    // rank order
+            const double* q = gathered + r * stride + (uint64_t)z * (1 + 2 * dim);
+            const double nb = q[0];
+            if (nb == 0.0) continue;
+            if (d < dim) {
+                const double mb = q[1 + d], sb = q[1 + dim + d];
+                if (n[z] == 0.0) { n[z] = nb; mean[z] = mb; m2[z] = sb; continue; }
+                const double tot = n[z] + nb, delta = mb - mean[z];
+                mean[z] = mean[z] + delta * (nb / tot);
+                m2[z] = m2[z] + sb + delta * delta * (n[z] * nb / tot);
+                n[z] = tot;
+            } else {
+                n[z] += nb;
+            }
+        }
+    if (d == 0 && count) *count = n[0];
+    if (d < dim) {
+        double sg = sqrt(sqrt(m2[0] / m2[1]));
+        const bool ok = (sg == sg) && sg > 0.0 && sg < __builtin_inf();
+        sg = ok ? fmin(fmax(sg, 1e-10), 1e10) : 1.0;
+        sigma[d] = sg;
+        mean_out[d] = mean[0] + sg * sg * mean[1];
+    }
+}
+typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+all_gather_fn rccl_all_gather() {
+    static all_gather_fn fn = [] {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        return h ? (all_gather_fn)dlsym(h, "ncclAllGather") : (all_gather_fn) nullptr;
+    }();
+    return fn;
+}
 thread_local std::string g_perr;
 }  // namespace
+
+extern "C" nm_status nm_pooled_exchange(void* rccl_comm, uint64_t world, uint64_t dim, const double* d_payload, double* d_gathered, void* stream) {
+    if (!d_payload || !d_gathered || dim == 0 || world == 0) { g_perr = "nm_pooled_exchange: null argument"; return NM_ERR_INVALID_ARG; }
+    const size_t n = 2 * (1 + 2 * (size_t)dim);
+    hipStream_t s = (hipStream_t)stream;
+    if (world == 1 || !rccl_comm) {
+        const hipError_t e = hipMemcpyAsync(d_gathered, d_payload, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { g_perr = std::string("nm_pooled_exchange: ") + hipGetErrorString(e); return NM_ERR_HIP; }
+        return NM_OK;
+    }
+    all_gather_fn ag = rccl_all_gather();
+    if (!ag) { g_perr = "nm_pooled_exchange: librccl.so (ncclAllGather) could not be loaded"; return NM_ERR_UNSUPPORTED; }
+    const int rc = ag(d_payload, d_gathered, n, /* ncclDouble */ 8, rccl_comm, s);
+    if (rc != 0) { g_perr = "nm_pooled_exchange: ncclAllGather failed with code " + std::to_string(rc); return NM_ERR_HIP; }
+    return NM_OK;
+}
+extern "C" nm_status nm_pooled_finish(uint64_t world, uint64_t dim, const double* d_gathered, double* d_sigma, double* d_mean, double* d_count, void* stream) {
+    if (!d_gathered || !d_sigma || !d_mean || dim == 0 || world == 0) { g_perr = "nm_pooled_finish: null argument"; return NM_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(pooled_finish_kernel, dim3((unsigned)((dim + 127) / 128)), dim3(128), 0, (hipStream_t)stream, world, dim, d_gathered, d_sigma, d_mean, d_count);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_perr = std::string("nm_pooled_finish: ") + hipGetErrorString(e); return NM_ERR_HIP; }
+    return NM_OK;
+}
 
 extern "C" const char* nm_pooled_last_error(void) { return g_perr.c_str(); }
 

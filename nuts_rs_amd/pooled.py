@@ -124,18 +124,18 @@ def pooled_warmup(batch, num_tune, dist=None, windows=None, collective_device=No
         if work is not None:
             work.wait()
         with torch.cuda.stream(side):
-            parts = [g.to(dev) for g in gathered]
-            d2 = 2 * dim + 1
-            cnt, mx, vx = _merge_payloads([g[:d2] for g in parts], dim)
-            _, mg, vg = _merge_payloads([g[d2:] for g in parts], dim)
-            if float(cnt) < 3.0:        # fewer than three pooled draws: no estimate (a RunningVariance asserts count > 1,
-                side.synchronize()      # adapt/diagonal.rs:48; with 2 the ratio of variances is noise) — keep the current transformation
-                return
-            sigma = torch.sqrt(torch.sqrt(vx / vg))
-            ok = torch.isfinite(sigma) & (sigma > 0)
-            sigma = torch.where(ok, torch.clamp(sigma, 1e-10, 1e10), torch.ones_like(sigma))
-            mean = mx + sigma * sigma * mg
+            # the merge of the gathered partials in rank order + the pooled transformation: the engine's own kernel (nm_pooled_finish,
+            # csrc/pooled_reduce.hip — what a host without Python calls after nm_pooled_exchange)
+            allp = torch.stack([g.to(dev) for g in gathered]).contiguous()
+            sigma = torch.empty(dim, dtype=torch.float64, device=dev)
+            mean = torch.empty(dim, dtype=torch.float64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.float64, device=dev)
+            from . import _lib
+            _lib.check_status(_lib.load().nm_pooled_finish(len(gathered), dim, allp.data_ptr(), sigma.data_ptr(), mean.data_ptr(), cnt.data_ptr(),
+                                                           side.cuda_stream), _lib.load().nm_pooled_last_error)
         side.synchronize()
+        if float(cnt.item()) < 3.0:     # fewer than three pooled draws: no estimate (a RunningVariance asserts count > 1,
+            return                      # adapt/diagonal.rs:48; with 2 the ratio of variances is noise) — keep the current transformation
         s_h, m_h = sigma.cpu().numpy(), mean.cpu().numpy()
         batch.set_transform(s_h, m_h, np.zeros(0), np.zeros((0, dim)), np.zeros(dim))
         updates.append((at, s_h, m_h))

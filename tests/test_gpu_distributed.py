@@ -130,3 +130,36 @@ def test_pooled_partials_kernel_matches_numpy():
         n_, mean_, m2_ = pooled.welford_partial(rows)
         assert out[k, 0] == n_ == good.sum()
         assert np.allclose(out[k, 1:1 + dim], mean_, rtol=1e-13, atol=1e-13) and np.allclose(out[k, 1 + dim:], m2_, rtol=1e-12)
+
+
+def test_pooled_exchange_and_finish_through_the_c_abi():
+    """nm_pooled_exchange (world 1: the copy path; with a communicator: ncclAllGather, librccl resolved at run time) + nm_pooled_finish:
+    the rank-order Chan merge of the gathered partials and the pooled diagonal transformation, against pooled.py's own merge — what
+    a host without Python (the Rust side behind the C ABI) calls between nm_pooled_partials and nm_engine_set_transform."""
+    import torch
+    from nuts_rs_amd import _lib, pooled
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    dim, world = 23, 5
+    payloads = []
+    for r in range(world):
+        n = 0 if r == 2 else int(rng.integers(3, 40))                 # one rank kept no draw in this window
+        rows_x, rows_g = rng.normal(size=(n, dim)) * 2 + 1, rng.normal(size=(n, dim)) * 0.5 - 1
+        px, pg = (pooled.welford_partial(a) if n else (0.0, np.zeros(dim), np.zeros(dim)) for a in (rows_x, rows_g))
+        payloads.append(np.concatenate([[px[0]], px[1], px[2], [pg[0]], pg[1], pg[2]]))
+    gathered = torch.tensor(np.stack(payloads), dtype=torch.float64, device="cuda")
+    sigma, mean, cnt = (torch.empty(k, dtype=torch.float64, device="cuda") for k in (dim, dim, 1))
+    stream = torch.cuda.current_stream().cuda_stream
+    # exchange with one rank = copy of the payload
+    one = torch.empty(2 * (1 + 2 * dim), dtype=torch.float64, device="cuda")
+    _lib.check_status(L.nm_pooled_exchange(None, 1, dim, gathered[0].data_ptr(), one.data_ptr(), stream), L.nm_pooled_last_error)
+    _lib.check_status(L.nm_pooled_finish(world, dim, gathered.data_ptr(), sigma.data_ptr(), mean.data_ptr(), cnt.data_ptr(), stream), L.nm_pooled_last_error)
+    torch.cuda.synchronize()
+    assert (one.cpu().numpy() == payloads[0]).all()
+    d2 = 2 * dim + 1
+    n_, mx, vx = pooled._merge_payloads([torch.tensor(p[:d2]) for p in payloads], dim)
+    _, mg, vg = pooled._merge_payloads([torch.tensor(p[d2:]) for p in payloads], dim)
+    want_sigma = np.clip(np.sqrt(np.sqrt(vx.numpy() / vg.numpy())), 1e-10, 1e10)
+    assert float(cnt.item()) == float(n_)
+    assert np.allclose(sigma.cpu().numpy(), want_sigma, rtol=1e-14)
+    assert np.allclose(mean.cpu().numpy(), mx.numpy() + want_sigma ** 2 * mg.numpy(), rtol=1e-13, atol=1e-13)

@@ -41,7 +41,10 @@ def _case(rng, i):
     return dens, dim, kw, logp
 
 
-def test_lane_kernel_sweep(oracle):
+@pytest.mark.parametrize("lane_chains", [2, 3], ids=["synchronised", "rounds"])
+def test_lane_kernel_sweep(oracle, lane_chains):
+    """lane_chains = 2: the 64 chains of a wavefront start every draw together; 3: unsynchronised draws (l_run_rounds: every lane
+    advances its own tree by one leapfrog per round, draws begin and end at epoch boundaries).  The same bits either way."""
     rng = np.random.default_rng(177)
     for i in range(int(os.environ.get("NM_LANE_SWEEP_CASES", "120"))):
         dens, dim, kw, logp = _case(rng, i)
@@ -50,7 +53,7 @@ def test_lane_kernel_sweep(oracle):
         x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
         n_draws = s.num_tune + 40
         grid = int(rng.integers(1, 3)) if rng.random() < 0.3 else 0
-        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, lane_chains=2, grid_blocks=grid,
+        pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, lane_chains=lane_chains, grid_blocks=grid,
                                      splits=(s.num_tune, s.num_tune + 1, s.num_tune + 17))
         pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=64)
         if failed or not (ex["status"] == 0).all():
