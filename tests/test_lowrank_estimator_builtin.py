@@ -35,6 +35,7 @@ KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "referen
 
 TOL_DIAG = 1e-13
 TOL_FULL_RANK = 1e-6
+TOL_MARGINAL_RANK = 1e-3      # dim <= n_draws - 1 < 1.05 dim: full rank on paper, the smallest singular value of the window is ~0 (measured 2.4e-6)
 TOL_RANK_DEFICIENT = 0.25
 TOL_SIGNAL_EIG = 0.05
 
