@@ -109,7 +109,7 @@ def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):
     raise ValueError(f"no tiling for dim {dim}")
 
 
-def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None):
+def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None, lane_struct=None):
     """Compile a user density (a functor `struct_name` defined in `header`, see include/nuts_amd.h "User densities")
     with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s)."""
     if dim > 4096:            # several blocks per chain: the cluster-mode kernels on the (16, 4) tiling; the density brings init_slice
@@ -123,6 +123,10 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 64:
             raise ValueError("group forms exist for dim <= 64")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_GROUP_DENSITY={group_struct}", f"-DNM_MODULE_GS={8 if dim <= 16 else 16 if dim <= 32 else 32}"]
+    if lane_struct:           # the density's lane form: one chain per lane for dim <= 16 (`template <int NP> struct ...`)
+        if dim > 16:
+            raise ValueError("lane forms exist for dim <= 16")
+        extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
     cmd = [hipcc] + FLAGS + list(extra_flags) + [
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
         f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),

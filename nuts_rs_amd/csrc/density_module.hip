@@ -8,6 +8,9 @@
 // Optional, for dim <= 64: -DNM_MODULE_GROUP_DENSITY=<template name> -DNM_MODULE_GS=<8|16|32> adds the density's group form
 // (several chains per wavefront, nuts_group.hpp): `template <class L> struct Name` written against L = Lanes.
 #include "nuts_launch.hpp"
+#ifdef NM_MODULE_LANE_DENSITY
+#include "nuts_lane.hpp"      // (before the user's header: its lane form is written against nm::lane)
+#endif
 #include NM_MODULE_HEADER
 
 #ifndef NM_MODULE_DPL
@@ -31,16 +34,51 @@ template <> struct GroupDensity<NM_MODULE_DENSITY> { using type = NM_MODULE_GROU
 #define NM_MODULE_GS_VALUE 0
 #endif
 
+// Optional, for dim <= 16: -DNM_MODULE_LANE_DENSITY=<template name> adds the density's LANE form (one chain per lane, nuts_lane.hpp):
+// `template <int NP> struct Name { void init(const double* params, int dim); double eval(const double (&x)[2 NP], double (&gx)[2 NP], int dim) const; }`
+// — the whole chain in one lane; sums over dim through nm::lane::pair_tree (the engine's order for <= 16 elements).
+#ifdef NM_MODULE_LANE_DENSITY
+namespace nm { namespace lane {
+template <int NP> struct LaneDensity<NM_MODULE_DENSITY, NP> { using type = NM_MODULE_LANE_DENSITY<NP>; };
+template <int NP>
+static hipError_t module_lane_t(int query, bool tune, const KParams& P, const LaneParams& LP, unsigned grid, hipStream_t stream, int* occ) {
+    if (query == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_lane_draw_kernel<NM_MODULE_DENSITY, NP, true>, 64, 0);
+    if (tune) hipLaunchKernelGGL((nuts_lane_draw_kernel<NM_MODULE_DENSITY, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
+    else hipLaunchKernelGGL((nuts_lane_draw_kernel<NM_MODULE_DENSITY, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
+    return hipGetLastError();
+}
+} }
+#define NM_MODULE_HAS_LANE 1
+#else
+#define NM_MODULE_HAS_LANE 0
+#endif
+
 extern "C" {
-// {sizeof(KParams), NM_ABI_VERSION, DPL, W, lanes per chain of the group form or 0, 1 if built for chains wider than one block}:
+// {sizeof(KParams), NM_ABI_VERSION, DPL, W, lanes per chain of the group form or 0, 1 if built for chains wider than one block,
+//  1 if the module carries a lane form}:
 // the engine refuses a module built against another layout
-void nm_module_info(uint64_t out[6]) {
+void nm_module_info(uint64_t out[8]) {
     out[0] = sizeof(nm::KParams); out[1] = NM_ABI_VERSION; out[2] = NM_MODULE_DPL; out[3] = NM_MODULE_W; out[4] = NM_MODULE_GS_VALUE;
-    out[5] = NM_CLUSTER_MODE;
+    out[5] = NM_CLUSTER_MODE; out[6] = NM_MODULE_HAS_LANE;
 }
 // kind: nm::KernelKind (init, draw, occupancy query; the group form's draw / warm-up / query)
 int nm_module_launch(int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ) {
     return (int)nm::launch_t<NM_MODULE_DPL, NM_MODULE_W, NM_MODULE_DENSITY>((nm::KernelKind)kind, *static_cast<const nm::KParams*>(kparams),
                                                                             grid_blocks, static_cast<hipStream_t>(stream), occ);
 }
+#if NM_MODULE_HAS_LANE
+// the one-chain-per-lane kernels for this density (query 1: resident wavefronts per CU; 0: launch; tune: the warm-up kernel)
+int nm_module_launch_lane(int query, int tune, const void* kparams, const void* lane_params, unsigned grid, void* stream, int* occ) {
+    const nm::KParams& P = *static_cast<const nm::KParams*>(kparams);
+    const nm::lane::LaneParams& LP = *static_cast<const nm::lane::LaneParams*>(lane_params);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (nm::lane::lane_pairs(P.dim)) {
+    case 2: return (int)nm::lane::module_lane_t<2>(query, tune != 0, P, LP, grid, s, occ);
+    case 4: return (int)nm::lane::module_lane_t<4>(query, tune != 0, P, LP, grid, s, occ);
+    case 5: return (int)nm::lane::module_lane_t<5>(query, tune != 0, P, LP, grid, s, occ);
+    case 8: return (int)nm::lane::module_lane_t<8>(query, tune != 0, P, LP, grid, s, occ);
+    }
+    return (int)hipErrorInvalidValue;
+}
+#endif
 }

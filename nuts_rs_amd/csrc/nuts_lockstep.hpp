@@ -799,14 +799,6 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { cz[h].a[r] = cv[h].a[r] = cg[h].a[r] = pz[h].a[r] = pvv[h].a[r] = zin[h].a[r] = vh[h].a[r] = fx[h].a[r] = fgx[h].a[r] = 0.; }
         int round_mode = M_IDLE;          // what my column submitted in the round in flight
-        // The far edge of the main tree, read for the top-level U-turn test of a doubling's last leaf, stays in registers until P3: when the
-        // next doubling turns round it starts there (half of all doublings) and needs no second trip to HBM.
-        int pe_id = -1;
-        Vec4 pez[SPW], pev[SPW], peg[SPW];
-#pragma unroll
-        for (int h = 0; h < SPW; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pez[h].a[r] = pev[h].a[r] = peg[h].a[r] = 0.; }
 #if NM_LOCK_PROF
         unsigned long long lkp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lkp_t = __builtin_amdgcn_s_memtime(), lkp_rounds = 0;
 #endif
@@ -895,10 +887,9 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zin[h].a[r] = 0.0;
                     if (mode == M_LEAF) {
-                        if (le >= 0) {
-                            if (le == pe_id) { cz[h] = pez[h]; cv[h] = pev[h]; cg[h] = peg[h]; }
-                            else { ldS(cz[h], EDGE0_Z + 3 * le, h); ldS(cv[h], EDGE0_V + 3 * le, h); ldS(cg[h], EDGE0_G + 3 * le, h); }
-                        }
+                        // (keeping the far edge in registers from the top-level test to here — half of all doublings start there — was
+                        // measured: 48 more live registers spill in the products, 76 -> 87 us per round)
+                        if (le >= 0) { ldS(cz[h], EDGE0_Z + 3 * le, h); ldS(cv[h], EDGE0_V + 3 * le, h); ldS(cg[h], EDGE0_G + 3 * le, h); }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             vh[h].a[r] = __builtin_fma(half, cg[h].a[r], cv[h].a[r]);
@@ -1027,9 +1018,6 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
             const LkChain& K1 = S.ch[c];
             const int k_n = K1.n, k_depth = K1.depth, k_fwd = K1.fwd, k_check = K1.check, k_ls = K1.left_slot, k_rs = K1.right_slot;
             const double half1 = K1.eps / 2.;
-            pe_id = -1;
-#pragma unroll
-            for (int h = 0; h < SPW; ++h) { pez[h] = zin[h]; pev[h] = zin[h]; peg[h] = zin[h]; }   // (defined every round: not live across the products)
             int ngroups = 0;                                       // U-turn test groups of my column's leaf
             if (round_mode == M_LEAF && k_check && (k_n & 1)) {
                 const int t = (int)__builtin_ctz(~(unsigned)k_n);
@@ -1088,13 +1076,10 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
                                 zl = EDGE0_Z + 3 * (k_fwd ? k_rs : k_ls);
                                 zb = k_depth == 1 ? -1 : slot_F(k_depth);
                             }
-                            const bool top = !(i < t - 1);
-                            if (top) pe_id = k_fwd ? k_ls : k_rs;
 #pragma unroll
                             for (int h = 0; h < SPW; ++h) {
                                 Vec4 az, av, lz, lvv, bz, bv;
                                 ldS(az, za, h); ldS(av, za + 1, h);
-                                if (top) { ldS(peg[h], za + 2, h); pez[h] = az; pev[h] = av; }
                                 ldS(lz, zl, h); ldS(lvv, zl + 1, h);
                                 if (zb >= 0) { ldS(bz, zb, h); ldS(bv, zb + 1, h); } else { bz = pz[h]; bv = pvv[h]; }
                                 double a6[6];

@@ -23,14 +23,15 @@ def module_path(dim=DIM):
     return os.path.join(MODDIR, f"my_diag_normal_dpl{dpl}_w{w}.so")
 
 
-def ensure_module(dim=DIM, group=False):
-    out = module_path(dim) if not group else os.path.join(MODDIR, f"my_diag_normal_group_dim{dim}.so")
+def ensure_module(dim=DIM, group=False, lane=False):
+    out = module_path(dim) if not (group or lane) else os.path.join(MODDIR, f"my_diag_normal_{'lane' if lane else 'group'}_dim{dim}.so")
     srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp",
-                                                          "nuts_group.hpp", "nuts_group_impl.hpp")]
+                                                          "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_lane.hpp")]
     srcs.append(os.path.join(HERE, "..", "include", "nuts_amd.h"))       # the ABI version is part of the module
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
         os.makedirs(MODDIR, exist_ok=True)
-        B.build_density_module(HEADER, "MyDiagNormal", dim, out, group_struct="MyDiagNormalGroup" if group else None)
+        B.build_density_module(HEADER, "MyDiagNormal", dim, out, group_struct="MyDiagNormalGroup" if (group or lane) else None,
+                               lane_struct="MyDiagNormalLane" if lane else None)
     return out
 
 
@@ -106,6 +107,32 @@ def test_user_density_group_form_matches_oracle(oracle):
     b.draw_many(5)
     assert b.group_launches() == 0
     b.close()
+
+
+def test_lane_form_module_builds():
+    m = C.CDLL(ensure_module(GROUP_DIM, lane=True))
+    info = (C.c_uint64 * 8)()
+    m.nm_module_info(info)
+    assert (info[2], info[3], info[4], info[6]) == (2, 1, 8, 1) and hasattr(m, "nm_module_launch_lane")
+
+
+@pytest.mark.gpu
+def test_user_density_lane_form_matches_oracle(oracle):
+    """A user density with a LANE form: its chains are drawn one per lane, 64 per wavefront, with the
+    oracle's bits — the one-chain-per-lane kernels are no longer reserved for the built-in densities."""
+    path = ensure_module(GROUP_DIM, lane=True)
+    prec = np.exp(np.random.default_rng(4).uniform(-2, 2, GROUP_DIM))
+    n = 150
+    s = N.DiagNutsSettings(num_chains=n, seed=79, num_tune=70)
+    x0 = oracle.init_positions_uniform(79, 0, n, GROUP_DIM)
+    b = N.ChainBatch(s, N.LogpSpec.module(GROUP_DIM, path, prec), n, lane_chains=2)
+    b.set_position(x0)
+    pos, st = b.draw_many(120)
+    assert b.lane_launches() >= 1 and b.group_launches() == 0
+    b.close()
+    pos_o, st_o, _, failed = run_oracle(oracle, s, N.LogpSpec.diag_normal(prec), n, x0, 120)
+    assert failed == 0
+    assert_bit_exact(pos, st, pos_o, st_o)
 
 
 WALLED = os.path.join(HERE, "user_density", "my_walled_normal.hpp")

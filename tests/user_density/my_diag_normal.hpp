@@ -83,3 +83,48 @@ struct MyDiagNormalGroup {
         return -0.5 * L::sum(acc) + norm;
     }
 };
+
+// The same density in LANE form (optional): for very many chains with dim <= 16 the engine draws one chain per LANE — the whole
+// vector (2 NP elements, zero beyond dim) sits in this lane's registers and nothing crosses lanes.  Sums over dim go through
+// nm::lane::pair_tree (pair partials in element order, then a balanced tree: the order every other kernel uses for <= 16 elements).
+#ifdef NM_MODULE_LANE_DENSITY
+template <int NP>
+struct MyDiagNormalLane {
+    static constexpr int E = 2 * NP;
+    const double* prec;
+    double norm;
+    NM_DEV void init(const double* params, int dim) {
+        prec = params;
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * l + j;
+                acc = acc + (d < dim ? nm::lane::llog(params[d < dim ? d : 0]) : 0.0);
+            }
+            p[l] = acc;
+        }
+        const double log_det_p = nm::lane::pair_tree<NP>(p);
+        norm = -0.5 * ((double)dim * nm::lane::llog(6.283185307179586) - log_det_p);
+    }
+    NM_DEV double eval(const double (&x)[E], double (&gx)[E], int dim) const {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                const bool valid = d < dim;
+                const double pr = valid ? prec[d] : 0.0;
+                const double px = pr * x[d];
+                gx[d] = valid ? -px : 0.0;
+                acc = acc + (valid ? x[d] * px : 0.0);
+            }
+            p[l] = acc;
+        }
+        return -0.5 * nm::lane::pair_tree<NP>(p) + norm;
+    }
+};
+#endif
