@@ -187,15 +187,25 @@ NM_DEV void gemm_stripes(GemmA& G, const double* packed, int w, int nst, int kpa
 #pragma unroll
         for (int h = 0; h < SPW; ++h)
 #pragma unroll
-            for (int i = 0; i < CH; ++i) a[h][i] = buf_load2(ra, lv, sbase[h] + (qq + i) * 1024);
+            for (int i = 0; i < CH; ++i) {
+#ifdef NM_LOCK_X_NOLOAD        // timing experiment (results are wrong): the products without their A-operand stream
+                a[h][i] = double2{(double)(qq + i), 1.0};
+#else
+                a[h][i] = buf_load2(ra, lv, sbase[h] + (qq + i) * 1024);
+#endif
+            }
     };
     auto chunk = [&](const double2 (&a)[SPW][CH], int qq) {       // its 16 MFMAs; the B operand of a k-step is read once for both stripes,
         double bv[2 * CH];                                        // and all eight of the chunk are requested before its first MFMA
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int r0 = 8 * (qq + i) + kk;
+#ifdef NM_LOCK_X_NOLDS         // timing experiment (results are wrong): ... without their B-operand reads
+            bv[2 * i] = (double)r0; bv[2 * i + 1] = (double)(r0 + c);
+#else
             bv[2 * i] = b[taddr(r0, c)];
             bv[2 * i + 1] = b[taddr(r0 + 4, c)];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -793,11 +803,11 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
             const int o = soff(slot, h);
             buf_store2(rscr, o, 0, v.a[0], v.a[1]); buf_store2(rscr, o + 16, 0, v.a[2], v.a[3]);
         };
-        Vec4 cz[SPW], cv[SPW], cg[SPW], pz[SPW], pvv[SPW], zin[SPW], vh[SPW], fx[SPW], fgx[SPW];
+        Vec4 cz[SPW], cv[SPW], cg[SPW], pz[SPW], pvv[SPW], zin[SPW], vh[SPW];
 #pragma unroll
         for (int h = 0; h < SPW; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { cz[h].a[r] = cv[h].a[r] = cg[h].a[r] = pz[h].a[r] = pvv[h].a[r] = zin[h].a[r] = vh[h].a[r] = fx[h].a[r] = fgx[h].a[r] = 0.; }
+            for (int r = 0; r < 4; ++r) { cz[h].a[r] = cv[h].a[r] = cg[h].a[r] = pz[h].a[r] = pvv[h].a[r] = zin[h].a[r] = vh[h].a[r] = 0.; }
         int round_mode = M_IDLE;          // what my column submitted in the round in flight
 #if NM_LOCK_PROF
         unsigned long long lkp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lkp_t = __builtin_amdgcn_s_memtime(), lkp_rounds = 0;
@@ -863,14 +873,15 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
                         if (st_cp >= 0) stS(pz[h], st_cp, h);
                         if (st_e >= 0) { stS(cz[h], EDGE0_Z + 3 * st_e, h); stS(cv[h], EDGE0_V + 3 * st_e, h); stS(cg[h], EDGE0_G + 3 * st_e, h); }
                     }
-                    if (fin) {                                     // the draw: fx, fgx, cz, cg
-                        if (P.out_positions) st_nat(fx[h], P.out_positions + row, s, g, dim);
-                        if (P.out_gradient) st_nat(fgx[h], P.out_gradient + row, s, g, dim);
+                    if (fin) {                                     // the draw's transformed point (its x and g_x rows left the registers in the products)
                         if (P.out_tpos) st_nat(cz[h], P.out_tpos + row, s, g, dim);
                         if (P.out_tgrad) st_nat(cg[h], P.out_tgrad + row, s, g, dim);
                         if (round_mode == M_RECOMP) {
-                            st_nat(fx[h], my_pv + (size_t)P_X * P.dpad, s, g, dim); st_nat(fgx[h], my_pv + (size_t)P_GX * P.dpad, s, g, dim);
                             st_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); st_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
+                        } else {                                   // M_KEEP: the stored point is the draw
+                            Vec4 t;
+                            if (P.out_positions) { ld_nat(t, my_pv + (size_t)P_X * P.dpad, s, g, dim); st_nat(t, P.out_positions + row, s, g, dim); }
+                            if (P.out_gradient) { ld_nat(t, my_pv + (size_t)P_GX * P.dpad, s, g, dim); st_nat(t, P.out_gradient + row, s, g, dim); }
                         }
                     }
                     if (round_mode == M_WHITEN) {                  // the re-whitened point is the chain's current point from now on
@@ -935,7 +946,10 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
                 }
             }
             blk_barrier();
-            Vec4 x[SPW], y[SPW];
+            // the output row of a column that recomputes its chosen point (the draw that ends with this round)
+            const size_t out_row = (size_t)((S.sc[c].draw_count - P.row_base) * P.n_chains + my_chain) * P.dim;
+            Vec4 x[SPW];
+            double xyp[SPW];
             {   // xt = zin + U S ; x = sigma (xt + mu_lr) + mean  (compute_untransformed_position: low_rank.rs:349-375, diagonal.rs:248-257)
 #pragma unroll
                 for (int h = 0; h < SPW; ++h) acc[h] = v4d{zin[h].a[0], zin[h].a[1], zin[h].a[2], zin[h].a[3]};
@@ -959,17 +973,23 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
 #pragma unroll
                 for (int h = 0; h < SPW; ++h) acc[h] = v4d{0.0, 0.0, 0.0, 0.0};
                 gemm_stripes(G, M.p, w, M.dim_st, M.dim_kp, S.t[0], acc);
-#pragma unroll
-                for (int h = 0; h < SPW; ++h)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[h].a[r] = acc[h][r];
             }
-            Vec4 t3[SPW], gx[SPW];
+            // y is used up here: the stripe's part of x'Px, g_x = -y, t3 = sigma g_x — and a recomputing column's x and g_x rows go
+            // straight to the draw's output row and the chain's persistent slots (nothing of x, y, g_x stays live across the last two
+            // products: with them the products spilled)
+            Vec4 t3[SPW];
 #pragma unroll
             for (int h = 0; h < SPW; ++h) {
                 const int s = w * SPW + h;
+                Vec4 gx;
+                double xy = 0.;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { gx[h].a[r] = 0.0; t3[h].a[r] = 0.0; }
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * s + g + 4 * r;
+                    gx.a[r] = 0.0; t3[h].a[r] = 0.0;
+                    xy = xy + (d < dim ? x[h].a[r] * acc[h][r] : 0.0);
+                }
+                xyp[h] = xy;
                 if (round_mode == M_WHITEN) {
                     Vec4 g0;
                     ld_nat(g0, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
@@ -977,7 +997,12 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
                     for (int r = 0; r < 4; ++r) t3[h].a[r] = g0.a[r] * S.sig[16 * s + g + 4 * r];
                 } else if (round_mode == M_LEAF || round_mode == M_RECOMP) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const int d = 16 * s + g + 4 * r; gx[h].a[r] = d < dim ? -y[h].a[r] : 0.0; t3[h].a[r] = gx[h].a[r] * S.sig[d]; }
+                    for (int r = 0; r < 4; ++r) { const int d = 16 * s + g + 4 * r; gx.a[r] = d < dim ? -acc[h][r] : 0.0; t3[h].a[r] = gx.a[r] * S.sig[d]; }
+                    if (round_mode == M_RECOMP) {
+                        if (P.out_positions) st_nat(x[h], P.out_positions + out_row, s, g, dim);
+                        if (P.out_gradient) st_nat(gx, P.out_gradient + out_row, s, g, dim);
+                        st_nat(x[h], my_pv + (size_t)P_X * P.dpad, s, g, dim); st_nat(gx, my_pv + (size_t)P_GX * P.dpad, s, g, dim);
+                    }
                 }
                 put_stripe(S.t[1], s, t3[h]);
             }
@@ -1029,21 +1054,17 @@ __global__ __launch_bounds__(64 * LWV, LWV / 4) void nuts_lockstep_kernel(const 
                 const int s = w * SPW + h;
                 pz[h] = cz[h]; pvv[h] = cv[h];
                 cz[h] = zin[h]; cg[h] = gz[h];                     // every column: nothing of the old point stays live across the products
-                fx[h] = x[h]; fgx[h] = gx[h];
                 if (round_mode == M_LEAF) {
-                    double ke = 0., xy = 0., ki = 0., t1 = 0., t2 = 0.;
+                    double ke = 0., ki = 0., t1 = 0., t2 = 0.;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int d = 16 * s + g + 4 * r;
                         cv[h].a[r] = __builtin_fma(half1, gz[h].a[r], vh[h].a[r]);
                         ke = __builtin_fma(cv[h].a[r], cv[h].a[r], ke);
-                        xy = xy + (d < dim ? x[h].a[r] * y[h].a[r] : 0.0);
                         ki = __builtin_fma(pvv[h].a[r], pvv[h].a[r], ki);
                         turn_acc(pz[h].a[r], pvv[h].a[r], cz[h].a[r], cv[h].a[r], t1, t2);
                     }
-                    emit(s, 0, ke); emit(s, 1, xy); emit(s, 2, ki); emit(s, 4, t1); emit(s, 5, t2);
+                    emit(s, 0, ke); emit(s, 1, xyp[h]); emit(s, 2, ki); emit(s, 4, t1); emit(s, 5, t2);
                 } else if (round_mode == M_KEEP) {                 // the stored point
-                    ld_nat(fx[h], my_pv + (size_t)P_X * P.dpad, s, g, dim); ld_nat(fgx[h], my_pv + (size_t)P_GX * P.dpad, s, g, dim);
                     ld_nat(cz[h], my_pv + (size_t)P_Z * P.dpad, s, g, dim); ld_nat(cg[h], my_pv + (size_t)P_GZ * P.dpad, s, g, dim);
                 }
                 if (round_mode == M_RECOMP || round_mode == M_KEEP) {
