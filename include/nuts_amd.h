@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 14
+#define NM_ABI_VERSION 15
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -425,6 +425,32 @@ int nm_lowrank_compute_update(void* unused, uint64_t dim, uint64_t n_draws, cons
 int nm_lowrank_test_spd_mean(uint64_t n, const double* cov_draws, const double* cov_grads, double* out, uint64_t force_base);
 int nm_lowrank_test_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const double* draws, const double* grads, double gamma,
                                          double* vals, double* vecs, uint64_t force_base);
+
+/* WHERE the built-in estimator runs.  The reference runs `compute_update` (src/transform/adapt/low_rank.rs:73-142) in the thread
+ * that runs the chain; here the default (NM_LR_PLACE_AUTO) is the device that runs the chains: one 256-thread block per paused
+ * chain works on the chain's window where the draw kernel left it (csrc/lowrank_device.hip, the block form of the same
+ * algorithm: csrc/lowrank_block.hpp), for dim <= 256 and windows of <= 1024 draws; other shapes, and any estimator set with
+ * nm_engine_set_lowrank_estimator, run on host threads.  NM_LR_PLACE_HOST: always the host threads.  NM_LR_PLACE_DEVICE: the
+ * device or NM_ERR_UNSUPPORTED at the first window it does not take.  The device form sums in another order than the host form:
+ * the two agree to rounding on full-rank windows and within the reference algorithm's own conditioning on rank-deficient ones
+ * (tests/test_lowrank_estimator_builtin.py states the tolerances for both against the literal reference algorithm). */
+#define NM_LR_PLACE_AUTO 0
+#define NM_LR_PLACE_HOST 1
+#define NM_LR_PLACE_DEVICE 2
+nm_status nm_engine_set_lowrank_estimator_place(nm_engine* e, uint64_t place);
+uint64_t  nm_engine_lowrank_device_updates(const nm_engine* e);   /* estimator calls that ran on the device so far */
+/* The device form's host TWIN (nm_lowrank_estimator_fn's signature; host only): the same steps walked by one thread with the
+ * kernel's reduction trees — bit for bit what the kernel computes (tests/test_gpu_lowrank.py), so CPU tests of the twin are
+ * statements about the kernel.  Returns 1 (None) also for shapes the block algorithm does not take. */
+int nm_lowrank_block_twin(void* unused, uint64_t dim, uint64_t n_draws, const double* draws, const double* grads,
+                          double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig,
+                          double* vals, double* vecs, double* mu_low_rank);
+/* Test hook: the estimator KERNEL on a batch of windows of one shape.  draws / grads [n_windows][n_draws][dim]; outputs carry a
+ * leading [n_windows] axis, vals [kmax] and vecs [kmax][dim] with kmax = min(dim, 2 n_draws); status[w] = 0 (Some) / 1 (None);
+ * logdet_bits[w] (optional) = the bits of -1/2 sum ln lambda.  Returns a hipError_t (0 = success). */
+int nm_lowrank_test_block_device(uint64_t dim, uint64_t n_draws, uint64_t n_windows, const double* draws, const double* grads,
+                                 double gamma, double eigval_cutoff, double* stds, double* mean, uint64_t* n_eig, double* vals,
+                                 double* vecs, double* mu_low_rank, uint64_t* status, uint64_t* logdet_bits);
 
 /* `LowRankMassMatrix::update(stds, mean, vals, vecs, mean_low_rank)` (src/transform/low_rank.rs:155-186) for every chain,
  * from the host: the transformation version moves on and the current points are re-whitened lazily at their next

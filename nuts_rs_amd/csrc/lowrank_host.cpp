@@ -46,10 +46,16 @@ extern "C" int nm_lowrank_compute_update(void*, uint64_t dim, uint64_t n_draws, 
     return (lr_wide() ? lr_avx2::compute_update : lr_base::compute_update)(dim, n_draws, draws, grads, gamma, eigval_cutoff, stds, mean, n_eig,
                                                                           vals, vecs, mu_low_rank);
 }
+// (lowrank_device.hip: the same two routines of the block form's twin; force_base == 2 selects them)
+extern "C" int nm_lowrank_block_twin_spd_mean(uint64_t n, const double* cov_draws, const double* cov_grads, double* out);
+extern "C" int nm_lowrank_block_twin_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const double* draws, const double* grads, double gamma,
+                                                          double* vals, double* vecs);
 extern "C" int nm_lowrank_test_spd_mean(uint64_t n, const double* cov_draws, const double* cov_grads, double* out, uint64_t force_base) {
+    if (force_base == 2) return nm_lowrank_block_twin_spd_mean(n, cov_draws, cov_grads, out);
     return (lr_wide() && !force_base ? lr_avx2::hook_spd_mean : lr_base::hook_spd_mean)(n, cov_draws, cov_grads, out);
 }
 extern "C" int nm_lowrank_test_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const double* draws, const double* grads, double gamma,
                                                     double* vals, double* vecs, uint64_t force_base) {
+    if (force_base == 2) return nm_lowrank_block_twin_estimate_mass_matrix(rows, n_draws, draws, grads, gamma, vals, vecs);
     return (lr_wide() && !force_base ? lr_avx2::hook_estimate_mass_matrix : lr_base::hook_estimate_mass_matrix)(rows, n_draws, draws, grads, gamma, vals, vecs);
 }

@@ -495,6 +495,16 @@ class ChainBatch:
         self._keep_est = fn
         check(_lib.load().nm_engine_set_lowrank_estimator(self._h, C.cast(fn, C.c_void_p) if fn is not None else None, None, n_threads))
 
+    def set_lowrank_estimator_place(self, place):
+        """Where the built-in estimator runs (nm_engine_set_lowrank_estimator_place): 0 / "auto" the device where the block
+        algorithm takes the window (dim <= 256, <= 1024 draws), else host threads; 1 / "host"; 2 / "device" (or an error)."""
+        place = {"auto": 0, "host": 1, "device": 2}.get(place, place)
+        check(_lib.load().nm_engine_set_lowrank_estimator_place(self._h, int(place)))
+
+    def lowrank_device_updates(self):
+        """Estimator calls that ran on the device so far."""
+        return int(_lib.load().nm_engine_lowrank_device_updates(self._h))
+
     def lowrank(self):
         """Current low-rank part per chain: (n_eig [n_chains], lambda^(1/2) [n_chains, max_rank], vecs [n_chains, max_rank, dim],
         mu_low_rank [n_chains, dim])."""

@@ -7,7 +7,9 @@ src/transform/adapt/low_rank.rs, src/math/cpu_math.rs:332-425) against the CPU o
   * whole chains with LowRankNutsSettings' ADAPTATION, the estimator's dense linear algebra injected identically on both
     sides (the oracle's LAPACK restatement), so that everything else — windows, schedule, pause / resume protocol,
     re-whitening, step-size search after the first update, statistics — must agree                 — bit-exact
-  * the built-in host estimator end to end (statistical) and the full-size K5 run (properties)
+  * the built-in estimator: its device form (one block per paused chain, what a default run executes) bit for bit against its
+    host twin, and a whole adaptive warm-up bit-exact against the oracle running that twin; the host form end to end
+    (statistical, and window by window against the literal reference algorithm); the full-size K5 run (properties)
 """
 import ctypes as C
 
@@ -236,6 +238,134 @@ def test_builtin_estimator_matches_lapack_restatement(oracle):
         assert np.allclose(np.sort(vals[:k]), np.sort(ref[2]), rtol=1e-8)
         assert np.abs(op(vals[:k], vecs[:k]) - op(ref[2], ref[3].T)).max() < 1e-8 * max(1.0, np.abs(op(ref[2], ref[3].T)).max())
         assert np.allclose(mu, ref[4], atol=1e-8)
+
+
+def twin_update(L, d, g, gamma, cutoff):
+    """nm_lowrank_block_twin on one window given as [n][dim] rows"""
+    n, dim = d.shape
+    m = min(dim, 2 * n)
+    stds, mean, vals, vecs, mu = np.zeros(dim), np.zeros(dim), np.zeros(m), np.zeros((m, dim)), np.zeros(dim)
+    ne = C.c_uint64()
+    rc = L.nm_lowrank_block_twin(None, dim, n, d.ctypes.data, g.ctypes.data, gamma, cutoff, stds.ctypes.data, mean.ctypes.data, C.byref(ne),
+                                 vals.ctypes.data, vecs.ctypes.data, mu.ctypes.data)
+    return rc, int(ne.value), stds, mean, vals, vecs, mu
+
+
+@pytest.mark.parametrize("dim,n", [(1, 5), (5, 3), (8, 40), (20, 12), (37, 50), (64, 30), (64, 100), (128, 100), (130, 70), (256, 60)])
+def test_estimator_kernel_is_its_twin_bit_for_bit(dim, n):
+    """The estimator KERNEL (csrc/lowrank_device.hip: one 256-thread block per window) against its host twin (the same template
+    code walked by one thread with the kernel's reduction trees): sigma, mean, mu, the eigenvalues, every eigenvector, the rank,
+    the log-determinant and the None cases, bit for bit.  The twin is what the CPU tests pin to the reference's KATs and to the
+    literal algorithm (tests/test_lowrank_estimator_builtin.py, impl "block")."""
+    import test_lowrank_estimator_builtin as T
+    L = _lib.load()
+    rng = np.random.default_rng(dim * 977 + n)
+    nw, gamma, cutoff = 7, 1e-5, 2.0
+    D, G = np.zeros((nw, n, dim)), np.zeros((nw, n, dim))
+    for w in range(nw):
+        if dim >= 4:
+            x, g = T.correlated_window(rng, dim, n, min(3, dim - 1))
+        else:
+            x = rng.normal(size=(dim, n)) * 3.0 + 1.0
+            g = -(x - 1.0) / 9.0
+        D[w], G[w] = x.T, g.T
+    G[3, :, dim // 2] = 2.0                               # grad variance 0 -> sigma not finite -> None
+    D[5] = D[5, :1]                                       # every draw the same point: zero variance -> None
+    m = min(dim, 2 * n)
+    stds, mean, mu = np.zeros((nw, dim)), np.zeros((nw, dim)), np.zeros((nw, dim))
+    vals, vecs = np.zeros((nw, m)), np.zeros((nw, m, dim))
+    n_eig, status, ld = np.zeros(nw, dtype=np.uint64), np.zeros(nw, dtype=np.uint64), np.zeros(nw, dtype=np.uint64)
+    er = L.nm_lowrank_test_block_device(dim, n, nw, D.ctypes.data, G.ctypes.data, gamma, cutoff, stds.ctypes.data, mean.ctypes.data, n_eig.ctypes.data,
+                                        vals.ctypes.data, vecs.ctypes.data, mu.ctypes.data, status.ctypes.data, ld.ctypes.data)
+    assert er == 0
+    some = 0
+    for w in range(nw):
+        rc, k, st, mn, vl, vc, m_ = twin_update(L, np.ascontiguousarray(D[w]), np.ascontiguousarray(G[w]), gamma, cutoff)
+        assert int(status[w]) == rc, (w, int(status[w]), rc)
+        if rc:
+            continue
+        some += 1
+        assert int(n_eig[w]) == k
+        for name, a, b in (("sigma", stds[w], st), ("mean", mean[w], mn), ("mu", mu[w], m_), ("vals", vals[w, :k], vl[:k]), ("vecs", vecs[w, :k], vc[:k])):
+            assert (a.view(np.uint64) == b.view(np.uint64)).all(), (w, name, np.abs(a - b).max())
+        want_ld = -0.0
+        for v in vl[:k]:
+            want_ld += -0.5 * np.log(v)
+        assert abs(ld[w:w + 1].view(np.float64)[0] - want_ld) <= 1e-12 * (1.0 + abs(want_ld))
+    assert some >= nw - 2 and status[3] == 1 and status[5] == 1
+
+
+@pytest.mark.parametrize("case", ["mvn_dim20_correlated", "funnel_dim11", "mvn_dim64_update_freq5", "mvn_dim128"])
+def test_lowrank_adaptation_device_estimator_bit_exact(oracle, case):
+    """A whole LowRankNutsSettings warm-up as a DEFAULT run executes it — the built-in estimator on the device, one block per
+    paused chain (NM_LR_PLACE_AUTO) — against the oracle with the device form's host twin as its estimator: bit-exact, every
+    draw, every statistic, the mass-matrix vectors.  (The same run with the estimator on the host threads,
+    NM_LR_PLACE_HOST, is a different rounding of the same algorithm: compared through the tolerances of
+    test_builtin_estimator_whole_run_vs_literal_reference_algorithm.)"""
+    L = _lib.load()
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    n, tune, draws, freq = 4, 120, 150, 20
+    if case == "mvn_dim20_correlated":
+        logp = N.LogpSpec.mvn_precision(correlated_precision(rng, 20, 2)[0])
+    elif case == "funnel_dim11":
+        logp = N.LogpSpec.funnel(11)
+    elif case == "mvn_dim64_update_freq5":
+        logp, n, tune, draws, freq = N.LogpSpec.mvn_precision(correlated_precision(rng, 64, 3)[0]), 3, 100, 120, 5
+    else:
+        logp, n, tune, draws, freq = N.LogpSpec.mvn_precision(correlated_precision(rng, 128, 5)[0]), 3, 160, 180, 20
+    s = lowrank_settings(num_chains=n, seed=5, num_tune=tune, store_mass_matrix=True)
+    s.adapt_options.mass_matrix_update_freq = freq
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, logp.dim)
+    b = N.ChainBatch(s, logp, n)
+    assert (b.set_position(x0) == 0).all()
+    b.set_lowrank_estimator_place("device")
+    pos, st, vec = b.expanded_draw_many(draws, vectors=["mass_matrix_inv", "mass_matrix_eigvals", "gradient"])
+    tpc = b.threads_per_chain()
+    n_dev = b.lowrank_device_updates()
+    b.close()
+    assert n_dev >= n * 3
+    cb_o = C.cast(L.nm_lowrank_block_twin, oracle.ESTIMATOR_FN)
+    vo = {}
+    pos_o, st_o, _, failed = oracle.run(oracle_settings(oracle, s), logp.kind, logp.dim, logp.params, oracle.gpu_cfg(tpc), n, x0,
+                                        draws, estimator=cb_o, vectors=vo)
+    assert failed == 0
+    assert_bit_exact(pos, st, pos_o, st_o)
+    assert (st["num_eigenvalues"] == st_o["num_eigenvalues"]).all()
+    for k in vec:
+        both_nan = np.isnan(vec[k]) & np.isnan(vo[k])
+        assert ((vec[k].view(np.uint64) == vo[k].view(np.uint64)) | both_nan).all(), k
+    assert (st["transformation_update_id"] >= 0).sum() >= n * 3 and st["num_eigenvalues"].max() >= (1 if "mvn" in case else 0)
+
+
+def test_estimator_place_host_and_device_agree_statistically_and_unsupported_shapes(oracle):
+    """NM_LR_PLACE_HOST keeps the estimator on the host threads (no device updates); NM_LR_PLACE_DEVICE refuses a shape the block
+    algorithm does not take (dim > 256) at the first window, NM_LR_PLACE_AUTO runs it on the host."""
+    rng = np.random.default_rng(8)
+    logp = N.LogpSpec.mvn_precision(correlated_precision(rng, 24, 2)[0])
+    s = lowrank_settings(num_chains=8, seed=3, num_tune=100)
+    eps = {}
+    for place in ("host", "device"):
+        b = N.ChainBatch(s, logp, 8)
+        b.set_position(b.init_positions_uniform())
+        b.set_lowrank_estimator_place(place)
+        _, st = b.draw_many(140)
+        assert (b.lowrank_device_updates() > 0) == (place == "device")
+        eps[place] = st["step_size"][100:].mean()
+        b.close()
+    assert abs(np.log(eps["host"] / eps["device"])) < np.log(1.3)
+    big = N.LogpSpec.iid_normal(300, 1.0)
+    s = lowrank_settings(num_chains=2, seed=3, num_tune=40)
+    b = N.ChainBatch(s, big, 2)
+    b.set_position(b.init_positions_uniform())
+    b.draw_many(45)
+    assert b.lowrank_device_updates() == 0                # auto: host threads
+    b.close()
+    b = N.ChainBatch(s, big, 2)
+    b.set_position(b.init_positions_uniform())
+    b.set_lowrank_estimator_place("device")
+    with pytest.raises(Exception, match="NM_LR_PLACE_DEVICE"):
+        b.draw_many(45)
+    b.close()
 
 
 @pytest.mark.parametrize("dim,tune", [(64, 300), (128, 220)])

@@ -1,8 +1,8 @@
-"""LowRankNutsSettings end to end at scale: the whole warm-up with per-chain low-rank adaptation (device kernels + the host
-estimator between launches), then sampling.  One JSON line: wall time of the warm-up, the share spent in the host
-estimator rounds, estimator calls, ranks found, sampling throughput.
+"""LowRankNutsSettings end to end at scale: the whole warm-up with per-chain low-rank adaptation (draw kernels + the estimator
+rounds between launches: on the device by default, --place host for the host threads), then sampling.  One JSON line: wall time
+of the warm-up, the share spent outside the draw kernels, the estimator rounds' parts, ranks found, sampling throughput.
 
-  python tools/bench_lowrank_adapt.py [--chains 1024] [--dim 128] [--tune 300] [--draws 100]
+  python tools/bench_lowrank_adapt.py [--chains 1024] [--dim 128] [--tune 300] [--draws 100] [--place auto|host|device]
 """
 import argparse
 import json
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--tune", type=int, default=300)
     ap.add_argument("--draws", type=int, default=100)
+    ap.add_argument("--place", default="auto")
     a = ap.parse_args()
     rng = np.random.default_rng(3)
     u = np.linalg.qr(rng.normal(size=(a.dim, 4)))[0]
@@ -33,6 +34,7 @@ def main():
     prec = (prec + prec.T) / 2
     s = N.LowRankNutsSettings(num_chains=a.chains, seed=11, num_tune=a.tune, num_draws=a.draws)
     b = N.ChainBatch(s, N.LogpSpec.mvn_precision(prec), a.chains)
+    b.set_lowrank_estimator_place(a.place)
     b.init_with_retries()
     t = time.time()
     _, st_w = b.draw_many(a.tune, positions=False)
@@ -52,7 +54,9 @@ def main():
     print(json.dumps({
         "config": f"LowRankNutsSettings, full-precision normal dim {a.dim} (4 strong directions) x {a.chains} chains, num_tune {a.tune}",
         "warmup_wall_s": t_warm, "warmup_kernel_s": c_w["kernel_ms"] * 1e-3, "warmup_launches": c_w["kernel_launches"],
-        "warmup_host_share": 1.0 - c_w["kernel_ms"] * 1e-3 / t_warm,
+        "estimator_place": a.place, "estimator_calls_on_device": b.lowrank_device_updates(),
+        "warmup_share_outside_draw_kernels": 1.0 - c_w["kernel_ms"] * 1e-3 / t_warm,
+        "warmup_host_share": (t_warm - c_w["kernel_ms"] * 1e-3 - (tm[2] if b.lowrank_device_updates() else 0.0)) / t_warm,
         "estimator_rounds_s": {"total": tm[0], "window_download": tm[1], "estimator_threads": tm[2], "upload_scatter": tm[3],
                                "rounds": int(tm[4]), "estimator_calls": int(tm[5])},
         "updates_per_chain": float((st_w["transformation_update_id"] >= 0).sum() / a.chains),
