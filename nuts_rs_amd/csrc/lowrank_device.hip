@@ -217,22 +217,28 @@ extern "C" int nm_lowrank_test_block_device(uint64_t dim, uint64_t n, uint64_t n
     uint64_t *d_jobs = nullptr, *d_meta = nullptr; unsigned long long* d_tw = nullptr; ChainScalars* d_sc = nullptr;
     hipError_t er = hipSuccess;
     auto T = [&](hipError_t x) { if (er == hipSuccess) er = x; };
+    hipStream_t st = nullptr;                              // (stream discipline: the hook's own stream, nothing on the null stream)
+    T(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    auto up = [&](void* d, const void* h, size_t n) { T(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st)); };
+    auto down = [&](void* h, const void* d, size_t n) { T(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, st)); };
+    auto zero = [&](void* d, size_t n) { T(hipMemsetAsync(d, 0, n, st)); };
     T(hipMalloc((void**)&d_win, win.size() * 8)); T(hipMalloc((void**)&d_scr, ss * grid * 8)); T(hipMalloc((void**)&d_rows, nw * rows * dim * 8));
     T(hipMalloc((void**)&d_v2, nw * 2 * rmax * 8)); T(hipMalloc((void**)&d_vp, nw * rmax * 8)); T(hipMalloc((void**)&d_jobs, jobs.size() * 8));
     T(hipMalloc((void**)&d_meta, jobs.size() * 8)); T(hipMalloc((void**)&d_tw, 8)); T(hipMalloc((void**)&d_sc, nw * sizeof(ChainScalars)));
     if (er == hipSuccess) {
-        T(hipMemcpy(d_win, win.data(), win.size() * 8, hipMemcpyHostToDevice));
-        T(hipMemcpy(d_jobs, jobs.data(), jobs.size() * 8, hipMemcpyHostToDevice));
-        T(hipMemset(d_tw, 0, 8)); T(hipMemset(d_sc, 0, nw * sizeof(ChainScalars))); T(hipMemset(d_rows, 0, nw * rows * dim * 8));
-        T(launch_estimate(grid, nullptr, d_jobs, nw, dim, d_win, n, gamma, eigval_cutoff, d_scr, ss, d_rows, rows, dim, d_v2, rmax, d_meta, d_tw, d_sc, d_vp));
-        T(hipDeviceSynchronize());
+        up(d_win, win.data(), win.size() * 8);
+        up(d_jobs, jobs.data(), jobs.size() * 8);
+        zero(d_tw, 8); zero(d_sc, nw * sizeof(ChainScalars)); zero(d_rows, nw * rows * dim * 8);
+        T(launch_estimate(grid, st, d_jobs, nw, dim, d_win, n, gamma, eigval_cutoff, d_scr, ss, d_rows, rows, dim, d_v2, rmax, d_meta, d_tw, d_sc, d_vp));
+        T(hipStreamSynchronize(st));
     }
     if (er == hipSuccess) {
         std::vector<double> h_rows(nw * rows * dim), h_vp(nw * rmax);
         std::vector<uint64_t> meta(3 * nw);
         std::vector<ChainScalars> sc(nw);
-        T(hipMemcpy(h_rows.data(), d_rows, h_rows.size() * 8, hipMemcpyDeviceToHost)); T(hipMemcpy(h_vp.data(), d_vp, h_vp.size() * 8, hipMemcpyDeviceToHost));
-        T(hipMemcpy(meta.data(), d_meta, meta.size() * 8, hipMemcpyDeviceToHost)); T(hipMemcpy(sc.data(), d_sc, nw * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        down(h_rows.data(), d_rows, h_rows.size() * 8); down(h_vp.data(), d_vp, h_vp.size() * 8);
+        down(meta.data(), d_meta, meta.size() * 8); down(sc.data(), d_sc, nw * sizeof(ChainScalars));
+        T(hipStreamSynchronize(st));
         if (er == hipSuccess)
             for (size_t w = 0; w < nw; ++w) {
                 const double* R = &h_rows[w * rows * dim];
@@ -247,5 +253,6 @@ extern "C" int nm_lowrank_test_block_device(uint64_t dim, uint64_t n, uint64_t n
     }
     (void)hipFree(d_win); (void)hipFree(d_scr); (void)hipFree(d_rows); (void)hipFree(d_v2); (void)hipFree(d_vp); (void)hipFree(d_jobs); (void)hipFree(d_meta);
     (void)hipFree(d_tw); (void)hipFree(d_sc);
+    if (st) (void)hipStreamDestroy(st);
     return (int)er;
 }
