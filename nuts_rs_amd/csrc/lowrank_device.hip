@@ -20,8 +20,19 @@ using namespace nm::lrb;
 
 namespace {
 
+#ifdef NM_LRB_PROF
+__device__ unsigned long long lrb_prof[16];
+#endif
 struct DevEx {
     int tid; Small* S;
+#ifdef NM_LRB_PROF
+    unsigned long long last = 0;
+    __device__ __forceinline__ void mark(int id) {
+        if (tid == 0) { const unsigned long long t = wall_clock64(); if (last) atomicAdd(&lrb_prof[id], t - last); last = t; }
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
     template <class F> __device__ __forceinline__ void par(size_t n, F f) {
         __syncthreads();
         for (size_t i = (size_t)tid; i < n; i += LRB_T) f(i);
@@ -41,6 +52,41 @@ struct DevEx {
         if ((tid & 63) == 0) S->red[tid >> 6] = p;
         __syncthreads();
         return ((S->red[0] + S->red[1]) + S->red[2]) + S->red[3];
+    }
+    // item i: *addr(i) = f(i, *addr(i)); four items in flight per thread (their loads before their stores)
+    template <class FA, class F> __device__ __forceinline__ void rmw(size_t n, FA addr, F f) {
+        __syncthreads();
+        for (size_t i = (size_t)tid; i < n; i += 4 * LRB_T) {
+            double* p[4]; double v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (i + c * LRB_T < n) { p[c] = addr(i + c * LRB_T); v[c] = *p[c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (i + c * LRB_T < n) *p[c] = f(i + c * LRB_T, v[c]);
+        }
+        __syncthreads();
+    }
+    // out(j, sum_k f(k, j)) for j < ncols, k < len: one wavefront per column (four columns at a time), lane l sums k = l, l + 64, ...
+    // then the butterfly
+    template <class F, class FO> __device__ __forceinline__ void col_dots(size_t ncols, size_t len, F f, FO out) {
+        __syncthreads();
+        const size_t lane = (size_t)(tid & 63);
+        for (size_t j0 = (size_t)(tid >> 6) * 4; j0 < ncols; j0 += 16) {
+            double p[4] = {0.0, 0.0, 0.0, 0.0};
+            for (size_t k = lane; k < len; k += 64) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (j0 + c < ncols) p[c] += f(k, j0 + c);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) p[c] += __shfl_xor(p[c], off);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (j0 + c < ncols) out(j0 + c, p[c]);
+            }
+        }
+        __syncthreads();
     }
     // largest f(i); ties and the all-NaN case go to the smallest index (val = -inf, idx = n when nothing compares)
     template <class F> __device__ __forceinline__ void argmax(size_t n, F f, double& val, size_t& idx) {
@@ -63,6 +109,7 @@ struct DevEx {
 
 // the same steps, one thread: items in a loop, the reductions through the device's tree
 struct SimEx {
+    void mark(int) {}
     template <class F> void par(size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
     template <class F> void one(F f) { f(); }
     template <class F> double sum(size_t n, F f) {
@@ -75,6 +122,20 @@ struct SimEx {
             memcpy(p, q, sizeof(p));
         }
         return ((p[0] + p[64]) + p[128]) + p[192];
+    }
+    template <class FA, class F> void rmw(size_t n, FA addr, F f) { for (size_t i = 0; i < n; ++i) { double* p = addr(i); *p = f(i, *p); } }
+    template <class F, class FO> void col_dots(size_t ncols, size_t len, F f, FO out) {
+        for (size_t j = 0; j < ncols; ++j) {
+            double p[64];
+            for (int t = 0; t < 64; ++t) p[t] = 0.0;
+            for (size_t k = 0; k < len; ++k) p[k % 64] += f(k, j);
+            for (int off = 32; off >= 1; off >>= 1) {
+                double q[64];
+                for (int t = 0; t < 64; ++t) q[t] = p[t] + p[t ^ off];
+                memcpy(p, q, sizeof(p));
+            }
+            out(j, p[0]);
+        }
     }
     template <class F> void argmax(size_t n, F f, double& val, size_t& idx) {
         double bv = -HUGE_VAL; size_t bi = n;             // the tree's winner is the first largest element: order-free
@@ -120,6 +181,14 @@ __global__ __launch_bounds__(LRB_T) void lr_estimate_kernel(const uint64_t* jobs
     }
 }
 
+#ifdef NM_LRB_PROF
+// tuning builds: wall-clock ticks (100 MHz) per phase, summed over blocks; out[16]
+extern "C" int nm_debug_lrb_prof(unsigned long long* out, int reset) {
+    hipError_t er = hipMemcpyFromSymbol(out, HIP_SYMBOL(lrb_prof), sizeof(lrb_prof));
+    if (er == hipSuccess && reset) { unsigned long long z[16] = {0}; er = hipMemcpyToSymbol(HIP_SYMBOL(lrb_prof), z, sizeof(z)); }
+    return (int)er;
+}
+#endif
 bool block_estimator_takes(uint64_t dim, uint64_t n_max) { return dim >= 1 && dim <= LRB_KMAX && n_max >= 1 && n_max <= LRB_NMAX; }
 size_t block_estimator_scratch_doubles(uint64_t dim, uint64_t n_max) { return scratch_doubles((size_t)dim, (size_t)n_max); }
 
@@ -167,7 +236,8 @@ extern "C" int nm_lowrank_block_twin_spd_mean(uint64_t n, const double* cov_draw
     memcpy(&buf[n * n], cov_grads, n * n * sizeof(double));
     static thread_local Small S;
     SimEx ex;
-    M covd{&buf[0], (size_t)n}, covg{&buf[n * n], (size_t)n}, t1{&buf[2 * n * n], (size_t)n}, t2{&buf[3 * n * n], (size_t)n}, t3{&buf[4 * n * n], (size_t)n};
+    const size_t nn = (size_t)n;
+    const M covd = colmajor(&buf[0], nn), covg = colmajor(&buf[nn * nn], nn), t1 = colmajor(&buf[2 * nn * nn], nn), t2 = colmajor(&buf[3 * nn * nn], nn), t3 = colmajor(&buf[4 * nn * nn], nn);
     if (!spd_mean(ex, S, covd, covg, t1, t2, t3, (size_t)n)) return 1;
     memcpy(out, &buf[0], n * n * sizeof(double));
     return 0;
@@ -179,8 +249,8 @@ extern "C" int nm_lowrank_block_twin_estimate_mass_matrix(uint64_t rows, uint64_
     std::vector<double> buf(5 * K * K, 0.0);
     static thread_local Small S;
     SimEx ex;
-    M covd{&buf[0], K}, covg{&buf[K * K], K}, t1{&buf[2 * K * K], K}, t2{&buf[3 * K * K], K}, t3{&buf[4 * K * K], K};
-    M DP{const_cast<double*>(draws), K}, GP{const_cast<double*>(grads), K};
+    const M covd = colmajor(&buf[0], K), covg = colmajor(&buf[K * K], K), t1 = colmajor(&buf[2 * K * K], K), t2 = colmajor(&buf[3 * K * K], K), t3 = colmajor(&buf[4 * K * K], K);
+    const M DP = colmajor(const_cast<double*>(draws), K), GP = colmajor(const_cast<double*>(grads), K);
     const double ig = 1.0 / gamma;
     ex.par(K * K, [&](size_t idx) {
         const size_t i = idx % K, j = idx / K;
