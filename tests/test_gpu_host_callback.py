@@ -107,7 +107,9 @@ def test_host_callback_low_rank_transformation(oracle):
     pos, st = b.draw_many(400)
     b.close()
     sample = pos[200:].reshape(-1, 6)
-    assert (st["chain_status"] == 0).all() and abs(sample[:, 0].mean()) < 0.5 and 2.0 < sample[:, 0].var() < 7.0
+    # (1600 correlated draws of a heavy-shouldered target: over seeds 4..6 and both places of the estimator the sample variance of x0
+    #  came out between 1.5 and 5.0, the mean within 0.4 — tools/probes/hostcb_lowrank_probe.py; the band is for that spread)
+    assert (st["chain_status"] == 0).all() and abs(sample[:, 0].mean()) < 0.6 and 1.0 < sample[:, 0].var() < 8.0
     assert abs((sample[:, 1] - sample[:, 0] ** 2).mean()) < 0.2
 
 

@@ -91,6 +91,14 @@ def make_case(rng, scale=False):
         transform = (stds, mean, vals, np.ascontiguousarray(vecs).reshape(shp + (rank, dim)), mu)
         s = N.LowRankNutsSettings(freeze_transform=True, **kw)
         sampler = "lowrank-" + sampler
+    elif sampler != "mclmc" and not scale and dim <= 256 and rng.random() < 0.25:      # LowRankNutsSettings ADAPTING: the estimator kernel
+        lk = dict(kw)                                                                    # (engine) against its host twin (oracle)
+        lk["num_tune"] = int(rng.choice([60, 100, 150]))
+        s = N.LowRankNutsSettings(**lk)
+        s.adapt_options.mass_matrix_update_freq = int(rng.choice([1, 5, 20]))
+        transform = "adapt"
+        kw = lk
+        sampler = "lowrank-adapt-" + sampler
     eng = {}
     if sampler == "nuts" and dens != "schools" and dim <= 4096:
         from nuts_rs_amd.build import pick_tiling
@@ -111,6 +119,10 @@ def run_case(s, logp, n, draws, eng, rng=None, transform=None):
     x0 = O.init_positions_uniform(s.seed, 0, n, logp.dim)
     b = N.ChainBatch(s, logp, n, **eng)
     status = b.set_position(x0, raise_on_error=False)
+    adapt = isinstance(transform, str)
+    if adapt:
+        transform = None
+        b.set_lowrank_estimator_place("device")
     if transform is not None and (status == 0).all():
         b.set_transform(*transform)
     cut = draws // 2
@@ -122,17 +134,22 @@ def run_case(s, logp, n, draws, eng, rng=None, transform=None):
     b.close()
     cfg = O.gpu_cfg(tpc, gpu_slice=4096 if k > 1 else 0, lr_seq_dots=order if transform is not None else 0)
     so = oracle_settings(O, s)
+    est = {}
+    if adapt:
+        import ctypes as C
+        from nuts_rs_amd import _lib
+        est = dict(estimator=C.cast(_lib.load().nm_lowrank_block_twin, O.ESTIMATOR_FN))
     # per chain through the step-wise interface so that a failed chain does not end the comparison
     if n > 100:          # a sample of the chains, each from its own global id
         picks = sorted(set([0, n - 1] + [int(c) for c in rng.integers(0, n, 8)]))
-        outs = [O.run(so, logp.kind, logp.dim, logp.params, cfg, 1, x0[c:c + 1], draws, chain_offset=c, n_threads=1) for c in picks]
+        outs = [O.run(so, logp.kind, logp.dim, logp.params, cfg, 1, x0[c:c + 1], draws, chain_offset=c, n_threads=1, **est) for c in picks]
         pos_o = np.concatenate([o[0] for o in outs], axis=1); st_o = np.concatenate([o[1] for o in outs], axis=1)
         failed = sum(o[3] for o in outs)
         if (status == 0).all():
             pos, st = pos[:, picks], st[:, picks]
         status = status[picks]
     else:
-        pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8, transform=transform)
+        pos_o, st_o, _, failed = O.run(so, logp.kind, logp.dim, logp.params, cfg, n, x0, draws, n_threads=8, transform=transform, **est)
     if not (status == 0).all():
         return "init-failed" if failed else "MISMATCH: engine refused an initial point the oracle accepts"
     if failed:
