@@ -228,6 +228,12 @@ typedef struct nm_logp_spec {
  * `init(params, dim)` and `double eval(const double (&x)[2], double (&grad)[2], int dim) const`, where this lane holds
  * elements 2 L::lane(), 2 L::lane() + 1 and L::sum / L::bcast combine the chain's lanes, and is built with
  * -DNM_MODULE_GROUP_DENSITY=MyDensityGroup -DNM_MODULE_GS=<8|16|32 for dim <= 16|32|64> (tests/user_density/ has one).
+ * Lane form (optional, dim <= 16): one chain per lane (nm_engine_config.lane_chains): `template <int NP> struct MyDensityLane` with
+ * `init(params, dim)` and `double eval(const double (&x)[2 NP], double (&gx)[2 NP], int dim) const`, -DNM_MODULE_LANE_DENSITY=MyDensityLane.
+ * Other samplers (dim <= 4096): -DNM_MODULE_VARIANTS=<bits> compiles the SAME functor into the kernels that carry the low-rank
+ * transformation (bit 0: adaptation = NM_ADAPT_LOW_RANK, `LowRankNutsSettings`) and into those with the non-Euclidean trajectory kinds
+ * and MCLMC (bit 1); build_density_module(..., variants=("low_rank", "kinetic")).  Without them the engine answers
+ * NM_ERR_UNSUPPORTED for those settings with this module.
  * ------------------------------------------------------------------------------------------- */
 /* The tiling the engine uses for `dim` (requested_* = 0: automatic): doubles per lane and waves per chain. */
 nm_status nm_pick_tiling(uint64_t dim, uint64_t requested_dims_per_lane, uint64_t requested_waves_per_chain,
@@ -420,7 +426,8 @@ int nm_lowrank_compute_update(void* unused, uint64_t dim, uint64_t n_draws, cons
  * (`spd_mean`, `estimate_mass_matrix`: src/transform/adapt/low_rank.rs:228-290, tests :354-407), so that its vectors run
  * against THIS implementation and not only against the oracle's LAPACK restatement.  Matrices are column-major.
  * spd_mean: n x n inputs -> out n x n.  estimate_mass_matrix: draws / grads are (rows x n_draws) -> vals[rows] ascending,
- * vecs rows x rows (one eigenvector per column).  force_base != 0: the baseline-ISA build even where AVX2 is available.
+ * vecs rows x rows (one eigenvector per column).  force_base: 0 the widest ISA build, 1 the baseline-ISA build even where AVX2 is
+ * available, 2 the block form's twin (= the device kernel's arithmetic, see nm_lowrank_block_twin).
  * Return 0 (Some) or 1 (None). */
 int nm_lowrank_test_spd_mean(uint64_t n, const double* cov_draws, const double* cov_grads, double* out, uint64_t force_base);
 int nm_lowrank_test_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const double* draws, const double* grads, double gamma,

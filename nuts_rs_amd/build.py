@@ -109,9 +109,12 @@ def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):
     raise ValueError(f"no tiling for dim {dim}")
 
 
-def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None, lane_struct=None):
+def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_per_chain=0, extra_flags=(), group_struct=None, lane_struct=None,
+                         variants=()):
     """Compile a user density (a functor `struct_name` defined in `header`, see include/nuts_amd.h "User densities")
-    with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s)."""
+    with the engine's kernels into the module `out` for the tiling of `dim`.  Cross-compiles without a GPU (~20 s).
+    variants: "low_rank" adds the kernels LowRankNutsSettings needs, "kinetic" those of the non-Euclidean trajectory kinds / MCLMC
+    (each about doubles the build time)."""
     if dim > 4096:            # several blocks per chain: the cluster-mode kernels on the (16, 4) tiling; the density brings init_slice
         dpl, w = 16, 4
         extra_flags = list(extra_flags) + ["-DNM_CLUSTER_MODE=1"]
@@ -127,6 +130,11 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 16:
             raise ValueError("lane forms exist for dim <= 16")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
+    vbits = (1 if "low_rank" in variants else 0) | (2 if "kinetic" in variants else 0)
+    if vbits:
+        if dim > 4096:
+            raise ValueError("the low-rank / kinetic variants exist for dim <= 4096")
+        extra_flags = list(extra_flags) + [f"-DNM_MODULE_VARIANTS={vbits}"]
     cmd = [hipcc] + FLAGS + list(extra_flags) + [
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
         f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),

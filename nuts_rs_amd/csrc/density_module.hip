@@ -53,14 +53,32 @@ static hipError_t module_lane_t(int query, bool tune, const KParams& P, const La
 #define NM_MODULE_HAS_LANE 0
 #endif
 
+#ifndef NM_MODULE_VARIANTS
+#define NM_MODULE_VARIANTS 0          // bit 0: the kernels with the low-rank transformation (LowRankNutsSettings), bit 1: the non-Euclidean
+#endif                                // trajectory kinds / MCLMC — the same functor inside LrWrap / KinWrap, as for the built-in densities
+
 extern "C" {
 // {sizeof(KParams), NM_ABI_VERSION, DPL, W, lanes per chain of the group form or 0, 1 if built for chains wider than one block,
-//  1 if the module carries a lane form}:
+//  1 if the module carries a lane form, NM_MODULE_VARIANTS}:
 // the engine refuses a module built against another layout
 void nm_module_info(uint64_t out[8]) {
     out[0] = sizeof(nm::KParams); out[1] = NM_ABI_VERSION; out[2] = NM_MODULE_DPL; out[3] = NM_MODULE_W; out[4] = NM_MODULE_GS_VALUE;
-    out[5] = NM_CLUSTER_MODE; out[6] = NM_MODULE_HAS_LANE;
+    out[5] = NM_CLUSTER_MODE; out[6] = NM_MODULE_HAS_LANE; out[7] = NM_MODULE_VARIANTS;
 }
+#if NM_MODULE_VARIANTS
+// variant 1: LrWrap<density>, 2: KinWrap<density> (kern_lr_*.hip / kern_kin_*.hip for the built-in ones)
+int nm_module_launch_variant(int variant, int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ) {
+    const nm::KParams& P = *static_cast<const nm::KParams*>(kparams);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#if NM_MODULE_VARIANTS & 1
+    if (variant == 1) return (int)nm::launch_t<NM_MODULE_DPL, NM_MODULE_W, nm::LrWrap<NM_MODULE_DENSITY>>((nm::KernelKind)kind, P, grid_blocks, s, occ);
+#endif
+#if NM_MODULE_VARIANTS & 2
+    if (variant == 2) return (int)nm::launch_t<NM_MODULE_DPL, NM_MODULE_W, nm::KinWrap<NM_MODULE_DENSITY>>((nm::KernelKind)kind, P, grid_blocks, s, occ);
+#endif
+    return (int)hipErrorInvalidValue;
+}
+#endif
 // kind: nm::KernelKind (init, draw, occupancy query; the group form's draw / warm-up / query)
 int nm_module_launch(int kind, const void* kparams, unsigned grid_blocks, void* stream, int* occ) {
     return (int)nm::launch_t<NM_MODULE_DPL, NM_MODULE_W, NM_MODULE_DENSITY>((nm::KernelKind)kind, *static_cast<const nm::KParams*>(kparams),
