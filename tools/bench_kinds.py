@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nuts_rs_amd as N  # noqa: E402
 
 
-def run(name, settings, logp, chains, tune, draws):
-    b = N.ChainBatch(settings, logp, chains)
+def run(name, settings, logp, chains, tune, draws, **eng):
+    b = N.ChainBatch(settings, logp, chains, **eng)
     b.set_position(b.init_positions_uniform())
     b.draw_device(tune)
     b.reset_counters()
@@ -33,7 +33,8 @@ def run(name, settings, logp, chains, tune, draws):
            "draws_per_s_per_chain": draws / (c["kernel_ms"] * 1e-3),
            "leapfrogs_per_draw": c["total_leapfrogs"] / (draws * chains), "divergence_rate": float(s["diverging"].mean()),
            "mean_step_size": float(s["step_size"][-1].mean()),
-           "first_coordinate_mean": float(pos[:, :, 0].mean()), "first_coordinate_var": float(pos[:, :, 0].var())}
+           "first_coordinate_mean": float(pos[:, :, 0].mean()), "first_coordinate_var": float(pos[:, :, 0].var()),
+           "group_launches": b.group_launches(), "lane_launches": b.lane_launches()}
     b.close()
     print(json.dumps(out), flush=True)
 
@@ -41,8 +42,16 @@ def run(name, settings, logp, chains, tune, draws):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--draws", type=int, default=100)
+    ap.add_argument("--k4", action="store_true", help="only the K4-shaped cases: 8 schools dim 10 x 8192 chains, the kinds on the small-chain kernels and without them")
     a = ap.parse_args()
     K, M = N.KineticEnergyKind, N.MclmcTrajectoryKind
+    if a.k4:
+        base = dict(num_chains=8192, seed=20260928, num_tune=400)
+        for kname, kind in (("euclidean", K.EUCLIDEAN), ("exact_normal", K.EXACT_NORMAL), ("microcanonical", K.MICROCANONICAL)):
+            for lg, form in ((1, "one chain per wavefront"), (0, "automatic (8 chains per wavefront)")):
+                run(f"k4 8 schools nuts {kname}: {form}", N.DiagNutsSettings(trajectory_kind=kind, max_energy_error=50.0 if kind == K.MICROCANONICAL else 1000.0, **base),
+                    N.LogpSpec.eight_schools(), 8192, 400, a.draws, lane_groups=lg, lane_chains=1)
+        sys.exit(0)
     for dens, chains, mk in (("k2", 4096, lambda: N.LogpSpec.iid_normal(1024, 3.0)), ("k3", 8192, lambda: N.LogpSpec.funnel(101))):
         base = dict(num_chains=chains, seed=20260928, num_tune=400)
         run(dens + " nuts euclidean", N.DiagNutsSettings(**base), mk(), chains, 400, a.draws)
