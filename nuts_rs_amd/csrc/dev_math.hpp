@@ -447,7 +447,7 @@ static __host__ __device__ __noinline__ double dexpm1(double x) {
 // sin / cos of a step size (the ExactNormal trajectory kind; reference f64::sin / f64::cos, src/math/util.rs:580-581):
 // Cody-Waite reduction by pi/2 in two fma steps and the classic minimax kernels on [-pi/4, pi/4]; the same operation
 // sequence as oracle/nmo_math.hpp det_sincos (bit-identical), ~1 ulp from libm.
-static __host__ __device__ __noinline__ double2 dsincos(double x) {     // (sin x, cos x)
+static __host__ __device__ __forceinline__ double2 dsincos_impl(double x) {     // (sin x, cos x)
     if (!(x == x) || __builtin_isinf(x)) return make_double2(__builtin_nan(""), __builtin_nan(""));
     const double ax = __builtin_fabs(x);
     const double nf = __builtin_rint(ax * 6.36619772367581382433e-01);
@@ -474,6 +474,9 @@ static __host__ __device__ __noinline__ double2 dsincos(double x) {     // (sin 
     else { s_ = -cr; c_ = sr; }
     return make_double2(x < 0.0 ? -s_ : s_, c_);
 }
+// out of line for the one-chain kernels (every lane of the wavefront calls it together); kernels with several chains per wavefront call
+// dsincos_impl: no out-of-line call under a branch that is not uniform over the wavefront
+static __host__ __device__ __noinline__ double2 dsincos(double x) { return dsincos_impl(x); }
 
 NM_DEV bool is_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 NM_DEV double clampd(double v, double lo, double hi) {   // f64::clamp: NaN stays NaN
