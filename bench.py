@@ -23,6 +23,8 @@
             `frac` = `frac_moved` = achieved / 8 TB/s <= 1.  The 64 B/(step x dim) algorithmic model of SURVEY §8(d) is
             reported beside it (`frac_sec8d_model`, `algorithmic`): it is NOT a bound for this design, whose live state is
             register / LDS resident (the model's rate exceeds the HBM peak).
+  low_rank_adaptation: a whole `LowRankNutsSettings` warm-up (dim 128 x 1024 chains) with its estimator rounds on the device: wall time,
+      the kernels' shares, the host's share.
   other_configs: BASELINE.json's other GPU configurations — K3 (funnel dim 101 x 8192 chains), K4 (8 schools dim 10: the whole
             65536-chain job on one GPU, and one GPU's shard of 8192 chains) and K5 (full-Sigma normal dim 256 x 4096 chains through
             the shared rank-256 transformation, the matrix-core kernel) — each measured by this script in the same run (one untimed
@@ -457,6 +459,42 @@ def other_configs(args):
     return out
 
 
+def low_rank_adaptation(seed):
+    """`LowRankNutsSettings` adapting per chain: the whole warm-up of 1024 chains at dim 128 — draw
+    kernels + the estimator rounds (`compute_update`, src/transform/adapt/low_rank.rs:73-142, on the device: csrc/lowrank_device.hip) — timed
+    as a caller sees it, with the share of it that is host time.  tools/bench_lowrank_adapt.py is the stand-alone form (its profile:
+    profiles/r04r_*)."""
+    import ctypes as C
+    import nuts_rs_amd as N
+    dim, chains, tune = 128, 1024, 300
+    rng = np.random.default_rng(3)
+    u = np.linalg.qr(rng.normal(size=(dim, 4)))[0]
+    sigma = np.eye(dim) + u @ np.diag([100.0, 50.0, 20.0, 10.0]) @ u.T
+    sc = np.exp(rng.normal(0, 0.5, dim))
+    sigma = np.diag(sc) @ sigma @ np.diag(sc)
+    prec = np.linalg.inv(sigma)
+    s = N.LowRankNutsSettings(num_chains=chains, seed=seed, num_tune=tune, num_draws=100)
+    b = N.ChainBatch(s, N.LogpSpec.mvn_precision((prec + prec.T) / 2), chains)
+    try:
+        b.init_with_retries()
+        t = time.time()
+        _, st = b.draw_many(tune, positions=False)
+        wall = time.time() - t
+        c = b.counters()
+        tm = (C.c_double * 6)()
+        N.load_library().nm_debug_lowrank_timing(b._h, tm)
+        on_dev = b.lowrank_device_updates()
+        est_s = tm[2] if on_dev else 0.0
+        return {"workload": f"LowRankNutsSettings adapting, full-precision normal dim {dim} x {chains} chains, num_tune {tune}",
+                "warmup_wall_s": wall, "draw_kernels_s": c["kernel_ms"] * 1e-3, "estimator_rounds": int(tm[4]), "estimator_calls": int(tm[5]),
+                "estimator_calls_on_device": on_dev, "estimator_kernel_s": est_s,
+                "host_share": (wall - c["kernel_ms"] * 1e-3 - est_s) / wall,
+                "updates_per_chain": float((st["transformation_update_id"] >= 0).sum() / chains),
+                "n_eig_median": float(np.median(b.lowrank()[0])), "divergences_in_warmup": int(st["diverging"].sum())}
+    finally:
+        b.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
@@ -739,6 +777,10 @@ def main():
             del d_pos, d_st
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args)
+            try:
+                out["low_rank_adaptation"] = low_rank_adaptation(args.seed)
+            except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
+                out["low_rank_adaptation"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             cores, cores_note = usable_cores()
             try:
