@@ -426,8 +426,9 @@ NM_DEV double logaddexp(double a, double b) {
 
 // exp(x) - 1 for the isokinetic momentum refresh (reference f64::exp_m1, transformed_hamiltonian.rs:800-801): the same
 // operation sequence as oracle/nmo_math.hpp det_expm1 (Taylor series to x^14 for |x| <= 0.35, else exp(x) - 1)
-static __host__ __device__ __noinline__ double dexpm1(double x) {
-    if (!(__builtin_fabs(x) <= 0.35)) return dexp(x) - 1.0;
+template <bool INL>
+static __host__ __device__ __forceinline__ double dexpm1_impl(double x) {
+    if (!(__builtin_fabs(x) <= 0.35)) return (INL ? dexp_impl<false>(x) : dexp(x)) - 1.0;
     double p = 1.1470745597729725e-11;                                 // 1/14!
     p = __builtin_fma(x, p, 1.6059043836821613e-10);    // 1/13!
     p = __builtin_fma(x, p, 2.08767569878681e-09);    // 1/12!
@@ -443,6 +444,9 @@ static __host__ __device__ __noinline__ double dexpm1(double x) {
     p = __builtin_fma(x, p, 0.5);
     return __builtin_fma(x * x, p, x);
 }
+// (out of line for the one-chain kernels; kernels with several chains per wavefront use dexpm1_impl<true>: nothing out of line under a
+// branch that is not uniform over the wavefront)
+static __host__ __device__ __noinline__ double dexpm1(double x) { return dexpm1_impl<false>(x); }
 
 // sin / cos of a step size (the ExactNormal trajectory kind; reference f64::sin / f64::cos, src/math/util.rs:580-581):
 // Cody-Waite reduction by pi/2 in two fma steps and the classic minimax kernels on [-pi/4, pi/4]; the same operation

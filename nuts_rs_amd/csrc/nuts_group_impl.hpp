@@ -420,11 +420,10 @@ NM_DEV double g_esh_update(const double (&g)[2], double (&p)[2], double step_siz
 }
 // leapfrog_kin (nuts_kernels.hpp; KineticEnergyKind::ExactNormal and ::Microcanonical, src/math/util.rs:186-258, :507-741)
 template <class GD>
-NM_DEV void g_leapfrog_kin(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon) {
+NM_DEV void g_leapfrog_kin(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon, double (&x)[2], double (&gx)[2]) {
     const bool micro = C.sc.kin == NM_TRAJ_MICROCANONICAL;
     const double half = epsilon / 2.;
     const double sqrt_n = __builtin_sqrt((double)C.dim);
-    double x[2], gx[2];
     if (micro) {
         o.v[0] = s.v[0]; o.v[1] = s.v[1];
         o.ke = s.ke + g_esh_update(s.g, o.v, sqrt_n * epsilon / 2., C.dim);
@@ -487,7 +486,7 @@ NM_DEV double g_initial_kinetic(GCtx<GD>& C, double (&v)[2]) {
 template <class GD>
 NM_DEV void g_leapfrog(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon) {
     if constexpr (gkin_trait<GD>::value) {
-        if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { g_leapfrog_kin(C, s, o, epsilon); return; }
+        if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { double x_[2], gx_[2]; g_leapfrog_kin(C, s, o, epsilon, x_, gx_); return; }
     }
     const double half = epsilon / 2.;
     double x[2], gx[2];
@@ -1085,11 +1084,232 @@ NM_DEV void g_emit_divergence_vectors(GCtx<GD>& C, int64_t start_idx, size_t row
     g_write_row(C, P.out_div_end, row, x);
 }
 
+// ---- MclmcChain::draw (reference src/mclmc.rs:219-400; chain_draw_mclmc of nuts_kernels.hpp) for the chains of a group: every chain of a
+// wavefront takes the same number of base steps (the step size is fixed), so the lockstep is free.  KinWrap instantiations only. ----
+template <class GD>
+NM_DEV void g_leapfrog_xg(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon, double (&x)[2], double (&gx)[2]) {
+    if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { g_leapfrog_kin(C, s, o, epsilon, x, gx); return; }
+    const double half = epsilon / 2.;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double vh = __builtin_fma(half, s.g[k], s.v[k]);
+        o.v[k] = vh;
+        o.z[k] = __builtin_fma(epsilon, vh, s.z[k]);
+        const double t = o.z[k] * C.sig[k];
+        x[k] = __builtin_fma(1.0, C.mu[k], t);
+    }
+    o.logp = C.dens.eval(x, gx, C.dim);
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        o.g[k] = gx[k] * C.sig[k];
+        o.v[k] = __builtin_fma(half, o.g[k], o.v[k]);
+        acc = __builtin_fma(o.v[k], o.v[k], acc);
+    }
+    o.ke = 0.5 * gsum(acc);
+}
+template <class GD>
+NM_DEV void g_sample_velocity(GCtx<GD>& C, double (&v)[2]) {
+    g_fill_normals(C.rng, C.samp, C.dim, C.zig);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v[k] = 2 * gl() + k < C.dim ? 1.0 * C.samp[2 * gl() + k] : 0.0;
+}
+NM_DEV double g_kinetic(const double (&v)[2]) {
+    double kacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) kacc = __builtin_fma(v[k], v[k], kacc);
+    return 0.5 * gsum(kacc);
+}
+// partial_momentum_refresh (transformed_hamiltonian.rs:770-825) with the noise the last g_fill_normals left in C.samp
+template <class GD>
+NM_DEV void g_partial_refresh(GCtx<GD>& C, GPt& p, double factor) {
+    const double half_step = C.sc.step_size * factor / 2.0;
+    const double L = C.P.s.momentum_decoherence_length;
+    double nz[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) nz[k] = 2 * gl() + k < C.dim ? 1.0 * C.samp[2 * gl() + k] : 0.0;
+    if (C.sc.kin == NM_TRAJ_MICROCANONICAL) {       // isokinetic Langevin on the unit sphere
+        const double nu = __builtin_sqrt(dexpm1_impl<true>(2.0 * half_step / L) / (double)C.dim);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) p.v[k] = __builtin_fma(nu, nz[k], p.v[k]);
+        g_normalize(p.v);
+    } else {                                        // Ornstein-Uhlenbeck: alpha p + sqrt(1 - alpha^2) z
+        const double alpha = dexp(-half_step / L);
+        const double beta = __builtin_sqrt(1.0 - alpha * alpha);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double nv = __builtin_fma(alpha, p.v[k], 0.0);
+            p.v[k] = __builtin_fma(beta, nz[k], nv);
+        }
+        p.ke = g_kinetic(p.v);
+    }
+}
+template <bool TUNE, class GD>
+NM_DEV void g_chain_draw_mclmc(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
+    const KParams& P = C.P;
+    const nm_settings& s = P.s;
+    ChainScalars& sc = C.sc;
+    nm_draw_stats out = {};
+    out.draw = sc.draw_count; out.chain = P.chain_id_offset + chain;
+    bool resample_velocity = false;                 // Euclidean -> Microcanonical switch (mclmc.rs:490-504)
+    if (s.mclmc_trajectory_kind == NM_MCLMC_EUCLIDEAN_EARLY_THEN_MICROCANONICAL && sc.draw_count == P.mclmc_switch_draw &&
+        sc.kin != NM_TRAJ_MICROCANONICAL) {
+        sc.kin = NM_TRAJ_MICROCANONICAL;
+        resample_velocity = true;
+    }
+    const double base_step_size = sc.step_size;
+    uint64_t num_base_steps;
+    {
+        const double q = s.subsample_frequency * s.momentum_decoherence_length / base_step_size;
+        double r = __builtin_round(q);
+        r = r != r ? 1.0 : (r > 1.0 ? r : 1.0);
+        r = r < 1e6 ? r : 1e6;
+        num_base_steps = (uint64_t)r;
+    }
+    const int max_halvings = s.dynamic_step_size ? 10 : 0;
+    GPt cur, nxt;
+    double x[2], gx[2];
+    C.ld(x, C.Pp(P_X)); C.ld(gx, C.Pp(P_GX));
+    if (resample_velocity) g_sample_velocity(C, cur.v); else C.ld(cur.v, C.Pp(P_V));
+    if (sc.mm_id != sc.transform_id) {              // inv_transform_normalize (diagonal.rs:210-221)
+        double isig[2];
+        C.ld(isig, C.Pp(P_ISIG));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double t = __builtin_fma(-1.0, C.mu[k], x[k]);
+            cur.z[k] = isig[k] * t;
+            cur.g[k] = gx[k] * C.sig[k];
+        }
+        C.st(cur.z, C.Pp(P_Z)); C.st(cur.g, C.Pp(P_GZ));
+        sc.logdet = sc.mm_logdet;
+        sc.transform_id = sc.mm_id;
+    } else {
+        C.ld(cur.z, C.Pp(P_Z)); C.ld(cur.g, C.Pp(P_GZ));
+    }
+    const double logdet = sc.logdet;
+    cur.ke = resample_velocity ? g_initial_kinetic(C, cur.v) : (sc.kin == NM_TRAJ_MICROCANONICAL ? 0.0 : g_kinetic(cur.v));
+    cur.logp = sc.logp; cur.idx = 0;
+    const double initial_energy = cur.ke - (cur.logp + logdet);
+    g_fill_normals(C.rng, C.samp, C.dim, C.zig);    // sample_noise
+    const double draw_start_energy = initial_energy;
+    GAccept col;
+    col.register_init(0.0);
+    bool diverged = false, div_has_energy = false, div_has_end = false;
+    double div_energy_error = 0.0;
+    uint64_t steps_taken = 0, remaining = num_base_steps, stack0 = 0;
+    uint32_t stack_bits = 0;
+    int stack_len = 0;
+    double factor = 1.0, time = 0.0;
+    double xn[2] = {0.0, 0.0}, gxn[2] = {0.0, 0.0};
+    const int tmp_slot = slot_F(0);                 // tmp_velocity (mclmc.rs:272-274)
+    while (remaining > 0) {
+        C.st(cur.v, C.Ss(tmp_slot));
+        g_partial_refresh(C, cur, factor);
+        const double step_baseline = cur.ke - (cur.logp + logdet);
+        g_leapfrog_xg(C, cur, nxt, base_step_size * factor, xn, gxn);
+        nxt.idx = cur.idx + 1;
+        const double energy = nxt.ke - (nxt.logp + logdet);
+        const double err = energy - step_baseline;
+        bool div_now = false;
+        if (g_bad_energy(C, err, s.max_energy_error * factor / (double)num_base_steps)) {
+            col.register_divergent(); div_now = true; div_has_energy = true; div_has_end = true; div_energy_error = err;
+        } else col.register_ok(energy);
+        if (!div_now) {
+            g_fill_normals(C.rng, C.samp, C.dim, C.zig);
+            g_partial_refresh(C, nxt, factor);
+            g_fill_normals(C.rng, C.samp, C.dim, C.zig);
+            cur = nxt; x[0] = xn[0]; x[1] = xn[1]; gx[0] = gxn[0]; gx[1] = gxn[1];
+            steps_taken += 1;
+            remaining -= 1;
+            time += factor * base_step_size;
+            while (remaining == 0) {
+                if (stack_len == 0) break;
+                stack_len -= 1;
+                remaining = (stack_len == 0 ? stack0 : (((stack_bits >> stack_len) & 1u) ? 2ull : 1ull)) - 1;
+                factor *= 2.0;
+            }
+        } else {
+            if (stack_len >= max_halvings) { diverged = true; break; }
+            factor *= 0.5;
+            if (stack_len == 0) stack0 = remaining;
+            else stack_bits = (stack_bits & ~(1u << stack_len)) | ((remaining == 2 ? 1u : 0u) << stack_len);
+            stack_len += 1;
+            remaining = 2;
+            C.ld(cur.v, C.Ss(tmp_slot));
+        }
+    }
+    const size_t row = (size_t)(t_out * P.n_chains + chain) * P.dim;
+    const bool is_good = diverged ? (cur.idx > 4) : (cur.idx != 0);
+    const double cur_energy = cur.ke - (cur.logp + logdet);
+    double energy_change, state_energy, state_energy_error, state_logp;
+    int64_t state_idx;
+    double sx[2], sgx[2], sz[2], sgz[2];
+    if (diverged) {                                 // stay at the pre-trajectory position with a fresh momentum (mclmc.rs:361-388)
+        g_write_row(C, P.out_div_start, row, x);
+        g_write_row(C, P.out_div_start_grad, row, gx);
+        if (div_has_end) g_write_row(C, P.out_div_end, row, xn);
+        double v[2];
+        g_sample_velocity(C, v);
+        const double ke_new = g_initial_kinetic(C, v);
+        C.st(v, C.Pp(P_V));
+        C.ld(sx, C.Pp(P_X)); C.ld(sgx, C.Pp(P_GX)); C.ld(sz, C.Pp(P_Z)); C.ld(sgz, C.Pp(P_GZ));
+        energy_change = cur_energy - draw_start_energy;
+        state_logp = sc.logp;
+        state_energy = ke_new - (state_logp + logdet);
+        state_energy_error = state_energy - state_energy;
+        state_idx = 0;
+    } else {
+        C.st(x, C.Pp(P_X)); C.st(gx, C.Pp(P_GX)); C.st(cur.z, C.Pp(P_Z)); C.st(cur.g, C.Pp(P_GZ)); C.st(cur.v, C.Pp(P_V));
+        sc.logp = cur.logp;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { sx[k] = x[k]; sgx[k] = gx[k]; sz[k] = cur.z[k]; sgz[k] = cur.g[k]; }
+        energy_change = cur_energy - initial_energy;
+        state_logp = cur.logp; state_energy = cur_energy; state_energy_error = energy_change; state_idx = cur.idx;
+    }
+    sc.px_stale = 0;
+    g_write_row(C, P.out_positions, row, sx);
+    g_write_row(C, P.out_gradient, row, sgx);
+    g_write_row(C, P.out_tpos, row, sz);
+    g_write_row(C, P.out_tgrad, row, sgz);
+    double fd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) fd = fd + (sz[k] + sgz[k]) * (sz[k] + sgz[k]);
+    fd = gsum(fd);
+    const int64_t trans_id = sc.transform_id;
+    sc.total_steps += col.count;
+    const uint64_t ast = g_adapt<TUNE>(C, col, is_good, x, gx);
+    if (ast != NM_CHAIN_OK) sc.status = ast;
+    out.depth = steps_taken; out.maxdepth_reached = 0; out.diverging = diverged;
+    out.tuning = sc.tuning; out.n_steps = sc.last_n_steps;
+    out.index_in_trajectory = state_idx; out.transformation_index = trans_id;
+    out.step_size = sc.step_size; out.step_size_bar = s.fixed_step_size;
+    out.mean_tree_accept = sc.last_mean_tree_accept; out.mean_tree_accept_sym = sc.last_sym_mean_tree_accept;
+    out.max_energy_error = sc.last_max_energy_error;
+    out.logp = state_logp; out.energy = state_energy; out.energy_error = state_energy_error;
+    out.fisher_distance = fd;
+    out.divergence_energy_error = (diverged && div_has_energy) ? div_energy_error : __builtin_nan("");
+    out.chain_status = ast;
+    out.transformation_update_id = -1;
+    out.num_eigenvalues = 0;
+    out.energy_change = energy_change; out.average_step_size = time / (double)steps_taken;
+    if (sc.mm_id != sc.stats_last_id) {
+        out.transformation_update_id = sc.mm_id;
+        g_write_row(C, P.out_mm_inv, row, C.sig);
+        g_write_row(C, P.out_mm_mu, row, C.mu);
+    }
+    sc.stats_last_id = sc.mm_id;
+    if (P.out_stats && gl() == 0) P.out_stats[t_out * P.n_chains + chain] = out;
+    sc.draw_count += 1;
+}
+
 // NutsChain::draw (reference src/chain.rs:151-188) + the scalar statistics of expanded_draw (:190-232)
 template <bool TUNE, class GD>
 NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
     const KParams& P = C.P;
     ChainScalars& sc = C.sc;
+    if constexpr (gkin_trait<GD>::value) {
+        if (P.s.sampler == NM_SAMPLER_MCLMC) { g_chain_draw_mclmc<TUNE>(C, chain, t_out); return; }
+    }
     GAccept col;
     DrawResult R;
     double x[2], gx[2], z[2], gz[2];

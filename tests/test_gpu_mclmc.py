@@ -47,16 +47,25 @@ def _density(dens, dim, rng):
     return N.LogpSpec.diag_normal(np.exp(rng.uniform(-3, 3, dim)))
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_mclmc_parity_bit_exact(oracle, case):
+def _runs():
+    out = []
+    for c in CASES:
+        out.append(pytest.param(c, 1, id=c[0] + "-wave"))
+        if c[2] <= 64 and c[6] == 0:                 # the small-chain kernels: 8 / 4 / 2 chains per wavefront (nuts_group.hpp), since round 4
+            out.append(pytest.param(c, 2, id=c[0] + "-group"))
+    return out
+
+
+@pytest.mark.parametrize("case,lane_groups", _runs())
+def test_mclmc_parity_bit_exact(oracle, case, lane_groups):
     name, kw, dim, n_chains, n_draws, dens, tiling = case
     s = N.DiagMclmcSettings(num_chains=n_chains, **kw)
     logp = _density(dens, dim, np.random.default_rng(kw["seed"]))
     x0 = oracle.init_positions_uniform(s.seed, 0, n_chains, dim)
     dpl, wpc = tiling if isinstance(tiling, tuple) else (tiling, 0)
-    pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl, waves_per_chain=wpc, lane_groups=2,
+    pos_g, st_g, ex = run_engine(s, logp, n_chains, x0, n_draws, dims_per_lane=dpl, waves_per_chain=wpc, lane_groups=lane_groups,
                                  splits=(n_draws // 3,))                 # the momentum survives the end of a launch too
-    assert ex["group_launches"] == 0
+    assert (ex["group_launches"] >= 1) == (lane_groups == 2)
     pos_o, st_o, steps, failed = run_oracle(oracle, s, logp, n_chains, x0, n_draws, gpu_threads=ex["threads_per_chain"])
     assert failed == 0 and (ex["status"] == 0).all()
     assert_bit_exact(pos_g, st_g, pos_o, st_o)

@@ -51,6 +51,9 @@ if __name__ == "__main__":
             for lg, form in ((1, "one chain per wavefront"), (0, "automatic (8 chains per wavefront)")):
                 run(f"k4 8 schools nuts {kname}: {form}", N.DiagNutsSettings(trajectory_kind=kind, max_energy_error=50.0 if kind == K.MICROCANONICAL else 1000.0, **base),
                     N.LogpSpec.eight_schools(), 8192, 400, a.draws, lane_groups=lg, lane_chains=1)
+        for lg, form in ((1, "one chain per wavefront"), (0, "automatic (8 chains per wavefront)")):
+            run(f"k4 8 schools mclmc: {form}", N.DiagMclmcSettings(step_size=0.4, max_energy_error=30.0, **base), N.LogpSpec.eight_schools(), 8192, 400, a.draws,
+                lane_groups=lg, lane_chains=1)
         sys.exit(0)
     for dens, chains, mk in (("k2", 4096, lambda: N.LogpSpec.iid_normal(1024, 3.0)), ("k3", 8192, lambda: N.LogpSpec.funnel(101))):
         base = dict(num_chains=chains, seed=20260928, num_tune=400)
