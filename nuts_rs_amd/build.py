@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libnuts_amd.so")
 UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lockstep.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
          "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_host_cb.hip",
          "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
-         "kern_lane.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
+         "kern_lane.hip", "kern_lane_kin.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
          "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip", "pooled_reduce.hip", "lowrank_device.hip",
          "lowrank_host.cpp"]
 # (lowrank_host.cpp holds both ISA builds of the host estimator in ONE translation unit: per-function target attributes, see there)

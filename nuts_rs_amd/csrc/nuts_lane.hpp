@@ -203,6 +203,12 @@ struct LFunnel {
     }
 };
 template <class Dens, int NP> struct LaneDensity { using type = void; };
+// KinWrap<D> (nuts_kernels.hpp): the density's own lane form; the non-Euclidean trajectory kinds are switched on in the lane code by the marker
+// LKin around it (round 4; kern_lane_kin.hip) — the Euclidean instantiations compile the code they always had
+template <class D, int NP> struct LaneDensity<KinWrap<D>, NP> { using type = typename LaneDensity<D, NP>::type; };
+template <class LD> struct LKin : LD {};
+template <class LD> struct lkin_trait { static constexpr bool value = false; };
+template <class LD> struct lkin_trait<LKin<LD>> { static constexpr bool value = true; };
 template <int NP> struct LaneDensity<IidNormal, NP> { using type = LIidNormal<NP>; };
 template <int NP> struct LaneDensity<DiagNormal, NP> { using type = LDiagNormal<NP>; };
 template <int NP> struct LaneDensity<Funnel, NP> { using type = LFunnel<NP>; };
@@ -402,8 +408,126 @@ struct LCtx {
     NM_DEV void ld_edge(LPt<NP>& p, int id) const { ldS(p.z, EDGE0_Z + 3 * id); ldS(p.v, EDGE0_V + 3 * id); ldS(p.g, EDGE0_G + 3 * id); }
 };
 
+// ---- the non-Euclidean KineticEnergyKinds in one lane (LKin instantiations only): normalize_tile / esh_update_core / leapfrog_kin of
+// nuts_kernels.hpp with the chain's sums formed as the engine forms them — per pair of elements, then the balanced tree over the pairs ----
+template <int NP>
+NM_DEV double l_sum_sq(const double (&v)[2 * NP]) {
+    double p[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc = acc + v[2 * l + k] * v[2 * l + k];
+        p[l] = acc;
+    }
+    return pair_tree<NP>(p);
+}
+template <int NP>
+NM_DEV void l_normalize(double (&v)[2 * NP]) {
+    const double inv = 1.0 / __builtin_sqrt(l_sum_sq<NP>(v));
+#pragma unroll
+    for (int d = 0; d < 2 * NP; ++d) v[d] *= inv;
+}
+template <int NP>
+NM_DEV double l_esh_update(const double (&g)[2 * NP], double (&pv)[2 * NP], double step_size, int dim) {
+    const double grad_norm = __builtin_sqrt(l_sum_sq<NP>(g));
+    const double inv_grad_norm = 1.0 / grad_norm;
+    double p[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc = acc + pv[2 * l + k] * g[2 * l + k] * inv_grad_norm;
+        p[l] = acc;
+    }
+    const double momentum_proj = pair_tree<NP>(p);
+    const double dims_m1 = (double)(dim - 1);
+    const double delta = step_size * grad_norm / dims_m1;
+    const double zeta = lexp(-delta);
+    const double coeff_g = (1.0 - zeta) * (1.0 + zeta + momentum_proj * (1.0 - zeta));
+    const double coeff_p = 2.0 * zeta;
+#pragma unroll
+    for (int d = 0; d < 2 * NP; ++d) pv[d] = coeff_g * (g[d] * inv_grad_norm) + coeff_p * pv[d];
+    l_normalize<NP>(pv);
+    const double arg = momentum_proj + (1.0 - momentum_proj) * zeta * zeta;
+    return (delta - 6.93147180559945286227e-01 + llog1p(arg)) * dims_m1;
+}
+template <int NP, class LD>
+NM_DEV void l_leapfrog_kin(LCtx<NP, LD>& C, const LPt<NP>& s, LPt<NP>& o, double epsilon) {
+    constexpr int E = 2 * NP;
+    const bool micro = C.sc.kin == NM_TRAJ_MICROCANONICAL;
+    const double half = epsilon / 2.;
+    const double sqrt_n = __builtin_sqrt((double)C.dim);
+    double x[E], gx[E];
+    if (micro) {
+#pragma unroll
+        for (int d = 0; d < E; ++d) o.v[d] = s.v[d];
+        o.ke = s.ke + l_esh_update<NP>(s.g, o.v, sqrt_n * epsilon / 2., C.dim);
+        const double eps_n = epsilon * sqrt_n;
+#pragma unroll
+        for (int d = 0; d < E; ++d) o.z[d] = __builtin_fma(eps_n, o.v[d], s.z[d]);
+    } else {
+        const double2 sc2 = dsincos_impl(epsilon);
+        const double es = sc2.x, ec = sc2.y, nes = -es;
+#pragma unroll
+        for (int d = 0; d < E; ++d) {
+            const double vh = __builtin_fma(half, s.z[d] + s.g[d], s.v[d]);
+            o.z[d] = __builtin_fma(s.z[d], ec, vh * es);
+            o.v[d] = __builtin_fma(s.z[d], nes, vh * ec);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < E; ++d) {
+        const double t = o.z[d] * C.sig[d];
+        x[d] = __builtin_fma(1.0, C.mu[d], t);
+    }
+    o.logp = C.dens.eval(x, gx, C.dim);
+#pragma unroll
+    for (int d = 0; d < E; ++d) o.g[d] = gx[d] * C.sig[d];
+    if (micro) {
+        o.ke = o.ke + l_esh_update<NP>(o.g, o.v, sqrt_n * epsilon / 2., C.dim);
+    } else {
+        double p[NP];
+#pragma unroll
+        for (int l = 0; l < NP; ++l) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = 2 * l + k;
+                o.v[d] = __builtin_fma(half, o.z[d] + o.g[d], o.v[d]);
+                acc = __builtin_fma(o.v[d], o.v[d], acc);
+            }
+            p[l] = acc;
+        }
+        o.ke = 0.5 * pair_tree<NP>(p);
+    }
+}
+// leapfrog's divergence criterion (transformed_hamiltonian.rs:583-590)
+template <int NP, class LD>
+NM_DEV bool l_bad_energy(const LCtx<NP, LD>& C, double energy_error, double max_energy_error) {
+    if constexpr (lkin_trait<LD>::value) {
+        if (C.sc.kin == NM_TRAJ_MICROCANONICAL) return (__builtin_fabs(energy_error) >= max_energy_error) | !is_finite(energy_error);
+    }
+    return (energy_error > max_energy_error) | !is_finite(energy_error);
+}
+// 1/2 |v|^2 in the engine's order
+template <int NP>
+NM_DEV double l_kinetic(const double (&v)[2 * NP]) {
+    double p[NP];
+#pragma unroll
+    for (int l = 0; l < NP; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc = __builtin_fma(v[2 * l + k], v[2 * l + k], acc);
+        p[l] = acc;
+    }
+    return 0.5 * pair_tree<NP>(p);
+}
 template <int NP, class LD>
 NM_DEV void l_leapfrog(LCtx<NP, LD>& C, const LPt<NP>& s, LPt<NP>& o, double epsilon) {
+    if constexpr (lkin_trait<LD>::value) {
+        if (C.sc.kin != NM_TRAJ_EUCLIDEAN) { l_leapfrog_kin(C, s, o, epsilon); return; }
+    }
     constexpr int E = 2 * NP;
     const double half = epsilon / 2.;
     double x[E], gx[E];
@@ -594,10 +718,14 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
     // staging slot; its rows beyond dim are zero since the allocation) instead of 2 NP inlined ones
     // (staged in LDS: a store to the scratch in HBM followed by the next sample's table look-up serialises on the one memory counter)
     C.draw_normals(Ep.v);
+    bool micro_ = false;
+    if constexpr (lkin_trait<LD>::value) micro_ = sc.kin == NM_TRAJ_MICROCANONICAL;
+    if (micro_) l_normalize<NP>(Ep.v);       // initialize_trajectory (transformed_hamiltonian.rs:697-727): the momentum on the unit sphere
     C.stS(Ep.z, EDGE0_Z); C.stS(Ep.v, EDGE0_V); C.stS(Ep.g, EDGE0_G);
     const double logdet = sc.logdet;
     double ke_init;
-    {
+    if (micro_) ke_init = 0.0;
+    else {
         double p[NP];
 #pragma unroll
         for (int l = 0; l < NP; ++l) {
@@ -608,6 +736,8 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
         }
         ke_init = 0.5 * pair_tree<NP>(p);
     }
+    Ep.ke = ke_init;
+    [[maybe_unused]] double left_ke = ke_init, right_ke = ke_init;   // the edges' kinetic_energy: an input of the microcanonical leapfrog only
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
@@ -665,7 +795,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
         {                                                                                                 \
             const double energy_ = (PT).ke - ((PT).logp + logdet);                                        \
             const double err_ = energy_ - e0;                                                             \
-            if ((err_ > s.max_energy_error) | !is_finite(err_)) {                                         \
+            if (l_bad_energy(C, err_, s.max_energy_error)) {                                              \
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
                 R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
@@ -686,7 +816,10 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
             sub_cand = {-2, Op.logp, Op.ke, Op.idx};
             NM_LP(C, 3);
         } else {
-            if (!reuse_edge) C.ld_edge(Op, fwd ? right_slot : left_slot);
+            if (!reuse_edge) {
+                C.ld_edge(Op, fwd ? right_slot : left_slot);
+                if constexpr (lkin_trait<LD>::value) Op.ke = fwd ? right_ke : left_ke;
+            }
             NM_LP(C, 1);
             for (uint64_t n = 0; n < nleaf; n += 2) {
                 double wE = 0., wO = 0.;
@@ -796,6 +929,7 @@ NM_DEV uint64_t l_transition(LCtx<NP, LD>& C, LAccept& col, DrawResult& R, doubl
             o_is_edge = true; o_edge_sign = sign;
         }
         if (fwd) right_idx = Op.idx; else left_idx = Op.idx;
+        if constexpr (lkin_trait<LD>::value) { if (fwd) right_ke = Op.ke; else left_ke = Op.ke; }
         depth += 1;
         log_size = total;
         if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
@@ -962,17 +1096,13 @@ NM_DEV uint64_t l_stepsize_init(LCtx<NP, LD>& C, const double (&x)[2 * NP]) {
     double ke0;
     {
         C.draw_normals(st.v);
+        bool micro_ = false;
+        if constexpr (lkin_trait<LD>::value) micro_ = C.sc.kin == NM_TRAJ_MICROCANONICAL;
+        if (micro_) l_normalize<NP>(st.v);
         C.stS(st.v, STAGE_V);
-        double p[NP];
-#pragma unroll
-        for (int l = 0; l < NP; ++l) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) acc = __builtin_fma(st.v[2 * l + k], st.v[2 * l + k], acc);
-            p[l] = acc;
-        }
-        ke0 = 0.5 * pair_tree<NP>(p);
+        ke0 = micro_ ? 0.0 : l_kinetic<NP>(st.v);
     }
+    st.ke = ke0;
     const double e0 = ke0 - (st.logp + logdet);
     LAccept col;
     C.sc.step_size = s.initial_step;
@@ -984,7 +1114,7 @@ NM_DEV uint64_t l_stepsize_init(LCtx<NP, LD>& C, const double (&x)[2 * NP]) {
         l_leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0);
         const double energy = o.ke - (o.logp + logdet);
         const double err = energy - e0;
-        if ((err > 1000.0) | !is_finite(err)) {
+        if (l_bad_energy(C, err, 1000.0)) {
             if (it > 0) C.sc.step_size = s.initial_step;
             return NM_CHAIN_OK;
         }
@@ -1600,7 +1730,8 @@ struct LaneShared {
 // start inside the warm-up).
 template <class Dens, int NP, bool TUNE>
 __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, const LaneParams LP) {
-    using LD = typename LaneDensity<Dens, NP>::type;
+    using LD0 = typename LaneDensity<Dens, NP>::type;
+    using LD = typename std::conditional<kin_trait<Dens>::value, LKin<LD0>, LD0>::type;
     constexpr int E = 2 * NP;
     __shared__ LaneShared<NP> sh;
     for (int i = (int)threadIdx.x; i < 257; i += 64) {

@@ -42,17 +42,22 @@ def run(name, settings, logp, chains, tune, draws, **eng):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--draws", type=int, default=100)
+    ap.add_argument("--chains", type=int, default=8192, help="--k4: chains (65536: the whole K4 job on one GPU, one chain per lane where that applies)")
     ap.add_argument("--k4", action="store_true", help="only the K4-shaped cases: 8 schools dim 10 x 8192 chains, the kinds on the small-chain kernels and without them")
     a = ap.parse_args()
     K, M = N.KineticEnergyKind, N.MclmcTrajectoryKind
     if a.k4:
-        base = dict(num_chains=8192, seed=20260928, num_tune=400)
+        nch = a.chains
+        base = dict(num_chains=nch, seed=20260928, num_tune=400)
+        auto = "automatic (8 chains per wavefront)" if nch < 24576 else "automatic (one chain per lane)"
         for kname, kind in (("euclidean", K.EUCLIDEAN), ("exact_normal", K.EXACT_NORMAL), ("microcanonical", K.MICROCANONICAL)):
-            for lg, form in ((1, "one chain per wavefront"), (0, "automatic (8 chains per wavefront)")):
+            for lg, lc, form in ((1, 1, "one chain per wavefront"), (2, 1, "8 chains per wavefront"), (0, 0, auto)):
+                if (lg, lc) == (2, 1) and nch < 24576:
+                    continue
                 run(f"k4 8 schools nuts {kname}: {form}", N.DiagNutsSettings(trajectory_kind=kind, max_energy_error=50.0 if kind == K.MICROCANONICAL else 1000.0, **base),
-                    N.LogpSpec.eight_schools(), 8192, 400, a.draws, lane_groups=lg, lane_chains=1)
+                    N.LogpSpec.eight_schools(), nch, 400, a.draws, lane_groups=lg, lane_chains=lc)
         for lg, form in ((1, "one chain per wavefront"), (0, "automatic (8 chains per wavefront)")):
-            run(f"k4 8 schools mclmc: {form}", N.DiagMclmcSettings(step_size=0.4, max_energy_error=30.0, **base), N.LogpSpec.eight_schools(), 8192, 400, a.draws,
+            run(f"k4 8 schools mclmc: {form}", N.DiagMclmcSettings(step_size=0.4, max_energy_error=30.0, **base), N.LogpSpec.eight_schools(), nch, 400, a.draws,
                 lane_groups=lg, lane_chains=1)
         sys.exit(0)
     for dens, chains, mk in (("k2", 4096, lambda: N.LogpSpec.iid_normal(1024, 3.0)), ("k3", 8192, lambda: N.LogpSpec.funnel(101))):
