@@ -195,6 +195,44 @@ def test_user_density_with_low_rank_adaptation_trajectory_kinds_and_mclmc(oracle
         assert e.value.status == 4 and "NM_MODULE_VARIANTS" in str(e.value)
 
 
+def ensure_group_variant_module():
+    out = os.path.join(MODDIR, f"my_diag_normal_group_kinetic_dim{GROUP_DIM}.so")
+    srcs = [HEADER] + [os.path.join(B.CSRC, f) for f in ("density_module.hip", "nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "nuts_group.hpp", "nuts_group_impl.hpp")]
+    srcs.append(os.path.join(HERE, "..", "include", "nuts_amd.h"))
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        os.makedirs(MODDIR, exist_ok=True)
+        B.build_density_module(HEADER, "MyDiagNormal", GROUP_DIM, out, group_struct="MyDiagNormalGroup", variants=("kinetic",))
+    return out
+
+
+def test_group_form_module_with_kinetic_variant_builds():
+    m = C.CDLL(ensure_group_variant_module())
+    info = (C.c_uint64 * 8)()
+    m.nm_module_info(info)
+    assert (info[4], info[7]) == (8, 2)
+
+
+@pytest.mark.gpu
+def test_user_density_group_form_with_trajectory_kinds_and_mclmc(oracle):
+    """A user density with a group form AND the kinetic variant: the ExactNormal / Microcanonical kinds and MCLMC run 8 chains per wavefront
+    on it, with the oracle's bits (the group kernels' kinds, nuts_group_impl.hpp, through the module mechanism)."""
+    path = ensure_group_variant_module()
+    prec = np.exp(np.random.default_rng(6).uniform(-2, 2, GROUP_DIM))
+    n = 37
+    for s, draws in ((N.DiagNutsSettings(num_chains=n, seed=91, num_tune=60, trajectory_kind=N.KineticEnergyKind.EXACT_NORMAL), 100),
+                     (N.DiagNutsSettings(num_chains=n, seed=92, num_tune=60, trajectory_kind=N.KineticEnergyKind.MICROCANONICAL), 100),
+                     (N.DiagMclmcSettings(num_chains=n, seed=93, num_tune=60, step_size=0.5), 100)):
+        x0 = oracle.init_positions_uniform(s.seed, 0, n, GROUP_DIM)
+        b = N.ChainBatch(s, N.LogpSpec.module(GROUP_DIM, path, prec), n, lane_groups=2)
+        b.set_position(x0)
+        pos, st = b.draw_many(draws)
+        assert b.group_launches() >= 1
+        b.close()
+        pos_o, st_o, _, failed = run_oracle(oracle, s, N.LogpSpec.diag_normal(prec), n, x0, draws)
+        assert failed == 0
+        assert_bit_exact(pos, st, pos_o, st_o)
+
+
 WALLED = os.path.join(HERE, "user_density", "my_walled_normal.hpp")
 
 
