@@ -5,6 +5,7 @@ to create an engine without a HIP device (NM_ERR_NO_DEVICE).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -109,6 +110,26 @@ class NutsAmdError(RuntimeError):
         self.status = status
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it by the
+    name `libamdhip64.so`; libnuts_amd.so asks for `libamdhip64.so.7`.  When torch comes first the loader hands this library
+    torch's copy (SONAME match); when this library comes first it brings /opt/rocm's copy and torch then loads a SECOND runtime —
+    the one that initialises later sees no device (found in round 4: build() followed by smoke() in one process).  So torch's
+    copy, where torch is installed, is loaded here by path before the engine — without importing torch."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load():
     """Load the shared library (no compute, no GPU needed)."""
     global _lib
@@ -118,6 +139,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension with `python -m nuts_rs_amd.build` "
             "(nuts_rs_amd has no CPU fallback)")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, dbl = C.c_void_p, C.c_uint64, C.c_double
     L.nm_settings_default.argtypes = [C.POINTER(NmSettings)]
