@@ -257,6 +257,17 @@ NM_DEV double2 buf_load2(rsrc_t r, int voff, int soff) {
 #define NM_NT_STORES 1
 #endif
 constexpr int NM_AUX_NT = NM_NT_STORES ? 2 : 0;
+// Output rows of a draw: plain masked 8-byte stores (0), a per-row buffer descriptor with 16-byte stores for every vector output (1) or for the
+// position row only (2), and the cache policy of those stores.  Measured on K2 with every draw recorded (tools/gpu_wrb.sh,
+// profiles/r04zz_write_row_variants.txt): 0: 75.8 ms per 200 draws, 1: 73.4, 2: 72.4, 2 + non-temporal: 72.1 (without recording: 71 - 72 ms in
+// every form) — the position row is the one output every caller takes; the kernel is at its register cap and the form that touches the least
+// code wins.
+#ifndef NM_WRITE_ROW_BUF
+#define NM_WRITE_ROW_BUF 2
+#endif
+#ifndef NM_ROW_AUX
+#define NM_ROW_AUX 2
+#endif
 // The data registers of a 128-bit buffer store must not be overwritten right behind it.  LLVM's hazard recogniser knows this
 // hazard ("VMEM store of more than 64 bits, then a VALU write of its data VGPRs": 1 wait state) but exempts MUBUF stores whose
 // soffset is an SGPR — the addressing used here — and gfx950 does show it: `buffer_store_dwordx4 v[4:7], .., s8 offen` directly
@@ -2463,9 +2474,26 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
 // ---------------------------------------------------------------------------------------------
 // one row of a [n_draws][n_chains][dim] statistics array
 template <int DPL, int W, class Dens>
-NM_DEV void write_row(ChainCtx<DPL, W, Dens>& C, double* base, size_t row, const Tile<DPL>& t) {
+NM_DEV void write_row(ChainCtx<DPL, W, Dens>& C, double* base, size_t row, const Tile<DPL>& t, bool positions = false) {
     if (!base) return;
     double* dst = base + row + C.goff;
+#if NM_WRITE_ROW_BUF
+  if (NM_WRITE_ROW_BUF == 1 || positions) {
+    // One buffer descriptor per row (its base is wave-uniform), a lane's pair of elements (2 t, 2 t + 1) as ONE 16-byte store, the
+    // rows beyond dim cut off by the descriptor's range (whole pairs: the range ends on a pair boundary, an odd last element is
+    // written by its lane below): DPL / 2 coalesced stores instead of DPL masked 8-byte stores with a 64-bit address each.
+    const int whole = C.dim & ~1;
+    const rsrc_t r = make_rsrc(dst, (uint64_t)whole * 8);
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m) buf_store2_aux<NM_ROW_AUX>(r, C.voff + m * (64 * W * 16), 0, t.a[2 * m], t.a[2 * m + 1]);
+    if (C.dim & 1) {
+#pragma unroll
+        for (int m = 0; m < DPL / 2; ++m)
+            if (C.elem(2 * m) == C.dim - 1) dst[C.dim - 1] = t.a[2 * m];
+    }
+    return;
+  }
+#endif
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
         int d = C.elem(k);
@@ -2826,7 +2854,7 @@ NM_DEV void chain_draw(ChainCtx<DPL, W, Dens>& C, uint64_t chain, uint64_t t_out
     // DrawGradCollector::register_draw (adapt/diagonal.rs:73-83)
     const int64_t idx = R.chosen.idx;
     const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
-    write_row(C, P.out_positions, row, x);
+    write_row(C, P.out_positions, row, x, true);
     write_row(C, P.out_gradient, row, gx);                       // PointStats (transformed_hamiltonian.rs:122-157)
     write_row(C, P.out_tpos, row, z);
     write_row(C, P.out_tgrad, row, gz);
@@ -2943,7 +2971,7 @@ NM_DEV bool chain_draw_lr(ChainCtx<DPL, W, Dens>& C, uint64_t chain) {
     }
     const int64_t idx = R.chosen.idx;
     const bool is_good = R.diverging ? ((idx < 0 ? -idx : idx) > 4) : (idx != 0);
-    write_row(C, P.out_positions, row, x);
+    write_row(C, P.out_positions, row, x, true);
     write_row(C, P.out_gradient, row, gx);
     write_row(C, P.out_tpos, row, z);
     write_row(C, P.out_tgrad, row, gz);
