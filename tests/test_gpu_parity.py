@@ -752,3 +752,20 @@ def test_to_host_pipeline_equals_device_buffers(oracle):
         _lib.check(L.nm_host_unregister(pos_h.ctypes.data))
     b.close()
     assert (pos_h.view(np.uint64) == ref_pos.view(np.uint64)).all() and (st_h.view(np.uint8) == ref_st.view(np.uint8)).all()
+
+
+@pytest.mark.parametrize("dim", [1, 3, 127, 129, 1023, 1025, 2047, 2049, 4095, 4097, 8191, 9001])
+def test_position_rows_of_odd_dims_in_every_tiling(oracle, dim):
+    """The position row of a draw is written through a per-row buffer descriptor whose range ends on the last whole PAIR of elements; an
+    odd last element is stored by the lane that holds it (`write_row`).  Odd dims on every tiling (2 / 4 / 8 / 16 doubles per
+    lane, 1 / 2 / 4 wavefronts per chain, several blocks per chain beyond 4096), rows of neighbouring chains and draws packed without
+    padding: the engine's positions and statistics are the oracle's, and the cell behind a row's last element is the next row's first."""
+    n, nd = 3, 14
+    s = N.DiagNutsSettings(num_chains=n, seed=100 + dim, num_tune=8, num_draws=6, maxdepth=4)
+    logp = N.LogpSpec.iid_normal(dim, 3.0)
+    x0 = oracle.init_positions_uniform(s.seed, 0, n, dim)
+    pos_g, st_g, ex = run_engine(s, logp, n, x0, nd)
+    cfg = oracle.gpu_cfg(256, gpu_slice=4096) if dim > 4096 else oracle.gpu_cfg(ex["threads_per_chain"])      # (beyond 4096: the blocks' slices, tests/test_gpu_wide_chains.py)
+    pos_o, st_o, _, failed = run_oracle(oracle, s, logp, n, x0, nd, cfg=cfg)
+    assert failed == 0
+    assert_bit_exact(pos_g, st_g, pos_o, st_o)
