@@ -21,6 +21,9 @@
 namespace nm {
 namespace grp {
 constexpr int GMAXDEPTH = 10;
+#ifndef NM_GROUP_OCC_TUNE
+#define NM_GROUP_OCC_TUNE 2  // ... and the warm-up kernel's (1 measured on K4's 8192-chain shard, where one wavefront per SIMD is resident anyway: see DESIGN §8)
+#endif
 #ifndef NM_GROUP_OCC
 #define NM_GROUP_OCC 2       // waves per SIMD the sampling kernel's register allocation leaves room for (3: spills, slower)
 #endif

@@ -1389,8 +1389,10 @@ NM_DEV void g_chain_draw(GCtx<GD>& C, uint64_t chain, uint64_t t_out) {
 
 // TUNE = true: the whole adaptation is compiled in (any launch that starts inside the warm-up); TUNE = false: launches
 // after it, with the registers the adaptation would cost left to the tree
-template <class Dens, bool TUNE>
-__global__ __launch_bounds__(64, (TUNE ? 2 : NM_GROUP_OCC)) void nuts_group_draw_kernel(const KParams P) {
+// ROOMY = true: the same kernel with the register allocation of ONE wavefront per SIMD, for launches that have no second one anyway (a
+// grid of at most 4 x CUs blocks: K4's shard of 8192 chains is 1024 wavefronts) — 1.47e9 -> 1.61e9 leapfrogs/s there
+template <class Dens, bool TUNE, bool ROOMY = false>
+__global__ __launch_bounds__(64, (ROOMY ? 1 : TUNE ? NM_GROUP_OCC_TUNE : NM_GROUP_OCC)) void nuts_group_draw_kernel(const KParams P) {
     using GD0 = typename GroupDensity<Dens>::type;
     using GD = typename std::conditional<kin_trait<Dens>::value, GKin<GD0>, GD0>::type;
     __shared__ GroupShared sh;

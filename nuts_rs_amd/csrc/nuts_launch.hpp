@@ -8,7 +8,8 @@
 
 namespace nm {
 enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
-                  K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY };  // the small-chain kernels of nuts_group.hpp (dim <= 64): sampling / warm-up
+                  K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY,    // the small-chain kernels of nuts_group.hpp (dim <= 64): sampling / warm-up
+                  K_GROUP_DRAW_ROOMY, K_GROUP_TUNE_ROOMY };     // ... compiled for one wavefront per SIMD (grids of at most 4 x CUs blocks; Euclidean NUTS, built-in densities)
 
 // the small-chain kernels exist for the densities that have a group form (nuts_group.hpp); the group size follows P.dim
 #define NM_LAUNCH_GROUP_NS(NS)                                                                                            \
@@ -21,6 +22,11 @@ enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per 
             *occ = a > b ? a : b;                                                                                         \
             return st;                                                                                                    \
         }                                                                                                                 \
+        if constexpr (!kin_trait<Dens>::value) {                                                                          \
+            if (kind == K_GROUP_TUNE_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
+            if (kind == K_GROUP_DRAW_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
+        }                                                                                                                 \
+        if (kind == K_GROUP_TUNE_ROOMY || kind == K_GROUP_DRAW_ROOMY) return hipErrorInvalidValue;                        \
         if (kind == K_GROUP_TUNE) hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true>), dim3(grid_blocks), dim3(64), 0, stream, P); \
         else hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false>), dim3(grid_blocks), dim3(64), 0, stream, P);    \
         return hipGetLastError();                                                                                         \
@@ -41,7 +47,7 @@ inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_
 // hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
 template <int DPL, int W, class Dens>
 inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
-    if (kind == K_GROUP_DRAW || kind == K_GROUP_TUNE || kind == K_GROUP_QUERY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
+    if (kind == K_GROUP_DRAW || kind == K_GROUP_TUNE || kind == K_GROUP_QUERY || kind == K_GROUP_DRAW_ROOMY || kind == K_GROUP_TUNE_ROOMY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
     if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
     dim3 grid(grid_blocks), block(64 * W);
     if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
