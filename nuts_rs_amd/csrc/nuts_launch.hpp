@@ -9,7 +9,7 @@
 namespace nm {
 enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
                   K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY,    // the small-chain kernels of nuts_group.hpp (dim <= 64): sampling / warm-up
-                  K_GROUP_DRAW_ROOMY, K_GROUP_TUNE_ROOMY };     // ... compiled for one wavefront per SIMD (grids of at most 4 x CUs blocks; Euclidean NUTS, built-in densities)
+                  K_GROUP_DRAW_ROOMY, K_GROUP_TUNE_ROOMY };     // ... compiled for one wavefront per SIMD (grids of at most 4 x CUs blocks; built-in densities)
 
 // the small-chain kernels exist for the densities that have a group form (nuts_group.hpp); the group size follows P.dim
 #define NM_LAUNCH_GROUP_NS(NS)                                                                                            \
@@ -22,11 +22,8 @@ enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per 
             *occ = a > b ? a : b;                                                                                         \
             return st;                                                                                                    \
         }                                                                                                                 \
-        if constexpr (!kin_trait<Dens>::value) {                                                                          \
-            if (kind == K_GROUP_TUNE_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
-            if (kind == K_GROUP_DRAW_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
-        }                                                                                                                 \
-        if (kind == K_GROUP_TUNE_ROOMY || kind == K_GROUP_DRAW_ROOMY) return hipErrorInvalidValue;                        \
+        if (kind == K_GROUP_TUNE_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
+        if (kind == K_GROUP_DRAW_ROOMY) { hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false, true>), dim3(grid_blocks), dim3(64), 0, stream, P); return hipGetLastError(); } \
         if (kind == K_GROUP_TUNE) hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, true>), dim3(grid_blocks), dim3(64), 0, stream, P); \
         else hipLaunchKernelGGL((NS::nuts_group_draw_kernel<Dens, false>), dim3(grid_blocks), dim3(64), 0, stream, P);    \
         return hipGetLastError();                                                                                         \
