@@ -424,6 +424,102 @@ NM_DEV double logaddexp(double a, double b) {
     return diff;
 }
 
+// ---- the merge's scalar arithmetic as ONE straight-line routine (round 5) --------------------------------------------------
+// A lone wavefront issues one instruction per ~4.3 cycles whatever its kind and whether or not it depends on the one before
+// (tools/probes/ubench_issue.hip), a taken branch costs ~25 cycles, a VALU compare feeding a scalar branch ~38, a call ~78: what a
+// merge costs is the NUMBER of instructions on its path, not the latency of its dependent chain.  merge_into's arithmetic
+// (src/nuts.rs:172-207: logaddexp = exp + ln_1p, exp, the Bernoulli compare) through the general-purpose dexp / dlog1p is ~400
+// instructions (exec-masked special cases, 64-bit constants built from two s_mov each, three calls); here it is ONE routine
+// without a branch: the main path of every function is evaluated unconditionally on operands that cannot fault (table indices are
+// masked, conversions saturate), the special cases are selects at the end, and the operation sequence of the main path is EXACTLY
+// dexp_impl / dlog1p_impl / dlog_core's (same bits; tests/test_merge_math.py runs both on the host over special and random operands).
+//   exp_sl(x)       == dexp_impl(x) for every x
+//   log1p_unit(x)   == dlog1p_impl(x) for x in [0, 1] or NaN (what exp(-|d|) can be)
+NM_HD int dm_cvt_i32(double x) {           // v_cvt_i32_f64: saturating, NaN -> 0 (a C cast of an out-of-range value is undefined)
+#if defined(__HIP_DEVICE_COMPILE__)
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));
+    return n;
+#else
+    return x != x ? 0 : (x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (int)(-2147483647 - 1) : (int)x));
+#endif
+}
+NM_HD double exp_sl(double x) {
+    const double nf = __builtin_rint(x * DM_EXP_INV_L);
+    const double r1 = __builtin_fma(-nf, DM_EXP_L_HI, x);
+    const double r = __builtin_fma(-nf, DM_EXP_L_LO, r1);
+    const int n = dm_cvt_i32(nf);
+    const int j = n & 63, k = n >> 6;
+    const double r2 = r * r;
+    const double a = __builtin_fma(r, DM_EXP_E3, DM_EXP_E2);
+    const double b = __builtin_fma(r, DM_EXP_E5, DM_EXP_E4);
+    const double q = __builtin_fma(r2, __builtin_fma(r2, DM_EXP_E6, b), a);
+    const double p = __builtin_fma(r2, q, r);
+    const double th = DM_TAB(DM_T_HI, DM_OFF_T_HI, j);
+    const double sum = __builtin_fma(th, p, DM_TAB(DM_T_LO, DM_OFF_T_LO, j));
+    double res = __builtin_ldexp(th + sum, k);
+    res = x > 7.09782712893383973096e+02 ? __builtin_inf() : res;
+    res = x < -7.45133219101941108420e+02 ? 0.0 : res;
+    return x != x ? x : res;
+}
+NM_HD double log1p_unit(double x) {
+    const double u = 1.0 + x;                                  // [1, 2] or NaN
+    const double c = x - (u - 1.0);
+    const uint64_t ub = d2u(u);
+    const uint64_t mant = ub & 0x000fffffffffffffull;
+    const int up = mant >= 0x6a09e667f3bcdull;
+    const int k = (int)(ub >> 52) - 1023 + up;                 // 0, 1 (or anything for NaN: discarded)
+    const double m = u2d(mant | ((uint64_t)(1023 - up) << 52));
+    const int j = (int)__builtin_rint(m * 64.0) - DM_LOG_J0;   // m in [sqrt 1/2, sqrt 2) whatever u's bits: 0..46
+    const double rj = DM_TAB(DM_R, DM_OFF_R, j);
+    const double z = __builtin_fma(m, rj, -1.0);
+    const double dk = (double)k;
+    const double z2 = z * z, z4 = z2 * z2;
+    const double p01 = __builtin_fma(z, DM_LOG_C3, DM_LOG_C2), p23 = __builtin_fma(z, DM_LOG_C5, DM_LOG_C4);
+    const double p45 = __builtin_fma(z, DM_LOG_C7, DM_LOG_C6), p67 = __builtin_fma(z, DM_LOG_C9, DM_LOG_C8);
+    const double q0 = __builtin_fma(z2, p23, p01), q1 = __builtin_fma(z2, p67, p45);
+    const double Q = __builtin_fma(z4, __builtin_fma(z4, DM_LOG_C10, q1), q0);
+    const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
+    const double corr = (c * rj) * u2d((uint64_t)(1023 - kc) << 52);
+    const double lo = __builtin_fma(dk, DM_LN2_LO, DM_TAB(DM_F_LO, DM_OFF_F_LO, j)) + corr;
+    const double t = __builtin_fma(z2, Q, lo);
+    const double hk = dk * DM_LN2_HI;
+    const double fh = DM_TAB(DM_F_HI, DM_OFF_F_HI, j);
+    const double s1 = hk + fh, e1 = (hk - s1) + fh;
+    const double s2 = s1 + z, e2 = (s1 - s2) + z;
+    double res = s2 + ((e1 + e2) + t);
+    res = u == 1.0 ? x : res;
+    return u != u ? u : res;
+}
+// merge_into's scalars (reference src/nuts.rs:172-207).  (w_lo, w_hi): the NEXT u64 of the chain's stream, read but not consumed by
+// the caller.  flags: bit 0 take other's draw, bit 1 the u64 was consumed (random_bool drew), bit 2 fatal (p outside [0, 1]: the reference panics)
+struct MergeOut { double total; uint32_t flags; };
+NM_HD MergeOut merge_math_impl(double a, double b, uint32_t is_main, uint32_t w_lo, uint32_t w_hi) {
+    const double diff = a - b;
+    const double e = exp_sl(diff > 0. ? -diff : diff);
+    const double lp = log1p_unit(e);
+    double total = (diff > 0. ? a : b) + lp;
+    total = (diff > 0. || diff < 0.) ? total : diff;                        // neither: NaN (util.rs:18)
+    total = a == b ? a + 0x1.62e42fefa39efp-1 : total;                      // = dlog(2.0), bit for bit (tests/test_merge_math.py)
+    const double self_log_size = is_main ? a : total;
+    const bool ge = b >= self_log_size;
+    const double p_ = exp_sl(b - self_log_size);
+    const bool in01 = p_ >= 0.0 && p_ < 1.0;                                // random_bool(p): p outside [0, 1) draws nothing
+    // (u64)(p * 2^64) for p in [0, 1): the integer part of an exact product
+    const double ph = __builtin_floor(p_ * 4294967296.0);                   // high 32 bits
+    const double pl = __builtin_floor(__builtin_fma(p_, 18446744073709551616.0, -ph * 4294967296.0));
+    const uint64_t p_int = in01 ? (((uint64_t)(uint32_t)ph << 32) | (uint64_t)(uint32_t)pl) : 0ull;
+    const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
+    const bool draws = !ge && in01;
+    const bool take = ge || (in01 ? w < p_int : p_ == 1.0);
+    const bool fatal = !ge && !in01 && !(p_ == 1.0);
+    MergeOut o;
+    o.total = total;
+    o.flags = (take && !fatal ? 1u : 0u) | (draws ? 2u : 0u) | (fatal ? 4u : 0u);
+    return o;
+}
+static __device__ __noinline__ MergeOut merge_math(double a, double b, uint32_t is_main, uint32_t w_lo, uint32_t w_hi) { return merge_math_impl(a, b, is_main, w_lo, w_hi); }
+
 // exp(x) - 1 for the isokinetic momentum refresh (reference f64::exp_m1, transformed_hamiltonian.rs:800-801): the same
 // operation sequence as oracle/nmo_math.hpp det_expm1 (Taylor series to x^14 for |x| <= 0.35, else exp(x) - 1)
 template <bool INL>

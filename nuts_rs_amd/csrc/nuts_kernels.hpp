@@ -76,6 +76,12 @@ __host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(m
 // (Computed once by the host into KParams::layout_md: reading both settings fields in ctx_begin changed the register allocation of the
 // 16-wavefront matrix-core kernel enough to break it — the last doubling of trees deeper than 6 stopped after one leaf)
 __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)(s.maxdepth + s.extra_doublings); }
+#ifndef NM_FUSED_LEAPFROG
+#define NM_FUSED_LEAPFROG 1        // 0: the leapfrog as three loops over the tile for every density (rounds 1-4; bisecting builds)
+#endif
+#ifndef NM_MERGE_MATH_ROUTINE
+#define NM_MERGE_MATH_ROUTINE 1   // 0: merge_weights through the general-purpose exp / ln_1p (rounds 1-4; bisecting builds)
+#endif
 #ifndef NM_BATCH_MERGES
 #define NM_BATCH_MERGES 1        // 0: every merge evaluated where the reference evaluates it (tuning / bisecting builds)
 #endif
@@ -297,6 +303,16 @@ NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
 // ---------------------------------------------------------------------------------------------
 struct IidNormal {
     static constexpr bool kNeedsLdsVector = false;
+    // element form of eval (leapfrog's fused loop): gradient element and, through `term`, what eval adds to its sum for this element
+    static constexpr bool kElementwise = true;
+    template <int W, bool FULL>
+    NM_DEV double elem(double xk, int k, int dim, double& term) const {
+        const double diff = xk - mu;
+        const double t = -0.5 * diff * diff;
+        if constexpr (FULL) { term = t; return -diff; }
+        else { const bool valid = elem_index<W>(k) < dim; term = valid ? t : 0.0; return valid ? -diff : 0.0; }
+    }
+    NM_DEV double finish(double sum) const { return sum; }
     NM_DEV void set_lds(double*) {}   // reference benches/sample.rs:49-62
     double mu;
     template <int W>
@@ -306,6 +322,18 @@ struct IidNormal {
     template <int DPL, int W>
     NM_DEV double eval(const Tile<DPL>& x, Tile<DPL>& gx, int dim, Reducer<W>& R) const {
         double acc = 0.0;
+#if !NM_CLUSTER_MODE
+        if (dim == DPL * 64 * W) {          // a full tile has no padding: no validity selects (4 v_cndmask + a compare per element; uniform branch)
+#pragma unroll
+            for (int k = 0; k < DPL; ++k) {
+                double diff = x.a[k] - mu;
+                double term = -0.5 * diff * diff;
+                gx.a[k] = -diff;
+                acc = acc + term;
+            }
+            return R.sum(acc);
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < DPL; ++k) {
             bool valid = elem_index<W>(k) < dim;
@@ -320,6 +348,17 @@ struct IidNormal {
 
 struct DiagNormal {
     static constexpr bool kNeedsLdsVector = false;
+    static constexpr bool kElementwise = true;
+    template <int W, bool FULL>
+    NM_DEV double elem(double xk, int k, int dim, double& term) const {
+        const int d = elem_index<W>(k);
+        const bool valid = FULL || d < dim;
+        const double p = valid ? prec[d] : 0.0;
+        const double px = p * xk;
+        term = valid ? xk * px : 0.0;
+        return valid ? -px : 0.0;
+    }
+    NM_DEV double finish(double sum) const { return -0.5 * sum + norm; }
     NM_DEV void set_lds(double*) {}  // diagonal-P case of the MvNormal fixture, reference src/transform/mod.rs:98-112
     const double* prec;
     double norm;
@@ -599,6 +638,8 @@ struct HostCb {
     }
 #endif
 };
+template <class D, class = void> struct elementwise_trait { static constexpr bool value = false; };
+template <class D> struct elementwise_trait<D, typename std::enable_if<D::kElementwise>::type> { static constexpr bool value = true; };
 template <class D, class = void> struct can_fail { static constexpr bool value = false; };
 template <class D> struct can_fail<D, typename std::enable_if<D::kCanFail>::type> { static constexpr bool value = true; };
 // status of the density's last evaluation (0 for densities that cannot fail)
@@ -1085,6 +1126,57 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
     }
     const double2* sg2 = C.tptr(C.lsig);
     const double2* mu2 = C.tptr(C.lmu);
+#if NM_FUSED_LEAPFROG
+    if constexpr (elementwise_trait<Dens>::value && !NM_CLUSTER_MODE && !NM_TILE_MODE) {
+        // Element-wise densities: everything the step does to element k — half kick, drift, x = sigma z + mu, the density's gradient
+        // element and logp term, g_z = sigma g_x, second half kick, v^2 — depends on element k alone; only the two sums couple the
+        // elements, and nothing reads them before the end.  ONE pass, element pair by element pair, instead of three loops over the
+        // tile: the intermediate tiles (x, g_x, the half-kicked v) never exist, so the two points the tree keeps (96 + 96 registers at
+        // 16 doubles per lane) stay in the 256 architectural registers instead of commuting to the accumulation registers
+        // (v_accvgpr_read / write: ~190 of a leapfrog's ~390 instructions in round 4's code; a lone wavefront is bound by the NUMBER of
+        // instructions it issues).  Same operations on the same operands in the same order per element; the sums accumulate in
+        // element order as before and go through one reduction of two values (the same butterfly per value): same bits.
+        double acc = 0.0, kacc = 0.0;
+        auto pass = [&](auto full_tile) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tile)::value;
+            double2 sg = sg2[0], mm = mu2[0];
+#pragma unroll
+            for (int m = 0; m < DPL / 2; ++m) {
+                const double2 sg_c = sg, mm_c = mm;
+                if (m + 1 < DPL / 2) { sg = sg2[(m + 1) * 64 * W]; mm = mu2[(m + 1) * 64 * W]; }      // the next pair's sigma / mu are in flight during this pair
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = 2 * m + j;
+                    const double sgk = j ? sg_c.y : sg_c.x, muk = j ? mm_c.y : mm_c.x;
+                    // (v_fma_f64 spelled out: the source point's v and z stay live, and the compiler's two-address form — v_mov_b64 + v_fmac_f64 —
+                    // costs an instruction more per fma; the same IEEE fused multiply-add)
+                    double vh, zk;
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+                    o.z.a[k] = zk;
+                    const double t = zk * sgk;
+                    const double xk = __builtin_fma(1.0, muk, t);
+                    double term;
+                    const double gxk = C.dens.template elem<W, FULL>(xk, k, C.dim, term);
+                    acc = acc + term;
+                    const double gk = gxk * sgk;
+                    o.g.a[k] = gk;
+                    const double vk = __builtin_fma(half, gk, vh);
+                    o.v.a[k] = vk;
+                    kacc = __builtin_fma(vk, vk, kacc);
+                    if (x_out) x_out->a[k] = xk;
+                    if (gx_out) gx_out->a[k] = gxk;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (C.dim == DPL * 64 * W) pass(std::true_type{}); else pass(std::false_type{});
+        C.red.sum2(acc, kacc);
+        o.logp = C.dens.finish(acc);
+        o.ke = 0.5 * kacc;
+        return;
+    }
+#endif
 #pragma unroll
     for (int m = 0; m < DPL / 2; ++m) {
         const double2 sg = sg2[m * 64 * W], mm = mu2[m * 64 * W];
@@ -1714,6 +1806,19 @@ NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b
     return false;
 #endif
     NM_MARK(C, 13)
+#if NM_MERGE_MATH_ROUTINE
+    // the whole of merge_into's arithmetic in one branch-free routine (dev_math.hpp merge_math).  The chain's next u64 is read here and
+    // consumed only if the routine says random_bool drew it; refilling the word cache early changes nothing (it is a window onto the stream).
+    if (!C.rng.has(2)) C.rng.refill();
+    const uint32_t off_ = (uint32_t)(C.rng.pos - C.rng.base);
+    const MergeOut mo = merge_math(a_log_size, b_log_size, is_main ? 1u : 0u, C.rng.cache[off_], C.rng.cache[off_ + 1]);
+    total = uniform_f64(mo.total);
+    const uint32_t mf = (uint32_t)__builtin_amdgcn_readfirstlane((int)mo.flags);
+    C.rng.pos += (uint64_t)(mf & 2u);
+    NM_MARK(C, 29)
+    if (mf & 4u) fatal = true;
+    return (mf & 1u) != 0;
+#else
     total = logaddexp(a_log_size, b_log_size);
     NM_MARK(C, 14)
     const double self_log_size = is_main ? a_log_size : total;
@@ -1724,6 +1829,7 @@ NM_DEV bool merge_weights(ChainCtx<DPL, W, Dens>& C, double a_log_size, double b
     NM_MARK(C, 29)
     if (b < 0) { fatal = true; return false; }
     return b == 1;
+#endif
 }
 
 struct DrawResult {
@@ -1737,17 +1843,27 @@ struct DrawResult {
 };
 
 
-// is_turning(first-generated a, later-generated b) for two register points; fwd decides which is `start`
+// is_turning and the direction of integration.  The reference orders the two states by index_in_trajectory
+// (transformed_hamiltonian.rs:617-638): integrating backwards, the LATER generated point b is `start` and the earlier one a is
+// `end`.  With s = (z_end + 0) - z_start, t1 += s v_start, t2 += s v_end (turn_acc), swapping the roles negates s exactly
+// (x - y = -(y - x) in IEEE arithmetic; both are +0 when x == y), hence every product, every partial sum and every step of the
+// reduction: (t1, t2)_backward = (-t2, -t1)_forward, up to the sign of zeros, which `< 0` cannot see.  So the sums are always
+// accumulated in generation order (a = start) and the direction only flips the comparison: fwd: t < 0, backward: t > 0 (NaN: false
+// both ways).  Per-element operand selects by `fwd` were 128 v_cndmask per level-1 test at 16 doubles per lane (round 5: a lone
+// wavefront is bound by the number of instructions it issues, tools/probes/ubench_issue.hip).
+NM_DEV bool turn_sign(bool fwd, double t) { return fwd ? t < 0. : t > 0.; }
+NM_DEV bool turn_any6(bool fwd, double s1, double s2, double s3, double s4, double s5, double s6) {
+    return fwd ? ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.))
+               : ((s1 > 0.) | (s2 > 0.) | (s3 > 0.) | (s4 > 0.) | (s5 > 0.) | (s6 > 0.));
+}
+// is_turning(first-generated a, later-generated b) for two register points
 template <int DPL, int W>
 NM_DEV bool turning_regs(const Pt<DPL>& a, const Pt<DPL>& b, bool fwd, Reducer<W>& R) {
     double s1 = 0., s2 = 0.;
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) {
-        if (fwd) turn_acc(a.z.a[k], a.v.a[k], b.z.a[k], b.v.a[k], s1, s2);
-        else turn_acc(b.z.a[k], b.v.a[k], a.z.a[k], a.v.a[k], s1, s2);
-    }
+    for (int k = 0; k < DPL; ++k) turn_acc(a.z.a[k], a.v.a[k], b.z.a[k], b.v.a[k], s1, s2);
     R.sum2(s1, s2);
-    return (s1 < 0.) | (s2 < 0.);
+    return turn_sign(fwd, s1) | turn_sign(fwd, s2);
 }
 
 // the candidate's z goes to a fresh pool slot
@@ -1794,7 +1910,7 @@ typedef const __attribute__((address_space(3))) uint32_t* lds_words_t;       // 
 NM_DEV ChunkOut resolve_chunk_core(double wv, uint32_t shape, lds_words_t words) {
     const int m = (int)(shape & 0xff), n_last = (int)((shape >> 8) & 0xff), k_last = (int)((shape >> 16) & 0xff);
     const int l = lane_id();
-    const double ln2 = dlog_impl<false>(2.0);
+    const double ln2 = 0x1.62e42fefa39efp-1;    // = dlog(2.0) (tests/cpp/merge_math_check.hip)
     double ls = wv;                      // log size of the sub-tree this lane currently closes (level 0: its own leaf)
     uint64_t pint[6];                    // Bernoulli thresholds of this lane's merges, by level
     uint32_t need = 0, sure = 0, bad = 0, perf = 0;
@@ -1807,11 +1923,11 @@ NM_DEV ChunkOut resolve_chunk_core(double wv, uint32_t shape, lds_words_t words)
             const bool done = part && (l < n_last || (l == n_last && k <= k_last));
             const double a = shfl_f64(ls, l - h), b = ls;                         // A = the sibling that closed h leaves earlier
             const double diff = a - b;
-            const double e = dexp_impl<false>(diff > 0. ? -diff : diff);
-            const double lp = dlog1p_impl<false>(e);
+            const double e = exp_sl(diff > 0. ? -diff : diff);                      // (branch-free forms of the same operation sequences, dev_math.hpp)
+            const double lp = log1p_unit(e);
             const double total = a == b ? a + ln2 : (diff > 0. ? a + lp : (diff < 0. ? b + lp : diff));   // logaddexp (util.rs:6-19)
             const bool ge = b >= total;                                           // self.log_size = the merged size (not the main tree)
-            const double p_ = dexp_impl<false>(b - total);
+            const double p_ = exp_sl(b - total);
             const bool in01 = p_ >= 0.0 && p_ < 1.0;                              // random_bool(p): p outside [0, 1) draws nothing
             pint[k - 1] = in01 ? (uint64_t)(p_ * 18446744073709551616.0) : 0ull;
             if (done) {
@@ -2020,40 +2136,41 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     for (int m = 0; m < DPL / 2; ++m) {
                         double2 az = fwd ? C.ld2(mlz.r, mlz.so, m) : C.ld2(mrz.r, mrz.so, m);
                         double2 av = fwd ? C.ld2(mlv.r, mlv.so, m) : C.ld2(mrv.r, mrv.so, m);
-                        if (fwd) { turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2); turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2); }
-                        else { turn_acc(O.z.a[2 * m], O.v.a[2 * m], az.x, av.x, s1, s2); turn_acc(O.z.a[2 * m + 1], O.v.a[2 * m + 1], az.y, av.y, s1, s2); }
+                        turn_acc(az.x, av.x, O.z.a[2 * m], O.v.a[2 * m], s1, s2); turn_acc(az.y, av.y, O.z.a[2 * m + 1], O.v.a[2 * m + 1], s1, s2);
                     }
                     C.red.sum2(s1, s2);
-                    return (s1 < 0.) | (s2 < 0.);
+                    return turn_sign(fwd, s1) | turn_sign(fwd, s2);
 #endif
                 } else {
                     // other.first (leaf 0 of this doubling): F[depth]; at depth 1 it is still E
                     const int so_ofz = C.soS(slot_F((int)depth)), so_ofv = C.soS(slot_F((int)depth) + 1);
                     const bool of_in_regs = NM_TRIM_FIRST && depth == 1;
+                    // The reference's three pairs (src/nuts.rs:143-161), each written (earlier in the trajectory, later):
+                    //   forward   (tree.left, other.right) (tree.right, other.right) (tree.left, other.left)     other.right = O, other.left = its first leaf
+                    //   backward  (other.left, tree.right) (other.right, tree.right) (other.left, tree.left)     other.left = O, other.right = its first leaf
+                    // In generation order (tree side first; turning_regs' note: a pair the other way round is the same sums negated) both
+                    // are (left, O) (right, O) (X, first leaf) with X = the tree's edge FAR from `other`: left going forward, right going
+                    // backward.  One loop per direction (they differ in one operand; selecting it per element would be 8 v_cndmask per row).
+                    auto rows = [&](auto far_is_left) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int m = 0; m < DPL / 2; ++m) {
-                        double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
-                        double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
-                        double2 oz, ov;
-                        if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
-                        else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
-                        const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
-                        const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
-                        if (fwd) {
-                            // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
+                        for (int m = 0; m < DPL / 2; ++m) {
+                            double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
+                            double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
+                            double2 oz, ov;
+                            if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
+                            else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
+                            const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
+                            const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                             turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
                             turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
-                            turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6);
-                        } else {
-                            // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
-                            turn_acc(cz0, cv0, rz.x, rv.x, s1, s2); turn_acc(cz1, cv1, rz.y, rv.y, s1, s2);
-                            turn_acc(oz.x, ov.x, rz.x, rv.x, s3, s4); turn_acc(oz.y, ov.y, rz.y, rv.y, s3, s4);
-                            turn_acc(cz0, cv0, lz.x, lv.x, s5, s6); turn_acc(cz1, cv1, lz.y, lv.y, s5, s6);
+                            if constexpr (decltype(far_is_left)::value) { turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6); }
+                            else { turn_acc(rz.x, rv.x, oz.x, ov.x, s5, s6); turn_acc(rz.y, rv.y, oz.y, ov.y, s5, s6); }
+                            NM_GROUP_BARRIER(m);
                         }
-                        NM_GROUP_BARRIER(m);
-                    }
+                    };
+                    if (fwd) rows(std::true_type{}); else rows(std::false_type{});
                     { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                    return (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+                    return turn_any6(fwd, s1, s2, s3, s4, s5, s6);
                 }
         };
         if (depth == 0) {
@@ -2122,15 +2239,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                     const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
                                     const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
                                     const double bz = E.z.a[2 * m + j], bv = E.v.a[2 * m + j];
-                                    if (fwd) {
-                                        turn_acc(azj, avj, cz, cv, s1, s2);
-                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
-                                        turn_acc(azj, avj, bz, bv, s5, s6);
-                                    } else {
-                                        turn_acc(cz, cv, azj, avj, s1, s2);
-                                        turn_acc(cz, cv, lzj, lvj, s3, s4);
-                                        turn_acc(bz, bv, azj, avj, s5, s6);
-                                    }
+                                    turn_acc(azj, avj, cz, cv, s1, s2);      // (generation order; the direction flips the comparison: turn_any6)
+                                    turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                    turn_acc(azj, avj, bz, bv, s5, s6);
                                 }
                                 NM_GROUP_BARRIER(m);
                             }
@@ -2147,21 +2258,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                     const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
                                     const double bz = j ? bz2.y : bz2.x, bv = j ? bv2.y : bv2.x;
                                     const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
-                                    if (fwd) {
-                                        turn_acc(azj, avj, cz, cv, s1, s2);
-                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
-                                        turn_acc(azj, avj, bz, bv, s5, s6);
-                                    } else {
-                                        turn_acc(cz, cv, azj, avj, s1, s2);
-                                        turn_acc(cz, cv, lzj, lvj, s3, s4);
-                                        turn_acc(bz, bv, azj, avj, s5, s6);
-                                    }
+                                    turn_acc(azj, avj, cz, cv, s1, s2);      // (generation order; the direction flips the comparison: turn_any6)
+                                    turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                    turn_acc(azj, avj, bz, bv, s5, s6);
                                 }
                                 NM_GROUP_BARRIER(m);
                             }
                         }
                         { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                        if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
+                        if (turn_any6(fwd, s1, s2, s3, s4, s5, s6)) turn_bits |= 1u << k;
                     }
                 }
                 NM_MARK(C, 21)
@@ -2281,15 +2386,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                         const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
                                         const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
                                         const double bz = E.z.a[2 * m + j], bv = E.v.a[2 * m + j];
-                                        if (fwd) {
-                                            turn_acc(azj, avj, cz, cv, s1, s2);
-                                            turn_acc(lzj, lvj, cz, cv, s3, s4);
-                                            turn_acc(azj, avj, bz, bv, s5, s6);
-                                        } else {
-                                            turn_acc(cz, cv, azj, avj, s1, s2);
-                                            turn_acc(cz, cv, lzj, lvj, s3, s4);
-                                            turn_acc(bz, bv, azj, avj, s5, s6);
-                                        }
+                                        turn_acc(azj, avj, cz, cv, s1, s2);      // (generation order; the direction flips the comparison: turn_any6)
+                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                        turn_acc(azj, avj, bz, bv, s5, s6);
                                     }
                                     NM_GROUP_BARRIER(m);
                                 }
@@ -2306,21 +2405,15 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                         const double lzj = j ? lz.y : lz.x, lvj = j ? lv.y : lv.x;
                                         const double bz = j ? bz2.y : bz2.x, bv = j ? bv2.y : bv2.x;
                                         const double cz = O.z.a[2 * m + j], cv = O.v.a[2 * m + j];
-                                        if (fwd) {
-                                            turn_acc(azj, avj, cz, cv, s1, s2);
-                                            turn_acc(lzj, lvj, cz, cv, s3, s4);
-                                            turn_acc(azj, avj, bz, bv, s5, s6);
-                                        } else {
-                                            turn_acc(cz, cv, azj, avj, s1, s2);
-                                            turn_acc(cz, cv, lzj, lvj, s3, s4);
-                                            turn_acc(bz, bv, azj, avj, s5, s6);
-                                        }
+                                        turn_acc(azj, avj, cz, cv, s1, s2);      // (generation order; the direction flips the comparison: turn_any6)
+                                        turn_acc(lzj, lvj, cz, cv, s3, s4);
+                                        turn_acc(azj, avj, bz, bv, s5, s6);
                                     }
                                     NM_GROUP_BARRIER(m);
                                 }
                             }
                             { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                            if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
+                            if (turn_any6(fwd, s1, s2, s3, s4, s5, s6)) turn_bits |= 1u << k;
                         }
                     }
                 NM_MARK(C, 21)
