@@ -221,6 +221,37 @@ def bound_model(st, D, kern_s, traffic):
                           "construction; moving more bytes cannot raise it"}
 
 
+def generic_bound(n_steps_cd, depth_cd, D, kern_s, traffic, elems_per_lane=None, latency=False):
+    """A lower bound on the launch time of ANY engine that integrates these trees: the largest of
+      t_hbm     necessary HBM bytes / 8 TB/s — per draw: read z, g_z, sigma, mu, write z, g_z and the position row (7 vectors) + the
+                192 B statistics row (tree end points are not counted here: a LOWER bound stays one when terms are left out);
+      t_valu    necessary f64 vector instructions / (1024 SIMDs x one 64-lane f64 instruction per 4 cycles x 2.4 GHz): 11 per
+                (leapfrog x element) + 12 per (closed sub-tree level x element), elements packed 64 per instruction;
+      t_chain   (latency=True: launches that last as long as their slowest chain) the leapfrogs of the deepest chain x the cycles one
+                wavefront needs to ISSUE the necessary instructions of one leapfrog of one chain (a lone wavefront issues one instruction
+                per 4 cycles, dependent or not: tools/probes/ubench_issue.hip).
+    n_steps_cd / depth_cd: [draws][chains] of the timed launch."""
+    n_steps = n_steps_cd.astype(np.float64)
+    depth = depth_cd.astype(np.float64)
+    draws = float(n_steps.size)
+    nec_bytes = draws * (7.0 * D * 8.0 + 192.0)
+    levels = n_steps.sum() + depth.sum()
+    ops_elem = NEC_VALU_LEAPFROG * n_steps.sum() + NEC_VALU_PER_TEST_LEVEL * levels
+    t_hbm = nec_bytes / (HBM_PEAK_GBS * 1e9)
+    t_valu = ops_elem * (D / 64.0) * F64_VALU_CYCLES_PER_WAVE_INSTR / (N_SIMD * SHADER_HZ)
+    terms = {"hbm": t_hbm, "valu": t_valu}
+    if latency:
+        per_chain = n_steps.sum(axis=0)
+        epl = elems_per_lane or max(1.0, float(-(-D // 64)))
+        ops_leaf = (NEC_VALU_LEAPFROG + NEC_VALU_PER_TEST_LEVEL * (levels / max(1.0, n_steps.sum()))) * epl
+        terms["slowest_chain"] = float(per_chain.max()) * ops_leaf * F64_VALU_CYCLES_PER_WAVE_INSTR / SHADER_HZ
+    binding = max(terms, key=terms.get)
+    t_min = terms[binding]
+    return {"frac": t_min / kern_s, "binding": binding, "t_min_ms": t_min * 1e3, "t_kernel_ms": kern_s * 1e3,
+            "terms_ms": {k: v * 1e3 for k, v in terms.items()}, "necessary_bytes": nec_bytes,
+            "waste_ratio": (traffic / nec_bytes) if traffic else None}
+
+
 def pmc_profile(steps_dims):
     """Fallback: the latest committed profile's bytes per (leapfrog-step x dim), scaled to this run's steps x dims."""
     best = None
@@ -381,7 +412,8 @@ def run_other_config(key, seed, steps, warmup, record=True):
     n_steps = int(st["n_steps"].sum())
     ok = n_steps == c["total_leapfrogs"] and bool((st["draw"][-1] == cfg["tune"] + warmup + steps - 1).all()) and \
         (not record or bool(torch.isfinite(d_pos[-1]).all().item()))
-    res = {"workload": cfg["name"], "chains": C_, "dim": D, "steps": steps, "value": n_steps * D / dt, "unit": "leapfrog-steps*dims/s",
+    res = {"_n_steps": st["n_steps"].astype(np.int64), "_depth": st["depth"].astype(np.int64),
+           "workload": cfg["name"], "chains": C_, "dim": D, "steps": steps, "value": n_steps * D / dt, "unit": "leapfrog-steps*dims/s",
            "leapfrogs_per_s": n_steps / dt, "ms_per_step": dt / steps * 1e3, "draws_per_sec_per_chain": steps / dt,
            "leapfrogs_per_draw": n_steps / (steps * C_), "kernel_ms_per_launch": c["kernel_ms"], "total_leapfrogs": n_steps,
            "divergence_rate": float(st["diverging"].mean()), "mean_depth": float(st["depth"].mean()),
@@ -417,6 +449,13 @@ def other_config_roofline(args, key, res, deadline):
                             hbm_bytes_per_leapfrog=(fetch_b + write_b) / child_steps, moved_over_algorithmic=traffic / algo)
             else:
                 roof["pmc_failed"] = why
+        # `frac` is a BOUND (t_min / t_kernel <= 1, cannot be raised by moving more bytes); the utilisation of moved bytes is `frac_moved`
+        bm = generic_bound(res["_n_steps"], res["_depth"], D, kern_s, roof["traffic"], latency=(key == "k3"))
+        roof["frac_moved"] = roof["frac"]
+        roof.update(frac=bm["frac"], binding=bm["binding"], waste_ratio=bm["waste_ratio"], t_min_ms=bm["t_min_ms"], bound_terms_ms=bm["terms_ms"],
+                    frac_sec8d_model=roof["algorithmic"]["frac_sec8d_model"],
+                    frac_definition="frac = t_min / t_kernel, t_min = max(necessary HBM bytes / 8 TB/s, necessary f64 VALU instructions / chip issue rate"
+                                    + (", leapfrogs of the deepest chain x issue cycles of one leapfrog" if key == "k3" else "") + "); waste_ratio = HBM bytes moved / necessary")
         return roof
     flop = 2.0 * (4 * D * D + D * D)        # per chain-leapfrog: U'v and U s for x and for g_z (rank = dim), P x for the density
     useful = n_steps * flop / kern_s / 1e12
@@ -436,6 +475,9 @@ def other_config_roofline(args, key, res, deadline):
                 roof["mfma_issued_TFLOPs"] = got["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0 / ck / 1e12
         else:
             roof["pmc_failed"] = why
+    roof["binding"] = "mfma"
+    roof["waste_ratio"] = (roof["mfma_issued_TFLOPs"] / useful) if roof.get("mfma_issued_TFLOPs") else None      # matrix-core flops issued / useful
+    roof["frac_definition"] = "frac = useful f64 flop of the dense products / launch time / 78.6 TFLOP/s (<= 1); waste_ratio = issued / useful matrix-core flops"
     return roof
 
 
@@ -452,6 +494,7 @@ def other_configs(args):
         try:
             res = run_other_config(k, args.seed, args.other_steps, args.warmup, record=not args.no_record)
             res["roofline"] = other_config_roofline(args, k, res, deadline)
+            res.pop("_n_steps", None); res.pop("_depth", None)
             res["key"] = k
             out.append(res)
         except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
@@ -735,6 +778,7 @@ def main():
         if traffic is None and args.pmc != "off":
             traffic, traffic_src = pmc_profile(steps_local * D)
         achieved = (traffic / kern_s / 1e9) if traffic else None
+        bm = (bound_model(st_all, D, kern_s, traffic) if st_all is not None else None) or {}
         out = {
             "metric": "leapfrog-steps*dims/sec at 4096 chains x dim 1024 (post-warm-up NUTS draws)",
             "value": value, "unit": "leapfrog-steps*dims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -752,14 +796,18 @@ def main():
             "adaptation": {"value": tune_steps_total * D / t_tune_max, "unit": "leapfrog-steps*dims/s",
                            "draws": args.num_tune, "seconds": t_tune_max},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         # both denominators by name: `frac` IS frac_moved
+                         # `frac` is the BOUND: t_min / t_kernel <= 1, and moving more bytes cannot raise it
+                         "frac": bm["frac"] if bm.get("frac") is not None else None,
+                         "binding": bm.get("binding"), "waste_ratio": (bm.get("hbm") or {}).get("moved_over_necessary"),
+                         "t_min_ms": bm.get("t_min_ms"), "t_kernel_ms": kern_s * 1e3,
                          "frac_moved": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "frac_sec8d_model": algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                         "frac_definition": "frac = frac_moved = HBM bytes the kernel moved (PMC) / launch time / 8 TB/s (<= 1: a utilisation "
-                                            "of bytes the design chose to move); frac_sec8d_model = 64 B x steps x dims / launch time / 8 TB/s "
+                         "frac_definition": "frac = t_min / t_kernel with t_min = max(necessary HBM bytes / 8 TB/s, necessary f64 VALU instructions / "
+                                            "(1024 SIMDs x 2.4 GHz / 4)) — a bound: <= 1 and not raised by moving more bytes (bound_model has the "
+                                            "enumeration); waste_ratio = HBM bytes moved / necessary; frac_moved = moved bytes (PMC) / launch time / "
+                                            "8 TB/s = achieved / peak (a utilisation); frac_sec8d_model = 64 B x steps x dims / launch time / 8 TB/s "
                                             "(SURVEY 8(d)'s streaming model; exceeds 1 because live points, sigma, mu never leave the CU)",
-                         "bound_model": bound_model(st_all, D, kern_s, traffic) if st_all is not None else None,
+                         "bound_model": bm,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL, "kernel_ms_per_launch": kern_ms, "launches": 1,
                          "frac_of_measured_copy": (achieved / (cal.get("copy_GBps") or HBM_COPY_GBS)) if achieved else None,

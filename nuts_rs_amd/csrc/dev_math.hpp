@@ -619,8 +619,11 @@ struct DevRng {
     uint64_t base;     // stream position of cache word 0 (multiple of 16)
     uint32_t* cache;   // LDS, at least RNG_CACHE_WORDS words
     uint32_t cap;      // valid words in the cache (RNG_CACHE_WORDS after a refill; more while a bulk fill lends its buffer)
+    bool one_wave;     // the block is one wavefront (read once: `blockDim.x` is a load from the dispatch packet, and a refill that asks
+                       // for it again waits for every outstanding memory operation of the wavefront)
 
     NM_DEV void init(const uint32_t* k, uint64_t p, uint32_t* lds) {
+        one_wave = NM_ONE_WAVE_BLOCK;
         key = k;
         pos = p;
         base = p + 16;   // invalid: forces a refill on first use
@@ -629,7 +632,7 @@ struct DevRng {
     }
     NM_DEV bool has(uint64_t nwords) const { return pos >= base && (pos - base) + nwords <= (uint64_t)cap; }
     NM_DEV void refill() {
-        block_sync(NM_ONE_WAVE_BLOCK);
+        block_sync(one_wave);
         base = pos & ~15ull;
         cap = RNG_CACHE_WORDS;
         if (tid() < RNG_CACHE_WORDS / 16) {
@@ -641,7 +644,7 @@ struct DevRng {
             dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
             dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
         }
-        block_sync(NM_ONE_WAVE_BLOCK);
+        block_sync(one_wave);
     }
     NM_DEV uint32_t next_u32() {
         if (!has(1)) refill();

@@ -76,6 +76,12 @@ __host__ __device__ inline int slot_R(int maxdepth, int i) { return num_sslots(m
 // (Computed once by the host into KParams::layout_md: reading both settings fields in ctx_begin changed the register allocation of the
 // 16-wavefront matrix-core kernel enough to break it — the last doubling of trees deeper than 6 stopped after one leaf)
 __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)(s.maxdepth + s.extra_doublings); }
+#ifndef NM_REG_EDGES
+#define NM_REG_EDGES 1            // the main tree's two end points live in registers (0: in the HBM scratch, rounds 1-4; bisecting builds)
+#endif
+#ifndef NM_EDGES_IN_ACC
+#define NM_EDGES_IN_ACC 0
+#endif
 #ifndef NM_FUSED_LEAPFROG
 #define NM_FUSED_LEAPFROG 1        // 0: the leapfrog as three loops over the tile for every density (rounds 1-4; bisecting builds)
 #endif
@@ -88,6 +94,16 @@ __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)
 #ifndef NM_BATCH_IN_TILES
 #define NM_BATCH_IN_TILES 0
 #endif
+// Main-tree end points in registers (round 5).  The tree's left and right ends (z, v, g_z each) were scratch slots in HBM: written after
+// every doubling that is followed by another, read back by every top-level U-turn test (four tiles) and when the trajectory is extended on
+// the other side (three) — 30 of the ~64 tiles of 8 KiB a K2 draw moved, every read a round trip of a microsecond or two under load on the
+// wavefront's critical path.  A block of one wavefront per SIMD owns 512 registers per lane; two live points and two end points are
+// 12 tiles of 32 = 384 — which the register allocator does not manage without spilling to scratch memory (measured: 1088 B per lane), so
+// the end points' (z, v) — what every test reads — are registers and their g_z, read only when the trajectory is extended on the other
+// side, stays in its slot: 10 tiles.  Not for the register-capped tile / cluster builds.
+// Measured (profiles/r05f_*): (16 doubles, 1 wave) K2 2.02e11 -> 2.13e11, (2, 1) K3 +7 %; the register-capped tilings in between lose
+// ((8, 1) at two wavefronts per SIMD: -33 %, (4, 1): -7 %: the end points go to scratch memory) and keep the slots.
+template <int DPL, int W> constexpr bool reg_edges() { return NM_REG_EDGES && NM_TRIM_FIRST && !NM_TILE_MODE && !NM_CLUSTER_MODE && W == 1 && (DPL == 16 || DPL == 2); }
 template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && (!NM_TILE_MODE || NM_BATCH_IN_TILES) && !NM_CLUSTER_MODE; }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
@@ -223,6 +239,38 @@ NM_DEV void store_tile(const Tile<DPL>& t, double* base) {
     for (int m = 0; m < DPL / 2; ++m) p[m * 64 * W] = make_double2(t.a[2 * m], t.a[2 * m + 1]);
 }
 // element index held in register k of this thread
+// Where the end points live.  Plain values: the allocator keeps them in the accumulation registers of the (16, 1) kernel (all 512
+// registers of its SIMD) at ~150 more vector instructions per leapfrog.  Placing them there BY HAND (NM_EDGES_IN_ACC = 1: v_accvgpr_write /
+// read, one per 32 bits, a write per doubling, a read per test) was built and is worse: the 128 accumulation registers it pins are the
+// allocator's spill space, and what no longer fits goes to scratch memory (544 B per lane against 384).
+template <int DPL, bool ACC> struct EdgeTile;
+template <int DPL> struct EdgeTile<DPL, false> {
+    Tile<DPL> t;
+    NM_DEV void put(const Tile<DPL>& s) { t = s; }
+    NM_DEV void get(Tile<DPL>& d) const { d = t; }
+    NM_DEV double2 pair(int m) const { return make_double2(t.a[2 * m], t.a[2 * m + 1]); }
+};
+template <int DPL> struct EdgeTile<DPL, true> {
+    int w[2 * DPL];
+    NM_DEV void put(const Tile<DPL>& s) {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(w[2 * k]) : "v"(__double2loint(s.a[k])));
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(w[2 * k + 1]) : "v"(__double2hiint(s.a[k])));
+        }
+    }
+    NM_DEV double at(int k) const {
+        int lo, hi;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(w[2 * k]));
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(w[2 * k + 1]));
+        return __hiloint2double(hi, lo);
+    }
+    NM_DEV void get(Tile<DPL>& d) const {
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) d.a[k] = at(k);
+    }
+    NM_DEV double2 pair(int m) const { return make_double2(at(2 * m), at(2 * m + 1)); }
+};
 template <int W>
 NM_DEV int elem_index(int k) { return 2 * ((k >> 1) * 64 * W + tid()) + (k & 1); }
 
@@ -241,6 +289,12 @@ typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 // input on the VALU — and then every buffer op taking it as soffset gets wrapped in a waterfall loop (T20), which
 // serialises the loads.  Laundering the value through an empty asm (opaque, "divergent" to the analysis) keeps the
 // readfirstlane, so the result is a real SGPR; the compiler still sees the builtin and pads its hazards.
+// a wave-uniform value the compiler must keep in a register (not re-load from where it came: kernel arguments are "rematerialisable")
+NM_DEV double pin_scalar(double x) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __hiloint2double(hi, lo);
+}
 NM_DEV int force_sgpr(int x) {
     asm volatile("" : "+v"(x));
     return __builtin_amdgcn_readfirstlane(x);
@@ -1253,8 +1307,11 @@ struct AcceptCollector {
 
 // is_turning partial sums (reference transformed_hamiltonian.rs:617-638, scalar_prods3 util.rs:221-347):
 // s = (z_end + 0) - z_start; t1 += s*v_start; t2 += s*v_end
+// (The reference's `+ 0` — scalar_prods3's third operand, the zeros vector — turns a -0.0 of z_end into +0.0, which can change the
+// SIGN of a zero difference and nothing else; a zero term leaves a non-zero sum alone and a sum of zeros compares false with zero
+// whatever its sign.  The sums are only ever compared with zero, so the addition is not executed: one instruction in four.)
 NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, double& t2) {
-    double s = (ze + 0.0) - zs;
+    double s = ze - zs;
     t1 = __builtin_fma(s, vs, t1);
     t2 = __builtin_fma(s, ve, t2);
 }
@@ -1263,7 +1320,7 @@ NM_DEV void turn_acc(double zs, double vs, double ze, double ve, double& t1, dou
 // in LDS (fill_standard_normals_bulk) and read back in tile order; STAGE_V (HBM) keeps a copy because the initial
 // point's velocity is the v of main-tree edge id 0.
 template <int DPL, int W, class Dens>
-NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
+NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v, bool stage = true) {
 #if NM_LDS_L1
     // at most 17 passes (1088 cells) per chunk: wider tilings take several chunks, which keeps the refresh's register
     // footprint (4 values per pass and lane in flight) the same for every kernel.  A vector that fits one 64-lane
@@ -1300,7 +1357,7 @@ NM_DEV void sample_velocity(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
         v.a[2 * m] = C.elem(2 * m) < C.dim ? 1.0 * q.x : 0.0;
         v.a[2 * m + 1] = C.elem(2 * m + 1) < C.dim ? 1.0 * q.y : 0.0;
     }
-    C.storeS(v, STAGE_V);
+    if (stage) C.storeS(v, STAGE_V);
 #endif
 #else
     fill_standard_normals(C.rng, C.sslot(STAGE_V), C.dim, C.zig);
@@ -1326,11 +1383,11 @@ NM_DEV double kinetic(const Tile<DPL>& v, Reducer<W>& R) {
 // microcanonical kind first puts the fresh momentum on the unit sphere (and re-stages it: the initial point's v is an
 // edge operand) and starts its accumulated kinetic-energy change at 0
 template <int DPL, int W, class Dens>
-NM_DEV double initial_kinetic(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v) {
+NM_DEV double initial_kinetic(ChainCtx<DPL, W, Dens>& C, Tile<DPL>& v, bool stage = true) {
     if constexpr (kin_trait<Dens>::value) {
         if (C.sc.kin == NM_TRAJ_MICROCANONICAL) {
             normalize_tile(v, C.red);
-            C.storeS(v, STAGE_V);
+            if (stage) C.storeS(v, STAGE_V);
             return 0.0;
         }
     }
@@ -2000,9 +2057,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     ChainScalars& sc = C.sc;
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
+    constexpr bool RE = reg_edges<DPL, W>();
+    [[maybe_unused]] EdgeTile<DPL, NM_EDGES_IN_ACC != 0> MLz, MLv, MRz, MRv;   // RE: (z, v) of the main tree's left / right end point; their g_z (read only when the
+                                                          // trajectory is extended on the other side) stays in the scratch slot
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
     NM_MARK(C, 0)
-    sample_velocity(C, E.v);
+    sample_velocity(C, E.v, !RE);
     NM_MARK(C, 1)
     if (sc.mm_id != sc.transform_id) {                           // lazy re-whitening (inv_transform_normalize, diagonal.rs:210-221)
         Tile<DPL> x, gx, isig, sig, mu;
@@ -2032,8 +2092,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         C.loadP(E.g, P_GZ);
     }
     const double logdet = sc.logdet;
-    const double ke_init = initial_kinetic(C, E.v);
+    const double ke_init = initial_kinetic(C, E.v, !RE);
     E.ke = ke_init;
+    if constexpr (RE) { MLz.put(E.z); MLv.put(E.v); MRz.put(E.z); MRv.put(E.v); }      // both ends = the initial point
     const double e0 = ke_init - (sc.logp + logdet);
     R.e0 = e0;
     col.register_init(e0);
@@ -2062,6 +2123,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         uint64_t xd = ce > mindepth ? ce : mindepth;
         maxdepth = xd < s.maxdepth ? xd : s.maxdepth;
     }
+    // (read once per draw into a register: as `s.max_energy_error` the compiler re-loaded it from the kernel's argument block after
+    // every leapfrog — an s_load and its full ~200-cycle latency, 50 instruction slots of a lone wavefront, on every leaf)
+    const double max_energy_error = pin_scalar(s.max_energy_error);
     R.diverging = false; R.reached_maxdepth = false; R.has_divergence_energy_error = false; R.has_div_end = true;
     R.divergence_energy_error = 0.; R.div_start_idx = 0;
     const bool want_div = C.P.out_div_start || C.P.out_div_start_grad || C.P.out_div_end;
@@ -2108,7 +2172,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if (want_div) C.storeS((START).z, slot_F(0));                                             \
                 stop = STOP_DIVERGING;                                                                    \
             } else                                                                                        \
-            if (bad_energy(C, err_, s.max_energy_error)) {                                                \
+            if (bad_energy(C, err_, max_energy_error)) {                                                  \
                 col.register_divergent();                                                                 \
                 R.diverging = true; R.has_divergence_energy_error = true; R.divergence_energy_error = err_; \
                 R.div_start_idx = (PT).idx - (int64_t)sign;                                               \
@@ -2154,8 +2218,13 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     auto rows = [&](auto far_is_left) __attribute__((always_inline)) {
 #pragma unroll
                         for (int m = 0; m < DPL / 2; ++m) {
-                            double2 lz = C.ld2(mlz.r, mlz.so, m), lv = C.ld2(mlv.r, mlv.so, m);
-                            double2 rz = C.ld2(mrz.r, mrz.so, m), rv = C.ld2(mrv.r, mrv.so, m);
+                            double2 lz, lv, rz, rv;
+                            if constexpr (RE) {
+                                lz = MLz.pair(m); lv = MLv.pair(m); rz = MRz.pair(m); rv = MRv.pair(m);
+                            } else {
+                                lz = C.ld2(mlz.r, mlz.so, m); lv = C.ld2(mlv.r, mlv.so, m);
+                                rz = C.ld2(mrz.r, mrz.so, m); rv = C.ld2(mrv.r, mrv.so, m);
+                            }
                             double2 oz, ov;
                             if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
                             else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
@@ -2187,7 +2256,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         } else {
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
                 const int es = fwd ? right_slot : left_slot;
+                if constexpr (RE) {
+                    C.loadRef(O.g, C.edge_g(es));
+                    if (fwd) { MRz.get(O.z); MRv.get(O.v); } else { MLz.get(O.z); MLv.get(O.v); }
+                } else {
                 C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es)); C.loadRef(O.g, C.edge_g(es));
+                }
                 if constexpr (kin_trait<Dens>::value) O.ke = fwd ? right_ke : left_ke;
             }
             for (uint64_t n = 0; n < nleaf; n += 2) {
@@ -2541,7 +2615,12 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             int ns = fwd ? right_slot : left_slot;
             const int other_side = fwd ? left_slot : right_slot;
             if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
+            if constexpr (RE) {
+                C.storeRef(O.g, C.edge_g(ns));
+                if (fwd) { MRz.put(O.z); MRv.put(O.v); } else { MLz.put(O.z); MLv.put(O.v); }
+            } else {
             C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); C.storeRef(O.g, C.edge_g(ns));
+            }
 #ifdef NM_EXTRA_TRAFFIC   // development: is the kernel bound by the bytes it moves? (two more tile stores per doubling)
             C.storeS(O.g, slot_F(MD)); C.storeS(O.z, slot_F(MD) + 1);
 #endif
@@ -3155,7 +3234,7 @@ NM_DEV ClusterLink cluster_start(const KParams& P, double* red_lds, unsigned cl_
 #endif
 
 template <int DPL, int W, class Dens>
-__global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) __attribute__((amdgpu_flat_work_group_size(64 * W, 64 * W))) void nuts_draw_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
 #if NM_CLUSTER_MODE
@@ -3221,7 +3300,7 @@ __global__ __launch_bounds__(64 * W, (draw_min_waves<DPL, W>())) void nuts_draw_
 
 // NutsChain::set_position (reference src/chain.rs:137-149 -> GlobalStrategy::init adapt_strategy.rs:100-119)
 template <int DPL, int W, class Dens>
-__global__ __launch_bounds__(64 * W) void nuts_init_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_flat_work_group_size(64 * W, 64 * W))) void nuts_init_kernel(const KParams P) {
     __shared__ BlockShared<DPL, W, Dens> sh;
     dm_init_lds();
 #if NM_CLUSTER_MODE
