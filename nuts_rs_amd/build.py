@@ -74,7 +74,52 @@ def needs_build():
     return any(_unit_stale(u) for u in UNITS) or _newer(LIB, [_obj(u) for u in UNITS])
 
 
-def build(force=False, verbose=False, extra_flags=()):
+class StoreHazardError(RuntimeError):
+    """A translation unit's device assembly has a buffer store whose data registers are rewritten inside the hazard window."""
+
+
+def _scan_store_hazards(asm_path, what):
+    """tools/check_store_hazard.py's rule, both modes, on one unit's device assembly: the build fails on an unguarded
+    instance instead of leaving it to a parity suite that does not travel with a user's module build.  The rule lives in ONE place: the
+    tool is executed, not re-implemented (it ships in the repo next to this package; a wheel without tools/ skips the scan and says so)."""
+    tool = os.path.join(HERE, "..", "tools", "check_store_hazard.py")
+    if not os.path.exists(tool):
+        print(f"nuts_rs_amd.build: tools/check_store_hazard.py not found, {what} NOT scanned for store-data hazards", file=sys.stderr)
+        return
+    for mode in ([], ["--mubuf64"]):
+        r = subprocess.run([sys.executable, tool, asm_path] + mode, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise StoreHazardError(f"{what}: unguarded store-data hazard(s) in the generated assembly (python tools/check_store_hazard.py "
+                                   f"{' '.join(mode)}; guard the store as buf_store2 / LCtx::bst do, DESIGN §15):\n" + r.stdout[-3000:])
+    # DESIGN §22's rule as a scan: no out-of-line call inside a kernel that carries several chains per wavefront
+    tool2 = os.path.join(HERE, "..", "tools", "check_divergent_calls.py")
+    if os.path.exists(tool2):
+        r = subprocess.run([sys.executable, tool2, asm_path], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise StoreHazardError(f"{what}: an out-of-line call inside a several-chains-per-wavefront kernel (python tools/check_divergent_calls.py; "
+                                   "force-inline the callee, DESIGN §22):\n" + r.stdout[-3000:])
+
+
+def _compile_scanned(hipcc, flags, src, out, what, link=False):
+    """Compile `src` (one hipcc run: -save-temps keeps the device assembly the object is assembled from), scan it, drop the temporaries."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="nm_tmp_", dir=os.path.dirname(out) or ".")
+    try:
+        # (-save-temps=obj writes next to the OUTPUT: compile into the temporary directory, then move the product out)
+        prod = os.path.join(tmp, os.path.basename(out))
+        subprocess.check_call([hipcc] + flags + ["-save-temps=obj"] + ([] if link else ["-c"]) + [src, "-o", prod])
+        asms = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".s") and "amdgcn" in f]
+        if not asms and not src.endswith(".cpp"):
+            raise RuntimeError(f"{what}: no device assembly among the compiler's temporaries (-save-temps=obj)")
+        for a in asms:
+            _scan_store_hazards(a, what)
+        os.replace(prod, out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def build(force=False, verbose=False, extra_flags=(), scan=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -85,10 +130,13 @@ def build(force=False, verbose=False, extra_flags=()):
         src, obj = _src(u), _obj(u)
         if force or _unit_stale(u):
             host_only = VARIANT_FLAGS[u.partition("@")[2]] if u.startswith("lowrank_host.cpp") else []
-            cmd = [hipcc] + FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", src, "-o", obj]
+            flags = FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
             if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+                print(" ".join([hipcc] + flags + ["-c", src, "-o", obj]), file=sys.stderr)
+            if scan and src.endswith(".hip"):
+                _compile_scanned(hipcc, flags, src, obj, os.path.basename(src))
+            else:
+                subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
@@ -130,16 +178,20 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 16:
             raise ValueError("lane forms exist for dim <= 16")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
+    if group_struct or lane_struct:
+        # a user functor that calls nm::dexp / dlog / dlog1p from a several-chains-per-wavefront kernel must not reach them through a call
+        # (tools/check_divergent_calls.py rejects it): the special functions are inlined in such a module
+        extra_flags = list(extra_flags) + ["-DNM_DETMATH_INLINE=1"]
     vbits = (1 if "low_rank" in variants else 0) | (2 if "kinetic" in variants else 0)
     if vbits:
         if dim > 4096:
             raise ValueError("the low-rank / kinetic variants exist for dim <= 4096")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_VARIANTS={vbits}"]
-    cmd = [hipcc] + FLAGS + list(extra_flags) + [
+    flags = FLAGS + list(extra_flags) + [
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
-        f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"),
-        os.path.join(CSRC, "density_module.hip"), "-o", out]
-    subprocess.check_call(cmd)
+        f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
+    # (the user's code is compiled into the same register-capped kernels: its assembly goes through the same scan as the engine's own)
+    _compile_scanned(hipcc, flags, os.path.join(CSRC, "density_module.hip"), os.path.abspath(out), f"density module {struct_name}", link=True)
     return out
 
 

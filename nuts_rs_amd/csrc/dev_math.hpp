@@ -321,7 +321,7 @@ static __host__ __device__ __forceinline__ int dm_index(int j) {
 }
 
 template <bool U>
-static __host__ __device__ __forceinline__ double dexp_impl(double x) {
+static __host__ __device__ __forceinline__ double dexp_branchy(double x) {
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return __builtin_inf();
     if (x < -7.45133219101941108420e+02) return 0.0;
@@ -339,6 +339,12 @@ static __host__ __device__ __forceinline__ double dexp_impl(double x) {
     const double sum = __builtin_fma(th, p, DM_TAB(DM_T_LO, DM_OFF_T_LO, j));
     return __builtin_ldexp(th + sum, k);
 }
+// (round 5) dexp_impl / dlog_impl / dlog1p_impl ARE the branch-free forms below (exp_sl, log_sl, log1p_sl: same operation sequences,
+// same results on every double — tests/cpp/merge_math_check.hip compares them with the *_branchy originals above); the template
+// parameter (a wave-uniform argument: scalar table loads) is accepted and ignored
+template <bool U> static __host__ __device__ __forceinline__ double dexp_impl(double x);
+template <bool U> static __host__ __device__ __forceinline__ double dlog_impl(double x);
+template <bool U> static __host__ __device__ __forceinline__ double dlog1p_impl(double x);
 #ifndef NM_DETMATH_INLINE
 #define NM_DETMATH_INLINE 0      // 1: exp / ln / ln_1p inlined at every call site (tuning builds; larger code, no call-boundary waits)
 #endif
@@ -347,7 +353,7 @@ static __host__ __device__ __forceinline__ double dexp_impl(double x) {
 #else
 #define NM_DM_CALL __noinline__
 #endif
-static __host__ __device__ NM_DM_CALL double dexp(double x) { return dexp_impl<false>(x); }
+static __host__ __device__ NM_DM_CALL double dexp(double x);
 
 // ln(x) + c / x for finite x > 0 (c = 0: plain ln; ln_1p passes the rounding error of 1 + t)
 template <bool U>
@@ -384,7 +390,7 @@ static __host__ __device__ __forceinline__ double dlog_core(double x, double c) 
 }
 
 template <bool U>
-static __host__ __device__ __forceinline__ double dlog_impl(double x) {
+static __host__ __device__ __forceinline__ double dlog_branchy(double x) {
     if (x != x) return x;
     if (x < 0.0) return __builtin_nan("");
     if (x == 0.0) return -__builtin_inf();
@@ -393,14 +399,14 @@ static __host__ __device__ __forceinline__ double dlog_impl(double x) {
 }
 // ln(1 + x): ln of the rounded sum plus the first-order term of its rounding error
 template <bool U>
-static __host__ __device__ __forceinline__ double dlog1p_impl(double x) {
+static __host__ __device__ __forceinline__ double dlog1p_branchy(double x) {
     const double u = 1.0 + x;
     if (u == 1.0) return x;
-    if (!(u == u) || __builtin_isinf(u) || !(u > 0.0)) return dlog_impl<U>(u);
+    if (!(u == u) || __builtin_isinf(u) || !(u > 0.0)) return dlog_branchy<U>(u);
     return dlog_core<U>(u, x - (u - 1.0));
 }
-static __host__ __device__ NM_DM_CALL double dlog(double x) { return dlog_impl<false>(x); }
-static __host__ __device__ NM_DM_CALL double dlog1p(double x) { return dlog1p_impl<false>(x); }
+static __host__ __device__ NM_DM_CALL double dlog(double x);
+static __host__ __device__ NM_DM_CALL double dlog1p(double x);
 // per-lane logaddexp (reference src/math/util.rs:6-19)
 NM_DEV double logaddexp_lane(double a, double b) {
     if (a == b) return a + dlog(2.0);
@@ -491,6 +497,72 @@ NM_HD double log1p_unit(double x) {
     res = u == 1.0 ? x : res;
     return u != u ? u : res;
 }
+// ln(x) + c / x on every double, ln(1 + x) on every double: dlog_impl / dlog1p_impl without a branch (the sub-normal rescaling and
+// the special cases are selects).  Same operation sequence on the main path, same results everywhere (tests/cpp/merge_math_check.hip).
+NM_HD double log_core_sl(double x, double c) {
+    uint64_t u = d2u(x);
+    const bool sub = u < 0x0010000000000000ull;
+    const double xs = x * 1.80143985094819840000e+16;           // 2^54
+    u = sub ? d2u(xs) : u;
+    int k = sub ? -54 : 0;
+    const uint64_t mant = u & 0x000fffffffffffffull;
+    const int up = mant >= 0x6a09e667f3bcdull;
+    k += (int)(u >> 52) - 1023 + up;
+    const double m = u2d(mant | ((uint64_t)(1023 - up) << 52));
+    const int j = (int)__builtin_rint(m * 64.0) - DM_LOG_J0;
+    const double rj = DM_TAB(DM_R, DM_OFF_R, j);
+    const double z = __builtin_fma(m, rj, -1.0);
+    const double dk = (double)k;
+    const double z2 = z * z, z4 = z2 * z2;
+    const double p01 = __builtin_fma(z, DM_LOG_C3, DM_LOG_C2), p23 = __builtin_fma(z, DM_LOG_C5, DM_LOG_C4);
+    const double p45 = __builtin_fma(z, DM_LOG_C7, DM_LOG_C6), p67 = __builtin_fma(z, DM_LOG_C9, DM_LOG_C8);
+    const double q0 = __builtin_fma(z2, p23, p01), q1 = __builtin_fma(z2, p67, p45);
+    const double Q = __builtin_fma(z4, __builtin_fma(z4, DM_LOG_C10, q1), q0);
+    const int kc = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
+    const double corr = (c * rj) * u2d((uint64_t)(1023 - kc) << 52);
+    const double lo = __builtin_fma(dk, DM_LN2_LO, DM_TAB(DM_F_LO, DM_OFF_F_LO, j)) + corr;
+    const double t = __builtin_fma(z2, Q, lo);
+    const double hk = dk * DM_LN2_HI;
+    const double fh = DM_TAB(DM_F_HI, DM_OFF_F_HI, j);
+    const double s1 = hk + fh, e1 = (hk - s1) + fh;
+    const double s2 = s1 + z, e2 = (s1 - s2) + z;
+    return s2 + ((e1 + e2) + t);
+}
+NM_HD double log_sl(double x) {
+    double res = log_core_sl(x, 0.0);
+    res = __builtin_isinf(x) ? x : res;                         // (+inf; -inf is negative: NaN below)
+    res = x == 0.0 ? -__builtin_inf() : res;
+    res = x < 0.0 ? __builtin_nan("") : res;
+    return x != x ? x : res;
+}
+NM_HD double log1p_sl(double x) {
+    const double u = 1.0 + x;
+    double res = log_core_sl(u, x - (u - 1.0));
+    // dlog1p_impl: u == 1 -> x; u NaN, infinite or not > 0 -> dlog_impl(u)
+    res = __builtin_isinf(u) ? u : res;
+    res = u == 0.0 ? -__builtin_inf() : res;
+    res = u < 0.0 ? __builtin_nan("") : res;
+    res = u != u ? u : res;
+    return u == 1.0 ? x : res;
+}
+#ifndef NM_BRANCH_FREE_MATH
+#define NM_BRANCH_FREE_MATH 1     // 0: the general-purpose forms of rounds 1-4 behind the same names (bisecting builds)
+#endif
+#if NM_BRANCH_FREE_MATH
+template <bool U> static __host__ __device__ __forceinline__ double dexp_impl(double x) { return exp_sl(x); }
+template <bool U> static __host__ __device__ __forceinline__ double dlog_impl(double x) { return log_sl(x); }
+template <bool U> static __host__ __device__ __forceinline__ double dlog1p_impl(double x) { return log1p_sl(x); }
+static __host__ __device__ NM_DM_CALL double dexp(double x) { return exp_sl(x); }
+static __host__ __device__ NM_DM_CALL double dlog(double x) { return log_sl(x); }
+static __host__ __device__ NM_DM_CALL double dlog1p(double x) { return log1p_sl(x); }
+#else
+template <bool U> static __host__ __device__ __forceinline__ double dexp_impl(double x) { return dexp_branchy<U>(x); }
+template <bool U> static __host__ __device__ __forceinline__ double dlog_impl(double x) { return dlog_branchy<U>(x); }
+template <bool U> static __host__ __device__ __forceinline__ double dlog1p_impl(double x) { return dlog1p_branchy<U>(x); }
+static __host__ __device__ NM_DM_CALL double dexp(double x) { return dexp_branchy<false>(x); }
+static __host__ __device__ NM_DM_CALL double dlog(double x) { return dlog_branchy<false>(x); }
+static __host__ __device__ NM_DM_CALL double dlog1p(double x) { return dlog1p_branchy<false>(x); }
+#endif
 // merge_into's scalars (reference src/nuts.rs:172-207).  (w_lo, w_hi): the NEXT u64 of the chain's stream, read but not consumed by
 // the caller.  flags: bit 0 take other's draw, bit 1 the u64 was consumed (random_bool drew), bit 2 fatal (p outside [0, 1]: the reference panics)
 struct MergeOut { double total; uint32_t flags; };

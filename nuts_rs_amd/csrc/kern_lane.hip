@@ -1,4 +1,11 @@
 // kern_lane.hip — the one-chain-per-lane draw kernels (nuts_lane.hpp) for the built-in densities with dim <= 16.
+// The one-chain-per-lane kernels keep the general-purpose exp / ln / ln_1p of rounds 1-4 (NM_BRANCH_FREE_MATH = 0).  Measured in round 5
+// with the branch-free forms the other kernel families use: K4 on 65536 chains 4.90e9 -> 3.88e9 leapfrogs/s (64 unrelated chains per wavefront
+// rarely take a special-case branch, and these kernels sit at their register cap: the straight-line forms' constants spill), and ONE parity
+// case of the 8-pair kernel (microcanonical, funnel dim 11: profiles/r05h_*) stopped matching the oracle at draw 87 although the two forms
+// agree on every operand on the device (tools/probes/sl_math_device_check.hip) — a code-generation-sensitive failure of the kind DESIGN §22
+// describes, not root-caused; the form that has passed every suite since round 3 stays.
+#define NM_BRANCH_FREE_MATH 0
 #include <hip/hip_runtime.h>
 #include "nuts_lane.hpp"
 namespace nm {

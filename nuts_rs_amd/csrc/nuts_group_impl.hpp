@@ -259,14 +259,20 @@ struct GRng {
         g_refill_blocks(key, base >> 4, cache);
         asm volatile("" ::: "memory");
     }
+    // Make sure the next n words are in the cache.  When ANY chain of the wavefront (any that is executing this) has run out, EVERY one
+    // re-bases its window at its own stream position (round 5): a refill costs the wavefront the same ~420 instructions however many of
+    // its chains take part (the others' lanes would sit masked), the window is only a view of the stream (same words, same results), and
+    // chains that refill together stay in step — ~0.3 refills per draw and wavefront instead of ~2.3 on K4.  The test is a ballot and a
+    // scalar branch instead of an exec-masked region.
+    NM_DEV void need(uint64_t n) { if (__ballot(!has(n)) != 0ull) refill(); }
     NM_DEV uint32_t next_u32() {
-        if (!has(1)) refill();
+        need(1);
         const uint32_t w = cache[pos - base];
         pos += 1;
         return w;
     }
     NM_DEV uint64_t next_u64() {
-        if (!has(2)) refill();
+        need(2);
         const uint64_t lo = cache[pos - base], hi = cache[pos - base + 1];
         pos += 2;
         return (hi << 32) | lo;
@@ -306,7 +312,7 @@ NM_DEV void g_fill_normals(GRng& rng, double* samp, int count, ZigTables T) {
     const int l = gl();
     int i = 0;
     while (i < count) {
-        if (!rng.has(2 * GS)) rng.refill();
+        rng.need(2 * GS);
         const int nvalid = (count - i) < GS ? (count - i) : GS;
         const uint32_t off = (uint32_t)(rng.pos - rng.base) + 2u * (uint32_t)l;
         const uint64_t bits = ((uint64_t)rng.cache[off + 1] << 32) | rng.cache[off];
@@ -512,22 +518,22 @@ NM_DEV void g_leapfrog(GCtx<GD>& C, const GPt& s, GPt& o, double epsilon) {
 NM_DEV bool g_turning_regs(const GPt& a, const GPt& b, bool fwd) {
     double s1 = 0., s2 = 0.;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (fwd) turn_acc(a.z[k], a.v[k], b.z[k], b.v[k], s1, s2);
-        else turn_acc(b.z[k], b.v[k], a.z[k], a.v[k], s1, s2);
-    }
-    gsum2(s1, s2);
-    return (s1 < 0.) | (s2 < 0.);
+    for (int k = 0; k < 2; ++k) turn_acc(a.z[k], a.v[k], b.z[k], b.v[k], s1, s2);     // generation order; the direction flips the comparison
+    gsum2(s1, s2);                                                                     // (nuts_kernels.hpp turning_regs: the reversed pair is the same sums negated)
+    return turn_sign(fwd, s1) | turn_sign(fwd, s2);
 }
 
 template <class GD>
 NM_DEV bool g_merge_weights(GCtx<GD>& C, double a_log_size, double b_log_size, bool is_main, double& total, bool& fatal) {
-    total = logaddexp_lane(a_log_size, b_log_size);
-    const double self_log_size = is_main ? a_log_size : total;
-    if (b_log_size >= self_log_size) return true;
-    const int b = C.rng.random_bool(dexp(b_log_size - self_log_size));
-    if (b < 0) { fatal = true; return false; }
-    return b == 1;
+    // merge_into's arithmetic as one branch-free sequence (dev_math.hpp merge_math_impl; inlined: no out-of-line call under control flow that
+    // is not uniform over the wavefront).  With several chains per wavefront every branch of the general routines was taken by some chain.
+    C.rng.need(2);
+    const uint32_t off_ = (uint32_t)(C.rng.pos - C.rng.base);
+    const MergeOut mo = merge_math_impl(a_log_size, b_log_size, is_main ? 1u : 0u, C.rng.cache[off_], C.rng.cache[off_ + 1]);
+    total = mo.total;
+    C.rng.pos += (uint64_t)(mo.flags & 2u);
+    if (mo.flags & 4u) fatal = true;
+    return (mo.flags & 1u) != 0;
 }
 
 template <class GD>
@@ -680,18 +686,12 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
                         double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            if (fwd) {
-                                turn_acc(az[j], av[j], O.z[j], O.v[j], s1, s2);
-                                turn_acc(lz[j], lv[j], O.z[j], O.v[j], s3, s4);
-                                turn_acc(az[j], av[j], bz[j], bv[j], s5, s6);
-                            } else {
-                                turn_acc(O.z[j], O.v[j], az[j], av[j], s1, s2);
-                                turn_acc(O.z[j], O.v[j], lz[j], lv[j], s3, s4);
-                                turn_acc(bz[j], bv[j], az[j], av[j], s5, s6);
-                            }
+                            turn_acc(az[j], av[j], O.z[j], O.v[j], s1, s2);
+                            turn_acc(lz[j], lv[j], O.z[j], O.v[j], s3, s4);
+                            turn_acc(az[j], av[j], bz[j], bv[j], s5, s6);
                         }
                         gsum2(s1, s2); gsum2(s3, s4); gsum2(s5, s6);
-                        if ((s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.)) turn_bits |= 1u << k;
+                        if (turn_any6(fwd, s1, s2, s3, s4, s5, s6)) turn_bits |= 1u << k;
                     }
                 }
                 {
@@ -755,18 +755,13 @@ NM_DEV uint64_t g_transition(GCtx<GD>& C, GAccept& col, DrawResult& R, double (&
                 double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (fwd) {     // (tree.left, other.right) (tree.right, other.right) (tree.left, other.left); other.right = O
-                        turn_acc(lz[j], lv[j], O.z[j], O.v[j], s1, s2);
-                        turn_acc(rz[j], rv[j], O.z[j], O.v[j], s3, s4);
-                        turn_acc(lz[j], lv[j], oz[j], ov[j], s5, s6);
-                    } else {       // (other.left, tree.right) (other.right, tree.right) (other.left, tree.left); other.left = O
-                        turn_acc(O.z[j], O.v[j], rz[j], rv[j], s1, s2);
-                        turn_acc(oz[j], ov[j], rz[j], rv[j], s3, s4);
-                        turn_acc(O.z[j], O.v[j], lz[j], lv[j], s5, s6);
-                    }
+                    // generation order (nuts_kernels.hpp top_level_turning): (left, O) (right, O) (X, first leaf), X = the tree's end FAR from `other`
+                    turn_acc(lz[j], lv[j], O.z[j], O.v[j], s1, s2);
+                    turn_acc(rz[j], rv[j], O.z[j], O.v[j], s3, s4);
+                    turn_acc(fwd ? lz[j] : rz[j], fwd ? lv[j] : rv[j], oz[j], ov[j], s5, s6);
                 }
                 gsum2(s1, s2); gsum2(s3, s4); gsum2(s5, s6);
-                turning = (s1 < 0.) | (s2 < 0.) | (s3 < 0.) | (s4 < 0.) | (s5 < 0.) | (s6 < 0.);
+                turning = turn_any6(fwd, s1, s2, s3, s4, s5, s6);
             }
         }
         double total;

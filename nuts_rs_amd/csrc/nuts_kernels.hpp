@@ -103,7 +103,7 @@ __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)
 // side, stays in its slot: 10 tiles.  Not for the register-capped tile / cluster builds.
 // Measured (profiles/r05f_*): (16 doubles, 1 wave) K2 2.02e11 -> 2.13e11, (2, 1) K3 +7 %; the register-capped tilings in between lose
 // ((8, 1) at two wavefronts per SIMD: -33 %, (4, 1): -7 %: the end points go to scratch memory) and keep the slots.
-template <int DPL, int W> constexpr bool reg_edges() { return NM_REG_EDGES && NM_TRIM_FIRST && !NM_TILE_MODE && !NM_CLUSTER_MODE && W == 1 && (DPL == 16 || DPL == 2); }
+template <int DPL, int W> constexpr bool reg_edges() { return bool(NM_REG_EDGES) & bool(NM_TRIM_FIRST) & !bool(NM_TILE_MODE) & !bool(NM_CLUSTER_MODE) & (W == 1) & (DPL == 16 || DPL == 2); }
 template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && (!NM_TILE_MODE || NM_BATCH_IN_TILES) && !NM_CLUSTER_MODE; }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
@@ -341,7 +341,9 @@ NM_DEV void buf_store2_aux(rsrc_t r, int voff, int soff, double a, double b) {
     q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a);
     q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
     __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, AUX);
+#ifndef NM_X_NO_STORE_GUARD            // (defined only by tests/test_build_guards.py: the build must REJECT the unguarded form)
     asm volatile("s_nop 1" ::"v"(q));     // the store-data hazard above
+#endif
 }
 NM_DEV void buf_store2(rsrc_t r, int voff, int soff, double a, double b) {
     v4u q;
@@ -2258,7 +2260,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 const int es = fwd ? right_slot : left_slot;
                 if constexpr (RE) {
                     C.loadRef(O.g, C.edge_g(es));
-                    if (fwd) { MRz.get(O.z); MRv.get(O.v); } else { MLz.get(O.z); MLv.get(O.v); }
+                    // (a real branch: as selects the choice costs a v_cndmask per 32 bits of both tiles; the empty asm keeps the arms apart)
+                    if (fwd) { asm volatile("; reload: right end"); MRz.get(O.z); MRv.get(O.v); } else { asm volatile("; reload: left end"); MLz.get(O.z); MLv.get(O.v); }
                 } else {
                 C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es)); C.loadRef(O.g, C.edge_g(es));
                 }
@@ -2617,7 +2620,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
             if constexpr (RE) {
                 C.storeRef(O.g, C.edge_g(ns));
-                if (fwd) { MRz.put(O.z); MRv.put(O.v); } else { MLz.put(O.z); MLv.put(O.v); }
+                if (fwd) { asm volatile("; new right end"); MRz.put(O.z); MRv.put(O.v); } else { asm volatile("; new left end"); MLz.put(O.z); MLv.put(O.v); }
             } else {
             C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); C.storeRef(O.g, C.edge_g(ns));
             }
