@@ -577,6 +577,8 @@ def main_k4(args, N, torch, dist, rank, world, device_index, red_dev, barrier):
         n_updates = len(pooled.pooled_warmup(batch, args.num_tune, dist=dist, collective_device=None if args.dist_backend == "nccl" else "cpu"))
     else:
         batch.draw_device(args.num_tune)
+    t_tune_local = time.perf_counter() - t0              # this rank's own warm-up (before the barrier: the first 8-GPU run is diagnosable per rank)
+    tune_kernel_ms_local = float(batch.counters()["kernel_ms"])
     barrier()
     t_tune = time.perf_counter() - t0
     if args.warmup:
@@ -591,15 +593,24 @@ def main_k4(args, N, torch, dist, rank, world, device_index, red_dev, barrier):
         t0 = time.perf_counter()
         batch.draw_device(args.steps, d_pos.data_ptr(), d_st.data_ptr(), sync=False)
         batch.synchronize()
+        el_local = time.perf_counter() - t0
         barrier()
         el = time.perf_counter() - t0
         steps_local = float(batch.counters()["total_leapfrogs"])
+        last_local = (el_local, float(batch.counters()["kernel_ms"]), steps_local)
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sv = torch.tensor([steps_local], dtype=torch.float64, device=red_dev); dist.all_reduce(sv, op=dist.ReduceOp.SUM)
             reps.append((float(t.item()), float(sv.item())))
         else:
             reps.append((el, steps_local))
+    # per-rank seconds: every rank's own warm-up and sampling times, gathered on rank 0
+    mine = [float(rank), t_tune_local, tune_kernel_ms_local * 1e-3, last_local[0], last_local[1] * 1e-3, last_local[2]]
+    per_rank = [mine]
+    if dist is not None:
+        g = [torch.zeros(len(mine), dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor(mine, dtype=torch.float64, device=red_dev))
+        per_rank = [[float(v) for v in t.tolist()] for t in g]
     if rank == 0:
         rates = [sv * D / el for el, sv in reps]
         mid = int(np.argsort(rates)[len(rates) // 2])
@@ -616,6 +627,11 @@ def main_k4(args, N, torch, dist, rank, world, device_index, red_dev, barrier):
             "leapfrogs_per_s": sv / el, "leapfrogs_per_draw": sv / (args.steps * total),
             "repeats": {"n": len(reps), "reported": "median", "values": rates},
             "adaptation": {"draws": args.num_tune, "seconds": t_tune},
+            "per_rank": [{"rank": int(r[0]), "warmup_s": r[1], "warmup_kernel_s": r[2], "sampling_s_last_repeat": r[3], "sampling_kernel_s_last_repeat": r[4],
+                          "leapfrogs_last_repeat": r[5]} for r in per_rank],
+            "expected": {"note": "one MI355X measured alone (profiles/r05*): the whole 65536-chain job on ONE GPU ~5e9 leapfrogs/s (one chain per lane); "
+                                 "a shard of 8192 chains ~2e9 leapfrogs/s (1024 wavefronts of 8 chains: one per SIMD, latency-bound) => 8 GPUs ~1.6e10 = ~3x one GPU "
+                                 "on this STRONG-scaling config; K2 (weak scaling, no collective) scales with the GPU count"},
             "roofline": None, "cpu_baseline": None}))
     batch.close()
     if dist is not None:

@@ -142,7 +142,26 @@ def build(force=False, verbose=False, extra_flags=(), scan=True):
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_unit, UNITS))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    selftest_if_gpu()
     return LIB
+
+
+def selftest_if_gpu():
+    """The known-answer self-test (nuts_rs_amd/selftest.py) on the library just built, when this machine has a GPU — in a fresh process (the
+    library of the building process may already be mapped).  Without a GPU (the cross-compiling build box) nothing runs: the driver's
+    smoke() and the first density-module engine run it on the GPU box."""
+    probe = ("import sys, torch\n"
+             "sys.exit(0 if torch.cuda.is_available() else 3)\n")
+    try:
+        if subprocess.run([sys.executable, "-c", probe], capture_output=True, timeout=300).returncode != 0:
+            return False
+    except Exception:
+        return False
+    r = subprocess.run([sys.executable, "-c", "import nuts_rs_amd.selftest as s; print(s.run(), 'self-test runs ok')"],
+                       cwd=os.path.join(HERE, ".."), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError("the library just built FAILED its known-answer self-test on this GPU:\n" + r.stdout[-2000:] + r.stderr[-3000:])
+    return True
 
 
 def pick_tiling(dim, dims_per_lane=0, waves_per_chain=0):

@@ -10,6 +10,7 @@ Names, argument meaning and error behaviour follow the reference; the only struc
 All arithmetic happens in libnuts_amd.so (HIP); this file only marshals arguments.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field, fields
 from typing import Optional
 
@@ -305,6 +306,11 @@ class ChainBatch:
         cfg.device, cfg.chain_id_offset, cfg.dims_per_lane = device, chain_id_offset, dims_per_lane
         cfg.waves_per_chain, cfg.grid_blocks, cfg.lane_groups = waves_per_chain, grid_blocks, lane_groups
         cfg.lowrank_max_rank, cfg.chain_tiles, cfg.lane_chains = lowrank_max_rank, chain_tiles, lane_chains
+        if logp.kind == LOGP_MODULE and os.environ.get("NUTS_AMD_SELFTEST", "1") != "0":
+            # a USER module is compiled by the user's compiler into this engine's kernels, and the parity suite does not travel with it: before
+            # the first such engine of a process, the built library must reproduce its known answers (nuts_rs_amd/selftest.py; ~0.1 s)
+            from . import selftest
+            selftest.run_once(device=device)
         self._cs = settings.to_c()
         self._cl = logp.to_c()
         h = C.c_void_p()

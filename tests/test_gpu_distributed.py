@@ -163,3 +163,31 @@ def test_pooled_exchange_and_finish_through_the_c_abi():
     assert float(cnt.item()) == float(n_)
     assert np.allclose(sigma.cpu().numpy(), want_sigma, rtol=1e-14)
     assert np.allclose(mean.cpu().numpy(), mx.numpy() + want_sigma ** 2 * mg.numpy(), rtol=1e-13, atol=1e-13)
+
+
+def test_pooled_exchange_over_a_real_rccl_communicator():
+    """nm_pooled_exchange (csrc/pooled_reduce.hip: dlopen librccl, ncclAllGather on the CALLER's communicator) with a
+    real two-rank ncclComm_t made by ncclCommInitRank — two processes on GPU 0.  RCCL may refuse two ranks on one device
+    ("duplicate GPU"): then the test is skipped with RCCL's own reason on record, and the first multi-GPU box runs it for real."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        ps = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_two_rank_worker.py"), str(r), d], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+        outs = []
+        for p in ps:
+            try:
+                outs.append(p.communicate(timeout=240))
+            except subprocess.TimeoutExpired:
+                for q in ps:
+                    q.kill()
+                pytest.skip("RCCL with two ranks on one GPU did not return within 240 s (its rendezvous needs one device per rank)")
+        res = []
+        for r in range(2):
+            f = os.path.join(d, f"result_{r}.json")
+            assert os.path.exists(f), (outs[r][0].decode(errors="replace")[-1500:] + outs[r][1].decode(errors="replace")[-1500:])
+            res.append(json.load(open(f)))
+    skips = [x["skip"] for x in res if "skip" in x]
+    if skips:
+        pytest.skip("two-rank RCCL communicator on one GPU: " + skips[0])
+    assert all(x.get("ok") for x in res), res

@@ -15,3 +15,5 @@ cat $O/speed.txt
 timeout 900 python tools/pmc_mix.py $O/mix_k4g.json nuts_group_draw_kernel 8 -- python tools/mix_driver.py k4g 200 > $O/mix_k4g.log 2>&1
 timeout 900 python tools/pmc_mix.py $O/mix_k3deep.json nuts_draw_kernel 1 -- python tools/mix_driver.py k3deep 20 > $O/mix_k3deep.log 2>&1
 timeout 900 python tools/fuzz_parity.py --cases 100 --seed 521 > $O/fuzz.txt 2>&1; tail -1 $O/fuzz.txt
+# the estimator launch's block count (scratch working set): libnuts_amd_est.so reads NM_LR_EST_BLOCKS
+for G in 1024 512 256 128; do NM_LR_EST_BLOCKS=$G NUTS_AMD_LIB=$PWD/nuts_rs_amd/libnuts_amd_est.so timeout 300 python tools/bench_lowrank_adapt.py 2>/dev/null | cut -c1-600 >> $O/est_blocks.txt; done; cat $O/est_blocks.txt
