@@ -228,7 +228,7 @@ typedef struct nm_logp_spec {
  * `init(params, dim)` and `double eval(const double (&x)[2], double (&grad)[2], int dim) const`, where this lane holds
  * elements 2 L::lane(), 2 L::lane() + 1 and L::sum / L::bcast combine the chain's lanes, and is built with
  * -DNM_MODULE_GROUP_DENSITY=MyDensityGroup -DNM_MODULE_GS=<8|16|32 for dim <= 16|32|64> (tests/user_density/ has one).
- * Lane form (optional, dim <= 16): one chain per lane (nm_engine_config.lane_chains): `template <int NP> struct MyDensityLane` with
+ * Lane form (optional, dim <= 10): one chain per lane (nm_engine_config.lane_chains): `template <int NP> struct MyDensityLane` with
  * `init(params, dim)` and `double eval(const double (&x)[2 NP], double (&gx)[2 NP], int dim) const`, -DNM_MODULE_LANE_DENSITY=MyDensityLane.
  * Other samplers (dim <= 4096): -DNM_MODULE_VARIANTS=<bits> compiles the SAME functor into the kernels that carry the low-rank
  * transformation (bit 0: adaptation = NM_ADAPT_LOW_RANK, `LowRankNutsSettings`) and into those with the non-Euclidean trajectory kinds
@@ -325,7 +325,7 @@ typedef struct nm_engine_config {
                                     * 0 = auto ((a) from 256 chains on, (b) whenever it applies), 1 = never, 2 = whenever it applies */
     uint64_t lowrank_max_rank;     /* NM_ADAPT_LOW_RANK: eigenvector slots per chain (HBM: (max_rank + 1) x dim f64 per chain).
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
-    uint64_t lane_chains;          /* chains with dim <= 16: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
+    uint64_t lane_chains;          /* chains with dim <= 10: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
                                     * Euclidean NUTS, maxdepth + extra_doublings <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
                                     * 0 = auto (dim <= 4 from 16384 chains on, dim <= 10 from 24576: the measured crossovers against the 8-lane kernels;
                                     * never for dim 11 .. 16), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */

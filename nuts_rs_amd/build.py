@@ -193,9 +193,9 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 64:
             raise ValueError("group forms exist for dim <= 64")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_GROUP_DENSITY={group_struct}", f"-DNM_MODULE_GS={8 if dim <= 16 else 16 if dim <= 32 else 32}"]
-    if lane_struct:           # the density's lane form: one chain per lane for dim <= 16 (`template <int NP> struct ...`)
-        if dim > 16:
-            raise ValueError("lane forms exist for dim <= 16")
+    if lane_struct:           # the density's lane form: one chain per lane for dim <= 10 (`template <int NP> struct ...`; the 8-pair kernel for dim 11 .. 16 was removed in round 5)
+        if dim > 10:
+            raise ValueError("lane forms exist for dim <= 10")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
     if group_struct or lane_struct:
         # a user functor that calls nm::dexp / dlog / dlog1p from a several-chains-per-wavefront kernel must not reach them through a call

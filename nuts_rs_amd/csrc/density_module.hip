@@ -94,7 +94,6 @@ int nm_module_launch_lane(int query, int tune, const void* kparams, const void* 
     case 2: return (int)nm::lane::module_lane_t<2>(query, tune != 0, P, LP, grid, s, occ);
     case 4: return (int)nm::lane::module_lane_t<4>(query, tune != 0, P, LP, grid, s, occ);
     case 5: return (int)nm::lane::module_lane_t<5>(query, tune != 0, P, LP, grid, s, occ);
-    case 8: return (int)nm::lane::module_lane_t<8>(query, tune != 0, P, LP, grid, s, occ);
     }
     return (int)hipErrorInvalidValue;
 }

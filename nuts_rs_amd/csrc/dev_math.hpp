@@ -20,6 +20,9 @@ namespace nm {
 #define NM_DEV __device__ __forceinline__
 
 #define NM_HD __host__ __device__ __forceinline__
+#ifndef NM_PACKED_SUMS
+#define NM_PACKED_SUMS 1      // several sums of a wavefront through one transposed butterfly (wave_sum_packed); 0: one butterfly per value (rounds 1-4)
+#endif
 NM_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 NM_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 // Tile mode (nuts_tile.hpp): a block holds 16 independent chains, one wavefront each, so "the chain's block" is the
@@ -62,6 +65,18 @@ NM_DEV double readlane_f64(double x, int lane) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
+NM_DEV double swap_add16(double x) {            // rows (r0, r1, r2, r3) -> (r0 + r1, r0 + r1, r2 + r3, r2 + r3)
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+NM_DEV double swap_add32(double x) {            // halves (lo, hi) -> lo + hi in every lane
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
 NM_DEV double wave_sum(double x) {
     x = x + dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]  : xor 1
     x = x + dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]  : xor 2
@@ -69,6 +84,12 @@ NM_DEV double wave_sum(double x) {
     x = x + dpp_mov<0x140>(x);   // row_mirror           : pairs the two halves of each row of 16 (= xor 8)
     const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
     return (r0 + r1) + (r2 + r3);
+}
+NM_DEV double wave_rows(double x) {              // wave_sum's first four steps: the sum of the lane's row of 16, in every lane of the row
+    x = x + dpp_mov<0xB1>(x);
+    x = x + dpp_mov<0x4E>(x);
+    x = x + dpp_mov<0x141>(x);
+    return x + dpp_mov<0x140>(x);
 }
 // two sums at once (independent chains interleave in the issue stream)
 NM_DEV void wave_sum2(double& a, double& b) {
@@ -81,6 +102,49 @@ NM_DEV void wave_sum2(double& a, double& b) {
     a = (a0 + a1) + (a2 + a3);
     b = (b0 + b1) + (b2 + b3);
 }
+// ---- several sums at once: the transposed butterfly (round 5) ---------------------------------------------------------------------
+// A lone wavefront pays for the NUMBER of instructions it issues (tools/probes/ubench_issue.hip), and wave_sum above is 27 of them per
+// value: six for a U-turn test group are 162.  The butterfly of N values can share its exchanges: at the xor-1 step a lane KEEPS one value
+// of a pair (A, B) and GIVES the other to its partner, so one add serves two values; after the xor-2 step a quad's four lanes hold four
+// values, after the xor-4 step an eight-group's lanes hold eight — the remaining steps work on ONE register whatever N is.  Each value
+// still goes through exactly wave_sum's tree — (i, i^1), (i, i^2), the two quads of an eight-group, the two halves of a row, then
+// (r0 + r1) + (r2 + r3) over the rows, IEEE addition being commutative — so every total has wave_sum's bits.
+// wave_sum pairs quads and half rows with the DPP mirrors (lane i <-> 7 - i, i <-> 15 - i), which is only the xor pairing when the paired
+// lanes hold the same thing; here they hold DIFFERENT values, so the value a lane keeps is chosen mirror-symmetrically: with b0..b3 the
+// low bits of the lane id, value id = (b0 ^ b2) + 2 (b1 ^ b2) + 4 (b2 ^ b3) — every partner under i^1, i^2, 7 - i, 15 - i that must hold
+// the same value does, every partner that must hold the other one does.  Total of value id v: in lane packed_lane(v) of every row.
+// The last two steps use gfx950's v_permlane16_swap / v_permlane32_swap (rows / halves exchanged between two registers: with the same
+// value in both, their sum is x + xor16(x), x + xor32(x)) instead of eight v_readlane and scalar-operand adds.
+__host__ __device__ constexpr int packed_lane(int v) { return (((v >> 2) & 1) << 2) | ((((v >> 1) ^ (v >> 2)) & 1) << 1) | ((v ^ (v >> 2)) & 1); }
+// one transposed step: a lane with `second` keeps b and gives a, the others keep a and give b; result = kept + partner's gift
+template <int CTRL>
+NM_DEV double fold_pair(double a, double b, bool second) {
+    const double keep = second ? b : a, give = second ? a : b;
+    return keep + dpp_mov<CTRL>(give);
+}
+// N = 2 .. 8 values -> one register: lane packed_lane(v) of every row holds the wave total of value v.  (Where a pair has only one member
+// the plain step x + dpp(x) is taken: the lanes that would have kept the missing value hold a second copy of its sibling's partial — the
+// sibling's tree is the same, and every lane of the result holds the total of SOME value < N: a sign test over all lanes sees exactly the N totals.)
+template <int N>
+NM_DEV double wave_sum_packed(const double (&v)[N]) {
+    static_assert(N >= 2 && N <= 8, "2 .. 8 values");
+    const int l = lane_id();
+    const bool c1 = ((l ^ (l >> 2)) & 1) != 0, c2 = (((l >> 1) ^ (l >> 2)) & 1) != 0, c3 = (((l >> 2) ^ (l >> 3)) & 1) != 0;
+    constexpr int NQ = (N + 1) / 2, NH = (NQ + 1) / 2;
+    double q[NQ];                                  // after the xor-1 step: q[j] = values (2 j, 2 j + 1)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+        q[j] = 2 * j + 1 < N ? fold_pair<0xB1>(v[2 * j], v[2 * j + 1 < N ? 2 * j + 1 : 0], c1) : v[2 * j] + dpp_mov<0xB1>(v[2 * j]);
+    double h[NH];                                  // after the xor-2 step: h[k] = pairs (2 k, 2 k + 1)
+#pragma unroll
+    for (int k = 0; k < NH; ++k)
+        h[k] = 2 * k + 1 < NQ ? fold_pair<0x4E>(q[2 * k], q[2 * k + 1 < NQ ? 2 * k + 1 : 0], c2) : q[2 * k] + dpp_mov<0x4E>(q[2 * k]);
+    double x = NH == 2 ? fold_pair<0x141>(h[0], h[NH - 1], c3) : h[0] + dpp_mov<0x141>(h[0]);      // row_half_mirror: the two quads of an eight-group
+    x = x + dpp_mov<0x140>(x);                                                                     // row_mirror: the two halves of a row
+    x = swap_add16(x);
+    return swap_add32(x);
+}
+
 // Block-wide sums for a chain that spans W waves.  Each wave reduces with DPP, lane 0 of every wave publishes its
 // total in LDS, one barrier, then every thread adds the W totals in wave order (w = 0 first) — the documented
 // cross-wave order (oracle gpu_reduce).  Two LDS buffers alternate so one barrier per reduction is enough.
@@ -115,6 +179,8 @@ template <int W>
 struct Reducer {
     double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES + 1 + 2 RED_MAX_VALUES CL_MAX_MEMBERS in cluster mode)
     int par;
+    bool packed = false;   // several sums through ONE transposed butterfly (wave_sum_packed: same bits).  Set by the kernel per tiling: measured
+                           // (2 doubles per lane) K3 +6.6 %, dim 100 +7 %; (4) dim 256 +4 %; (8) dim 512 -12 %; (16) K2 -24 % (96 more bytes of scratch): profiles/r05k_*, r05l_*
 #if NM_CLUSTER_MODE
     ClusterLink cl;      // by value: a pointer to a link inside the chain's context would pin the whole context in scratch memory
     NM_DEV void init(double* lds) { buf = lds; par = 0; }       // (cl is set by the kernel; k <= 1: no exchange)
@@ -225,11 +291,20 @@ struct Reducer {
     template <int N>
     NM_DEV void sum_n(double (&v)[N]) {
         static_assert(N <= RED_MAX_VALUES, "too many values");
-        if (N == 1) v[0] = wave_sum(v[0]);
-        else {
+        if (NM_PACKED_SUMS && packed) {
+            if constexpr (N == 1) v[0] = swap_add32(swap_add16(wave_rows(v[0])));
+            else {
+                const double pk = wave_sum_packed<N>(v);       // one shared butterfly (same tree, same bits per value), the totals read out as uniform values
 #pragma unroll
-            for (int i = 0; i + 1 < N; i += 2) wave_sum2(v[i], v[i + 1]);
-            if (N & 1) v[N - 1] = wave_sum(v[N - 1]);
+                for (int i = 0; i < N; ++i) v[i] = readlane_f64(pk, packed_lane(i));
+            }
+        } else {
+            if (N == 1) v[0] = wave_sum(v[0]);
+            else {
+#pragma unroll
+                for (int i = 0; i + 1 < N; i += 2) wave_sum2(v[i], v[i + 1]);
+                if (N & 1) v[N - 1] = wave_sum(v[N - 1]);
+            }
         }
         if (W != 1) {
             double* b = buf + par * (RED_MAX_VALUES * W);
@@ -250,6 +325,21 @@ struct Reducer {
 #if NM_CLUSTER_MODE
         if (cl.k > 1) cluster_combine<N>(v);
 #endif
+    }
+    // is any of the N block sums negative (neg) / positive (!neg)?  (the U-turn tests: is_turning's "< 0" with the direction folded into the
+    // sign, nuts_kernels.hpp turning_regs).  One wavefront per chain with packed sums: every lane of the packed register holds one of the N totals,
+    // so the answer is a compare and a ballot — no total is read out.  Same decision as sum_n + N scalar compares.
+    template <int N>
+    NM_DEV bool any_sign(double (&v)[N], bool neg) {
+        if (NM_PACKED_SUMS && packed && W == 1 && !NM_CLUSTER_MODE) {
+            const double pk = wave_sum_packed<N>(v);
+            return __ballot(neg ? pk < 0. : pk > 0.) != 0ull;
+        }
+        sum_n(v);
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) any = any | (neg ? v[i] < 0. : v[i] > 0.);
+        return any;
     }
     NM_DEV double sum(double x) { double v[1] = {x}; sum_n(v); return v[0]; }
     NM_DEV void sum2(double& a, double& b) { double v[2] = {a, b}; sum_n(v); a = v[0]; b = v[1]; }

@@ -16,11 +16,7 @@ hipError_t launch_lane_t(int query, bool tune, const KParams& P, const lane::Lan
         return hipErrorInvalidValue;
     } else {
         if (query == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, lane::nuts_lane_draw_kernel<Dens, NP, true>, 64, 0);
-        if (query == 2) {                 // unsynchronised draws (l_run_rounds)
-            if (tune) hipLaunchKernelGGL((lane::nuts_lane_rounds_kernel<Dens, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
-            else hipLaunchKernelGGL((lane::nuts_lane_rounds_kernel<Dens, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
-            return hipGetLastError();
-        }
+        if (query != 0) return hipErrorInvalidValue;          // (the unsynchronised launch form of round 4 is removed)
         if (tune) hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, true>), dim3(grid), dim3(64), 0, stream, P, LP);
         else hipLaunchKernelGGL((lane::nuts_lane_draw_kernel<Dens, NP, false>), dim3(grid), dim3(64), 0, stream, P, LP);
         return hipGetLastError();
@@ -32,7 +28,6 @@ hipError_t launch_lane_d(int query, bool tune, const KParams& P, const lane::Lan
     case 2: return launch_lane_t<Dens, 2>(query, tune, P, LP, grid, stream, occ);
     case 4: return launch_lane_t<Dens, 4>(query, tune, P, LP, grid, stream, occ);
     case 5: return launch_lane_t<Dens, 5>(query, tune, P, LP, grid, stream, occ);
-    case 8: return launch_lane_t<Dens, 8>(query, tune, P, LP, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }

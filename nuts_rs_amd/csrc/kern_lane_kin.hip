@@ -29,7 +29,6 @@ hipError_t launch_lane_kin_d(int query, bool tune, const KParams& P, const lane:
     case 2: return launch_lane_kin_t<Dens, 2>(query, tune, P, LP, grid, stream, occ);
     case 4: return launch_lane_kin_t<Dens, 4>(query, tune, P, LP, grid, stream, occ);
     case 5: return launch_lane_kin_t<Dens, 5>(query, tune, P, LP, grid, stream, occ);
-    case 8: return launch_lane_kin_t<Dens, 8>(query, tune, P, LP, grid, stream, occ);
     }
     return hipErrorInvalidValue;
 }

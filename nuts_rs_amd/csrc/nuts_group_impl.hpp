@@ -118,7 +118,16 @@ struct GDiagNormal {
 struct GEightSchools {
     NM_DEV void set_lds(double*) {}
     const double* par;
-    NM_DEV void init(const double* params, int) { par = params; }
+    double yk[2], sk[2];           // this lane's y_i and sigma_i (read once: they were two loads from global memory per element and leapfrog)
+    NM_DEV void init(const double* params, int) {
+        par = params;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int d = 2 * gl() + j;
+            const int i = (d >= 2 && d < 10) ? d - 2 : 0;
+            yk[j] = params[i]; sk[j] = params[8 + i];
+        }
+    }
     NM_DEV double eval(const double (&x)[2], double (&gx)[2], int) const {
         const double mu = gbcast(x[0], 0), lt = gbcast(x[1], 0);
         const double tau = dexp(lt);
@@ -131,8 +140,9 @@ struct GEightSchools {
             const bool school = d >= 2 && d < 10;
             const int i = school ? d - 2 : 0;
             const double th = x[j];
-            const double sg = par[8 + i];
-            const double r = (par[i] - (mu + tau * th)) / sg;
+            (void)i;
+            const double sg = sk[j];
+            const double r = (yk[j] - (mu + tau * th)) / sg;
             term[j] = -0.5 * th * th - 0.5 * r * r;
             dr[j] = r / sg;
             drth[j] = dr[j] * th;

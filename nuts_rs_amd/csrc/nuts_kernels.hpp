@@ -845,6 +845,7 @@ struct ChainCtx {
 #endif
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, uint64_t chain, uint64_t wave) {
+    C.red.packed = DPL <= 4 && !NM_TILE_MODE;        // (dev_math.hpp Reducer::packed: per tiling, from the measurements of round 5)
     const KParams& P = C.P;
     C.dim = (int)P.dim; C.gdim = (int)P.dim; C.goff = 0;
 #if NM_CLUSTER_MODE
@@ -1921,8 +1922,8 @@ NM_DEV bool turning_regs(const Pt<DPL>& a, const Pt<DPL>& b, bool fwd, Reducer<W
     double s1 = 0., s2 = 0.;
 #pragma unroll
     for (int k = 0; k < DPL; ++k) turn_acc(a.z.a[k], a.v.a[k], b.z.a[k], b.v.a[k], s1, s2);
-    R.sum2(s1, s2);
-    return turn_sign(fwd, s1) | turn_sign(fwd, s2);
+    double s2v[2] = {s1, s2};
+    return R.any_sign(s2v, fwd);
 }
 
 // the candidate's z goes to a fresh pool slot
@@ -2240,8 +2241,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         }
                     };
                     if (fwd) rows(std::true_type{}); else rows(std::false_type{});
-                    { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                    return turn_any6(fwd, s1, s2, s3, s4, s5, s6);
+                    { double sv6[6] = {s1, s2, s3, s4, s5, s6}; return C.red.any_sign(sv6, fwd); }
                 }
         };
         if (depth == 0) {
@@ -2342,8 +2342,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                 NM_GROUP_BARRIER(m);
                             }
                         }
-                        { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                        if (turn_any6(fwd, s1, s2, s3, s4, s5, s6)) turn_bits |= 1u << k;
+                        { double sv6[6] = {s1, s2, s3, s4, s5, s6}; if (C.red.any_sign(sv6, fwd)) turn_bits |= 1u << k; }
                     }
                 }
                 NM_MARK(C, 21)
@@ -2489,8 +2488,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                     NM_GROUP_BARRIER(m);
                                 }
                             }
-                            { double sv6[6] = {s1, s2, s3, s4, s5, s6}; C.red.sum_n(sv6); s1 = sv6[0]; s2 = sv6[1]; s3 = sv6[2]; s4 = sv6[3]; s5 = sv6[4]; s6 = sv6[5]; }
-                            if (turn_any6(fwd, s1, s2, s3, s4, s5, s6)) turn_bits |= 1u << k;
+                            { double sv6[6] = {s1, s2, s3, s4, s5, s6}; if (C.red.any_sign(sv6, fwd)) turn_bits |= 1u << k; }
                         }
                     }
                 NM_MARK(C, 21)

@@ -28,7 +28,8 @@ namespace nm {
 namespace lane {
 
 constexpr int LMAXDEPTH = 10;
-__host__ __device__ inline int lane_pairs(uint64_t dim) { return dim <= 4 ? 2 : dim <= 8 ? 4 : dim <= 10 ? 5 : dim <= 16 ? 8 : 0; }
+// (round 5: the 8-pair kernel for dim 11 .. 16 — 2 KB of scratch per lane, slower than the 8-lane kernels at every size measured — is removed)
+__host__ __device__ inline int lane_pairs(uint64_t dim) { return dim <= 4 ? 2 : dim <= 8 ? 4 : dim <= 10 ? 5 : 0; }
 
 struct LaneParams {
     double* lws;          // [grid][NUM_PSLOT][2 NP][64]  the chains' persistent vectors while the kernel runs
@@ -1675,45 +1676,9 @@ NM_DEV void l_draw_end(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out, LAccept&
     sc.draw_count += 1;
 }
 
-// all draws of the launch for the lane's chain, unsynchronised with the other lanes of the wavefront
-template <bool TUNE, int NP, class LD>
-NM_DEV void l_run_rounds(LCtx<NP, LD>& C, uint64_t chain, bool present) {
-    const KParams& P = C.P;
-    int phase = (present && C.sc.status == NM_CHAIN_OK && P.n_draws > 0) ? LP_BEGIN : LP_DONE;
-    uint64_t t_out = 0;
-    LTree<NP> T;
-    LAccept col;
-    DrawResult R;
-    LPt<NP> cur, prv;
-    bool fatal = false;
-    for (;;) {
-        // ---- epoch boundary
-        if (__any(phase == LP_END)) {
-            if (phase == LP_END) {
-                l_draw_end<TUNE>(C, chain, t_out, col, R, fatal);
-                t_out += 1;
-                phase = (!fatal && C.sc.status == NM_CHAIN_OK && t_out < P.n_draws) ? LP_BEGIN : LP_DONE;
-            }
-        }
-        if (__any(phase == LP_BEGIN)) {
-            if (phase == LP_BEGIN) {
-                l_draw_begin(C, T, col, R, cur);
-                phase = LP_LEAF;
-                if (!l_doubling_begin(C, T, R, cur)) { R.depth = T.depth; R.chosen = T.mc; phase = LP_END; }
-            }
-        }
-        if (!__any(phase == LP_LEAF || phase == LP_END)) break;
-        // ---- the epoch's leapfrog rounds
-        for (int r = 0; r < NM_LANE_EPOCH; ++r) {
-            if (phase == LP_LEAF) {
-                prv = cur;
-                l_leapfrog(C, prv, cur, T.eps);
-                if (!l_leaf_done<!TUNE>(C, T, col, R, prv, cur, fatal)) phase = LP_END;
-            }
-            if (!__any(phase == LP_LEAF)) break;
-        }
-    }
-}
+// (round 5: the launch form with unsynchronised draws — l_run_rounds / nuts_lane_rounds_kernel, `lane_chains = 3` — was bit-exact and slower
+// in every measurement of round 4 (K4 warm-up 328 against 157 ms) and is removed; the per-lane step functions above are unreferenced
+// templates now: no code is generated for them)
 
 template <int NP>
 struct LaneShared {
@@ -1788,53 +1753,6 @@ __global__ __launch_bounds__(64, 1) void nuts_lane_draw_kernel(const KParams P, 
     }
 }
 
-// the same launch shape with unsynchronised draws (l_run_rounds)
-template <class Dens, int NP, bool TUNE>
-__global__ __launch_bounds__(64, 1) void nuts_lane_rounds_kernel(const KParams P, const LaneParams LP) {
-    using LD = typename LaneDensity<Dens, NP>::type;
-    constexpr int E = 2 * NP;
-    __shared__ LaneShared<NP> sh;
-    for (int i = (int)threadIdx.x; i < 257; i += 64) {
-        sh.zig[i] = P.zig_x[i];
-        if (NP != 8) sh.zig[(NP != 8 ? 257 : 0) + i] = P.zig_f[i];
-    }
-    for (int i = (int)threadIdx.x; i < 2 * NP * 64; i += 64) sh.stage[i] = 0.0;
-    dm_init_lds();
-    __syncthreads();
-    const int l = (int)threadIdx.x;
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < P.n_chains; base += (uint64_t)gridDim.x * 64) {
-        const uint64_t chain = base + (uint64_t)l;
-        const bool present = chain < P.n_chains;
-        ChainScalars sc = P.sc[present ? chain : base];
-        LCtx<NP, LD> C(P, sc);
-        C.dim = (int)P.dim;
-        C.md = (int)P.layout_md;
-        C.rw = make_rsrc(LP.lws + (size_t)blockIdx.x * NUM_PSLOT * E * 64, (uint64_t)NUM_PSLOT * E * 512);
-        C.rsv = make_rsrc(LP.lsv + (size_t)blockIdx.x * LP.nslots * E * 64, (uint64_t)LP.nslots * E * 512);
-        C.l8 = l * 8;
-        C.pend.base = sh.pend + l;
-        C.zig = {sh.zig, NP != 8 ? sh.zig + 257 : P.zig_f};
-        C.stage = sh.stage + l;
-        if (present) {
-            const double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
-            for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
-#pragma unroll
-                for (int e = 0; e < E; ++e) C.stWe(s_, e, pv[(size_t)s_ * P.dpad + e]);
-        }
-        C.ldW(C.sig, P_SIG); C.ldW(C.mu, P_MU);
-        C.rng.init(sc.key, sc.rng_pos, sh.rng_ring + l);
-        C.dens.init(P.logp_params, C.dim);
-        l_run_rounds<TUNE>(C, chain, present);
-        if (present) {
-            sc.rng_pos = C.rng.pos;
-            double* pv = P.pvec + (size_t)chain * NUM_PSLOT * P.dpad;
-            for (int s_ = 0; s_ < (int)NUM_PSLOT; ++s_)
-#pragma unroll
-                for (int e = 0; e < E; ++e) pv[(size_t)s_ * P.dpad + e] = C.ldWe(s_, e);
-            P.sc[chain] = sc;
-        }
-    }
-}
 
 }  // namespace lane
 }  // namespace nm

@@ -75,7 +75,7 @@ def test_user_density_module_matches_builtin_and_oracle(oracle):
     assert e.value.status == 1 and "cannot load" in str(e.value)
 
 
-GROUP_DIM = 12
+GROUP_DIM = 10
 
 
 def test_group_form_module_builds():

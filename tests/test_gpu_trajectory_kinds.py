@@ -55,7 +55,7 @@ def _runs():
         out.append(pytest.param(c, "wave", id=c[0] + "-wave"))
         if c[3] <= 64 and c[7] == 0:                 # the small-chain kernels: 8 / 4 / 2 chains per wavefront (nuts_group.hpp), since round 4
             out.append(pytest.param(c, "group", id=c[0] + "-group"))
-        if c[3] <= 16 and c[7] == 0 and c[6] != "mvn":   # one chain per lane (nuts_lane.hpp): dim <= 16, the built-in element-wise densities
+        if c[3] <= 10 and c[7] == 0 and c[6] != "mvn":   # one chain per lane (nuts_lane.hpp): dim <= 10, the built-in element-wise densities
             out.append(pytest.param(c, "lane", id=c[0] + "-lane"))
     return out
 
