@@ -327,8 +327,9 @@ typedef struct nm_engine_config {
                                     * 0 = auto: min(dim, 2 (num_tune + 1)) — the most the reference's estimator can return — or dim with freeze_transform */
     uint64_t lane_chains;          /* chains with dim <= 10: ONE CHAIN PER LANE, 64 chains per wavefront (nuts_lane.hpp), same results.  DiagNutsSettings,
                                     * Euclidean NUTS, maxdepth + extra_doublings <= 10, the built-in iid / diagonal normal, funnel and (dim 10) 8-schools densities.
-                                    * 0 = auto (dim <= 4 from 16384 chains on, dim <= 10 from 24576: the measured crossovers against the 8-lane kernels;
-                                    * never for dim 11 .. 16), 1 = never, 2 = whenever the kernel applies.  Takes precedence over lane_groups. */
+                                    * 0 = auto (dim <= 4 from 32768 chains on, dim <= 10 from 49152, never for Neal's funnel: the crossovers against the
+                                    * 8-lane kernels measured by tools/crossover_sweep.py, profiles/r05m_crossovers.json), 1 = never, 2 = whenever the kernel
+                                    * applies.  Takes precedence over lane_groups. */
 } nm_engine_config;
 void nm_engine_config_default(nm_engine_config* c);
 

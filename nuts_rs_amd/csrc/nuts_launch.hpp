@@ -58,6 +58,9 @@ inline hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, un
 #ifdef NM_DEV_ONLY_K2
     case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
     default: return hipErrorInvalidValue;
+#elif defined(NM_DEV_ONLY_41)      // (bisecting builds: one tiling per unit compiles in a minute)
+    case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
+    default: return hipErrorInvalidValue;
 #else
     case 102: return launch_t<2, 1, Dens>(kind, P, grid, stream, occ);
     case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
