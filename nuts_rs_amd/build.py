@@ -100,6 +100,15 @@ def _scan_store_hazards(asm_path, what):
                                    "force-inline the callee, DESIGN §22):\n" + r.stdout[-3000:])
 
 
+    # the software-managed VALU hazards (DPP / v_readlane / v_permlane*_swap / SGPR forwarding / transcendental results) at TEXT level: the
+    # compiler's hazard recogniser cannot see into an inline-asm instruction (incidents three and four)
+    tool3 = os.path.join(HERE, "..", "tools", "check_valu_hazards.py")
+    if os.path.exists(tool3):
+        r = subprocess.run([sys.executable, tool3, asm_path], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise StoreHazardError(f"{what}: a software-managed VALU hazard without its wait states (python tools/check_valu_hazards.py):\n" + r.stdout[-3000:])
+
+
 def _compile_scanned(hipcc, flags, src, out, what, link=False):
     """Compile `src` (one hipcc run: -save-temps keeps the device assembly the object is assembled from), scan it, drop the temporaries."""
     import shutil
@@ -197,15 +206,18 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 10:
             raise ValueError("lane forms exist for dim <= 10")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
-    if group_struct or lane_struct:
-        # a user functor that calls nm::dexp / dlog / dlog1p from a several-chains-per-wavefront kernel must not reach them through a call
-        # (tools/check_divergent_calls.py rejects it): the special functions are inlined in such a module
-        extra_flags = list(extra_flags) + ["-DNM_DETMATH_INLINE=1"]
+    # The special functions (nm::dexp / dlog / dlog1p, merge_math) are INLINED in every module: a user functor must not reach them through a
+    # call from a several-chains-per-wavefront kernel (tools/check_divergent_calls.py rejects it), and since round 5 the
+    # one-chain kernels of a module are built the same way — the fourth incident of §22 includes a module whose out-of-line build reported
+    # a wrong energy statistic while the inlined build of the same sources is bit-exact (profiles/r05z_module_variants.txt); a module is
+    # compiled on the USER's machine, where the engine's parity suite does not run.
+    extra_flags = list(extra_flags) + ["-DNM_DETMATH_INLINE=1"]
     vbits = (1 if "low_rank" in variants else 0) | (2 if "kinetic" in variants else 0)
     if vbits:
         if dim > 4096:
             raise ValueError("the low-rank / kinetic variants exist for dim <= 4096")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_VARIANTS={vbits}"]
+    extra_flags = list(extra_flags) + os.environ.get("NM_MODULE_EXTRA_FLAGS", "").split()       # (tuning / bisecting builds of a module)
     flags = FLAGS + list(extra_flags) + [
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
         f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]

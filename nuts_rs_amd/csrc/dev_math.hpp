@@ -331,10 +331,12 @@ struct Reducer {
     // so the answer is a compare and a ballot — no total is read out.  Same decision as sum_n + N scalar compares.
     template <int N>
     NM_DEV bool any_sign(double (&v)[N], bool neg) {
+#ifndef NM_X_ANYSIGN_UNPACKED
         if (NM_PACKED_SUMS && packed && W == 1 && !NM_CLUSTER_MODE) {
             const double pk = wave_sum_packed<N>(v);
             return __ballot(neg ? pk < 0. : pk > 0.) != 0ull;
         }
+#endif
         sum_n(v);
         bool any = false;
 #pragma unroll
@@ -379,7 +381,9 @@ static constexpr double DM_T_HI[64] = DM_EXP_T_HI, DM_T_LO[64] = DM_EXP_T_LO;
 static constexpr double DM_R[47] = DM_LOG_R, DM_F_HI[47] = DM_LOG_F_HI, DM_F_LO[47] = DM_LOG_F_LO;
 constexpr int DM_OFF_T_HI = 0, DM_OFF_T_LO = 64, DM_OFF_R = 128, DM_OFF_F_HI = 175, DM_OFF_F_LO = 222, DM_LDS_DOUBLES = 269;
 #if defined(__HIP_DEVICE_COMPILE__)
-static __shared__ double dm_lds[DM_LDS_DOUBLES];
+// (16-byte aligned and a multiple of 16 bytes long: the kernels' own LDS structures follow it, and their 128-bit accesses — sigma / mu tiles, L[1] —
+// were 8 bytes off a 16-byte boundary for as long as this array was 269 doubles: every ds_read_b128 / ds_write_b128 of the hot loops misaligned)
+alignas(16) static __shared__ double dm_lds[(DM_LDS_DOUBLES + 1) / 2 * 2 + 2];
 #define DM_TAB(name, off, idx) dm_lds[(off) + (idx)]
 #else
 #define DM_TAB(name, off, idx) name[idx]

@@ -59,7 +59,7 @@ struct Lanes {
     NM_DEV static double bcast(double x, int j) { return gbcast(x, j); }   // the value lane j of this chain holds
 };
 
-struct GroupShared {
+struct alignas(16) GroupShared {
     uint32_t rng_cache[GPW][16 * GS];         // GS ChaCha blocks per chain
     double samp[GPW][2 * GS];                     // stream-ordered normals of the momentum refresh
     double xs[GPW][2 * GS];                   // the position, visible to the group (densities that need all of x)

@@ -82,6 +82,9 @@ __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)
 #ifndef NM_EDGES_IN_ACC
 #define NM_EDGES_IN_ACC 0
 #endif
+#ifndef NM_LF_FMA_FORM
+#define NM_LF_FMA_FORM 0          // the fused leapfrog's two fused multiply-adds: 0 inline asm, 1 volatile inline asm, 2 __builtin_fma (bisecting builds)
+#endif
 #ifndef NM_FUSED_LEAPFROG
 #define NM_FUSED_LEAPFROG 1        // 0: the leapfrog as three loops over the tile for every density (rounds 1-4; bisecting builds)
 #endif
@@ -735,19 +738,19 @@ struct PendEntry {        // a completed sub-tree of `other` waiting for its sib
 };
 
 template <int DPL, int W, class Dens>
-struct BlockShared {      // LDS of one block (one block = W waves = one resident chain)
-    uint32_t rng_cache[RNG_CACHE_WORDS];
-    double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
-    double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
-    double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES + 1 + 2 * RED_MAX_VALUES * CL_MAX_MEMBERS : 0)];
-    double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
-    double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
+struct alignas(16) BlockShared {      // LDS of one block (one block = W waves = one resident chain); the vectors are read and written 16 bytes at a time
+    alignas(16) uint32_t rng_cache[RNG_CACHE_WORDS];
+    alignas(16) double sig[NM_TILE_MODE ? 2 : 64 * W * DPL];     // DiagMassMatrix stds of the resident chain, tile order
+    alignas(16) double mu[NM_TILE_MODE ? 2 : 64 * W * DPL];      // DiagMassMatrix mean   (tile mode: one shared copy per block, nuts_tile.hpp)
+    alignas(16) double red[2 * RED_MAX_VALUES * W + (NM_CLUSTER_MODE ? RED_MAX_VALUES + 1 + 2 * RED_MAX_VALUES * CL_MAX_MEMBERS : 0)];
+    alignas(16) double l1_z[NM_LDS_L1 ? 64 * W * DPL : 2];    // L[1]: (z, v) of the last leaf of the pending level-1 sub-tree — the hottest
+    alignas(16) double l1_v[NM_LDS_L1 ? 64 * W * DPL + 72 : 2];   // end point (written every 4th leaf, read two leaves later) never leaves the CU
     // Between trees both arrays are free: the momentum refresh uses l1_v as its ChaCha word buffer (hence the 72
     // extra doubles: 64 spare cells + one block of alignment) and l1_z as the stream-ordered sample vector.
     // wave-uniform state is kept once PER WAVE: every wave computes the same values, so private copies need no
     // synchronisation (a shared copy would be a read-modify-write race between the waves)
     PendEntry pend[W][MAX_MAXDEPTH + 1];
-    double dens_lds[Dens::kNeedsLdsVector ? 64 * W * DPL : 2];   // a density's block-visible vector (MvnPrec: the position)
+    alignas(16) double dens_lds[Dens::kNeedsLdsVector ? 64 * W * DPL : 2];   // a density's block-visible vector (MvnPrec: the position)
     ChainScalars sc[W];       // the resident chain's scalars (copied in at ctx_begin; wave 0's copy goes back at ctx_end)
 };
 
@@ -1148,7 +1151,12 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
 // One leapfrog, registers to registers (reference transformed_hamiltonian.rs:524-615 + diagonal.rs:196-209, :248-265):
 //   v½ = fma(ε/2, g_z, v); z' = fma(ε, v½, z); x' = z'·σ + μ; (logp, g_x) = density(x'); g_z' = g_x·σ;
 //   v' = fma(ε/2, g_z', v½); KE' = ½ Σ fma(v', v', ·)
-template <int DPL, int W, class Dens>
+#ifndef NM_X_ASM_SITES
+#define NM_X_ASM_SITES 4          // call sites whose fused leapfrog uses the inline-asm form of its two fused multiply-adds: bit 0 MCLMC (x_out / gx_out), 1 the
+                                  // step-size search, 2 the tree.  Tree only: it is where the instruction pays (K2 +5 %: profiles/r05u), and every failing
+                                  // build of DESIGN §22's fourth incident had the asm form at the MCLMC site (never executed by the failing runs)
+#endif
+template <int DPL, int W, class Dens, int SITE = 0>
 NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
 #ifdef NM_X_NO_LEAPFROG           // timing experiment only: the tree without its integrator
     if (!x_out && !gx_out) { o.z = s.z; o.v = s.v; o.g = s.g; o.logp = s.logp + epsilon * 1e-6; o.ke = s.ke; return; }
@@ -1208,8 +1216,30 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
                     // (v_fma_f64 spelled out: the source point's v and z stay live, and the compiler's two-address form — v_mov_b64 + v_fmac_f64 —
                     // costs an instruction more per fma; the same IEEE fused multiply-add)
                     double vh, zk;
+#if NM_LF_FMA_FORM == 0
+                    if constexpr ((NM_X_ASM_SITES >> SITE) & 1) {
                     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
                     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+                    } else {
+                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
+                    }
+#elif NM_LF_FMA_FORM == 1
+                    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+#elif NM_LF_FMA_FORM == 3
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+#elif NM_LF_FMA_FORM == 4
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
+#elif NM_LF_FMA_FORM == 5
+                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+#else
+                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
+#endif
                     o.z.a[k] = zk;
                     const double t = zk * sgk;
                     const double xk = __builtin_fma(1.0, muk, t);
@@ -1224,11 +1254,17 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
                     if (x_out) x_out->a[k] = xk;
                     if (gx_out) gx_out->a[k] = gxk;
                 }
+#ifndef NM_X_LF_NO_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         };
         if (C.dim == DPL * 64 * W) pass(std::true_type{}); else pass(std::false_type{});
+#ifdef NM_X_LF_SUM2_UNPACKED
+        wave_sum2(acc, kacc);
+#else
         C.red.sum2(acc, kacc);
+#endif
         o.logp = C.dens.finish(acc);
         o.ke = 0.5 * kacc;
         return;
@@ -1493,7 +1529,7 @@ NM_DEV uint64_t stepsize_init(ChainCtx<DPL, W, Dens>& C, const Tile<DPL>& x) {
         Pt<DPL> o;
         const int sign = it == 0 ? 1 : dir;
         col.register_init(e0);
-        leapfrog(C, st, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+        leapfrog<DPL, W, Dens, 1>(C, st, o, (double)sign * C.sc.step_size * 1.0, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
         const double energy = o.ke - (o.logp + logdet);
         const double err = energy - e0;
         if (dens_status(C) != 0) {                              // `let LeapfrogResult::Ok(_) = .. else { .. return Ok(()) }` (adapt.rs:122-150)
@@ -2250,7 +2286,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             { const int es = fwd ? right_slot : left_slot;
               C.loadRef(E.z, C.edge_z(es)); C.loadRef(E.v, C.edge_v(es)); C.loadRef(E.g, C.edge_g(es)); }
 #endif
-            leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+            leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(E, O, sub_log_size)
             NM_MARK(C, 27)
@@ -2273,14 +2309,14 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
                 NM_MARK(C, 16)
-                leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                leapfrog<DPL, W, Dens, 2>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 17)
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_LEAF_ACCOUNT(O, E, wE)
                 if (stop != STOP_NONE) break;
                 // ---- odd leaf n + 1
                 NM_MARK(C, 18)
-                leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 19)
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
                 NM_LEAF_ACCOUNT(E, O, wO)
@@ -2395,7 +2431,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
                 NM_MARK(C, 16)
-                leapfrog(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                leapfrog<DPL, W, Dens, 2>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 17)
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
                 NM_LEAF_ACCOUNT(O, E, wE)
@@ -2416,7 +2452,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 }
                 // ---- odd leaf n + 1
                 NM_MARK(C, 18)
-                leapfrog(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+                leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 19)
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
                 NM_LEAF_ACCOUNT(E, O, wO)

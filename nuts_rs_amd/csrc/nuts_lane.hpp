@@ -1681,7 +1681,7 @@ NM_DEV void l_draw_end(LCtx<NP, LD>& C, uint64_t chain, uint64_t t_out, LAccept&
 // templates now: no code is generated for them)
 
 template <int NP>
-struct LaneShared {
+struct alignas(16) LaneShared {
 #if NM_LANE_PROF
     unsigned long long lp_clock;
 #endif

@@ -4,17 +4,20 @@
 // nuts_tile.hpp (rounds 2-3) keeps one wavefront per chain: 16 wavefronts of a block run the whole one-chain NUTS code at 128
 // registers each (321 spilled) and meet for the dense products — the matrix cores sat at 39 % busy for two rounds because every
 // round waits for the slowest of 16 branchy, spilling chain programs.  Here the mapping is north_star's:
-//   * a block of 16 wavefronts owns 16 chains and advances ALL of them by one density evaluation per round, in lockstep;
-//   * wavefront s owns ROWS 16 s .. 16 s + 15 of every vector of all 16 chains, in the C / D layout of v_mfma_f64_16x16x4_f64
-//     (lane (g, c) = (lane >> 4, lane & 15) holds rows 16 s + g + 4 r, r = 0 .. 3, of chain column c): the products' results
-//     land where the leapfrog's elementwise work wants them, nothing is spilled (a vector is 4 doubles per lane);
-//   * the tree — per chain, ragged, data dependent — is a per-chain STATE MACHINE advanced once per round by one lane of
-//     wavefront 0 (lane c = chain c: north_star's "one chain per lane" for everything scalar: energies, multinomial merges,
-//     U-turn decisions, the generator, the step-size adaptation), on sums the 16 wavefronts reduce stripe by stripe;
+//   * a block of EIGHT wavefronts (two per SIMD, 256 registers each) owns 16 chains and advances ALL of them by one density evaluation
+//     per round, in lockstep;
+//   * wavefront w owns the two 16-row stripes 2 w, 2 w + 1 of every vector of all 16 chains, in the C / D layout of v_mfma_f64_16x16x4_f64
+//     (lane (g, c) = (lane >> 4, lane & 15) holds rows 16 s + g + 4 r, r = 0 .. 3, of chain column c): the products' results land where the
+//     leapfrog's elementwise work wants them (a vector is 4 doubles per lane and stripe).  The kernel is NOT spill-free: rocprofv3 reports
+//     1224 B of scratch per lane (the state machines' and refresh units' out-of-line code; the product loops themselves keep their
+//     operands in registers) — the first build, 16 wavefronts with one stripe each at 128 registers, spilled 245 registers around every product;
+//   * the tree — per chain, ragged, data dependent — is a per-chain STATE MACHINE advanced once per round by ONE LANE: wavefronts 0 .. 3 run
+//     the machines of four chains each (lane c = chain c: north_star's "one chain per lane" for everything scalar: energies, multinomial
+//     merges, U-turn decisions, the generator, the step-size adaptation), on sums the eight wavefronts reduce stripe by stripe;
 //   * draws are NOT synchronised between the chains of a block: a chain that finishes its tree recomputes its chosen point,
 //     writes its draw and starts the next one while the others continue — every column of every product carries a chain;
-//   * the momentum refresh of the next draw (256 normals of the chain's ChaCha stream) is produced by wavefronts 1 .. 4 while
-//     wavefront 0 runs the state machines.
+//   * the momentum refresh of the next draw (256 normals of the chain's ChaCha stream) is produced by wavefronts 4 .. 7 (four refresh units)
+//     while wavefronts 0 .. 3 run the state machines.
 // A round = [P3: form the next input column] -> five products (U'z, U s, P x, U't, U s') -> [P1: finish the leapfrog, partial
 // sums] -> [stripe reduction] -> [P2: the chains' state machines].
 //
@@ -49,7 +52,7 @@ constexpr int GROUPS_PER_PASS = 4; // U-turn test groups (6 sums each) per pass
 constexpr int LOCK_MAXDEPTH = 11; // maxdepth + extra_doublings the kernel is laid out for (sums, pend table); the engine checks
 constexpr int MAX_GROUPS = LOCK_MAXDEPTH + 1;
 constexpr int NSUM = 8 + 6 * MAX_GROUPS;
-constexpr int NUNIT = 4;           // momentum-refresh units (wavefronts 1 .. NUNIT)
+constexpr int NUNIT = 4;           // momentum-refresh units (wavefronts 4 .. 4 + NUNIT - 1)
 constexpr int RF_P = 5;            // passes of the bulk ziggurat per chunk: 320 cells, one chunk for 256 samples and the cells their slow paths swallow
 
 // Development (-DNM_LOCK_PROF=1, tools/bench_k5.py): shader-clock cycles of wavefront 0 of block 0 between the phase marks of a round,
@@ -115,7 +118,7 @@ struct LkChain {
 
 struct PendL { double log_size; CandRef c; };
 
-struct LockShared {
+struct alignas(16) LockShared {
     double t[2][LROWS * LC];  // column tiles A, B (products' B operands); between the products and P3 both together: the stripes' partial sums
     double sums[LC][NSUM];    // reduced sums of the round, per chain
     double sig[LROWS], mu[LROWS], mul[LROWS], isig[LROWS];   // shared sigma, mean, mu_lr, 1 / sigma

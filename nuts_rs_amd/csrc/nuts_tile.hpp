@@ -57,7 +57,7 @@ struct TileMats {
     int dim_st, rank_st;     // 16-row stripes of dim / rank outputs
 };
 
-struct TileShared {
+struct alignas(16) TileShared {
     double zin[TD * TC];     // the chains' input columns; the second product of an apply accumulates in place
     double sbuf[TD * TC];    // S = U' z (first product of an apply) / y = P x
     double sig[TD], mu[TD];  // the shared DiagMassMatrix part (tile order of a one-wave chain)

@@ -171,11 +171,15 @@ if __name__ == "__main__":
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated case indices to run (every case is still generated: same cases as a full run; not with --scale)")
     a = ap.parse_args()
+    only = {int(x) for x in a.only.split(",") if x}
     rng = np.random.default_rng(a.seed)
     tally = {}
     for i in range(a.cases):
         s, logp, n, draws, eng, desc, transform = make_case(rng, a.scale)
+        if only and i not in only:
+            continue
         try:
             res = run_case(s, logp, n, draws, eng, rng, transform)
         except N.NutsAmdError as e:
