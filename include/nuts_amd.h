@@ -437,7 +437,7 @@ int nm_lowrank_test_estimate_mass_matrix(uint64_t rows, uint64_t n_draws, const 
 /* WHERE the built-in estimator runs.  The reference runs `compute_update` (src/transform/adapt/low_rank.rs:73-142) in the thread
  * that runs the chain; here the default (NM_LR_PLACE_AUTO) is the device that runs the chains: one 256-thread block per paused
  * chain works on the chain's window where the draw kernel left it (csrc/lowrank_device.hip, the block form of the same
- * algorithm: csrc/lowrank_block.hpp), for dim <= 256 and windows of <= 1024 draws; other shapes, and any estimator set with
+ * algorithm: csrc/lowrank_block.hpp), for dim <= 512 and windows of <= 1024 draws; other shapes, and any estimator set with
  * nm_engine_set_lowrank_estimator, run on host threads.  NM_LR_PLACE_HOST: always the host threads.  NM_LR_PLACE_DEVICE: the
  * device or NM_ERR_UNSUPPORTED at the first window it does not take.  The device form sums in another order than the host form:
  * the two agree to rounding on full-rank windows and within the reference algorithm's own conditioning on rank-deficient ones

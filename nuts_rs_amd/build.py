@@ -25,7 +25,10 @@ VARIANT_FLAGS = {"": []}
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed"]
+# -amdgpu-function-calls=false: NO out-of-line device calls (everything is inlined into its kernel).  All four code-generation incidents of
+# DESIGN §22 were in kernels that reach their special functions through s_swappc (the one-chain-per-block family); the kernel families
+# that always inlined them never had one.  Measured on K2 / K3 / K4's shard: the same speed to three digits (profiles/r05aa_no_calls_ab.txt).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-function-calls=false"]
 
 
 def _newer(target, deps):

@@ -331,12 +331,10 @@ struct Reducer {
     // so the answer is a compare and a ballot — no total is read out.  Same decision as sum_n + N scalar compares.
     template <int N>
     NM_DEV bool any_sign(double (&v)[N], bool neg) {
-#ifndef NM_X_ANYSIGN_UNPACKED
         if (NM_PACKED_SUMS && packed && W == 1 && !NM_CLUSTER_MODE) {
             const double pk = wave_sum_packed<N>(v);
             return __ballot(neg ? pk < 0. : pk > 0.) != 0ull;
         }
-#endif
         sum_n(v);
         bool any = false;
 #pragma unroll
@@ -536,17 +534,7 @@ NM_DEV double logaddexp(double a, double b) {
 //   exp_sl(x)       == dexp_impl(x) for every x
 //   log1p_unit(x)   == dlog1p_impl(x) for x in [0, 1] or NaN (what exp(-|d|) can be)
 NM_HD int dm_cvt_i32(double x) {           // v_cvt_i32_f64: saturating, NaN -> 0 (a C cast of an out-of-range value is undefined)
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NM_X_ASM_CVT)      // bisecting builds (1: plain asm, 2: volatile, 3: early-clobber output)
-    int n;
-#if NM_X_ASM_CVT == 2
-    asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));
-#elif NM_X_ASM_CVT == 3
-    asm("v_cvt_i32_f64 %0, %1" : "=&v"(n) : "v"(x));
-#else
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));
-#endif
-    return n;
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     // the compiler's own conversion of an operand clamped into range first (v_max_f64 / v_min_f64 return the other operand for a NaN):
     // defined for every double; operands that were in range — the only ones whose result is used — convert as before
     return (int)__builtin_fmin(__builtin_fmax(x, -2.0e9), 2.0e9);

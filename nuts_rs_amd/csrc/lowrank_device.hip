@@ -24,7 +24,7 @@ namespace {
 __device__ unsigned long long lrb_prof[16];
 #endif
 struct DevEx {
-    int tid; Small* S;
+    int tid; double* red; unsigned long long* redi;       // (the block's reduction cells: SmallT::red / redi)
 #ifdef NM_LRB_PROF
     unsigned long long last = 0;
     __device__ __forceinline__ void mark(int id) {
@@ -49,9 +49,9 @@ struct DevEx {
         for (size_t i = (size_t)tid; i < n; i += LRB_T) p += f(i);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off);
-        if ((tid & 63) == 0) S->red[tid >> 6] = p;
+        if ((tid & 63) == 0) red[tid >> 6] = p;
         __syncthreads();
-        return ((S->red[0] + S->red[1]) + S->red[2]) + S->red[3];
+        return ((red[0] + red[1]) + red[2]) + red[3];
     }
     // item i: *addr(i) = f(i, *addr(i)); four items in flight per thread (their loads before their stores)
     template <class FA, class F> __device__ __forceinline__ void rmw(size_t n, FA addr, F f) {
@@ -98,11 +98,11 @@ struct DevEx {
             const double ov = __shfl_xor(bv, off); const unsigned long long oi = __shfl_xor(bi, off);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if ((tid & 63) == 0) { S->red[4 + (tid >> 6)] = bv; S->redi[tid >> 6] = bi; }
+        if ((tid & 63) == 0) { red[4 + (tid >> 6)] = bv; redi[tid >> 6] = bi; }
         __syncthreads();
-        bv = S->red[4]; bi = S->redi[0];
+        bv = red[4]; bi = redi[0];
 #pragma unroll
-        for (int wv = 1; wv < 4; ++wv) { const double ov = S->red[4 + wv]; const unsigned long long oi = S->redi[wv]; if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+        for (int wv = 1; wv < 4; ++wv) { const double ov = red[4 + wv]; const unsigned long long oi = redi[wv]; if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
         val = bv; idx = (size_t)bi;
     }
 };
@@ -153,13 +153,14 @@ namespace nm { namespace lrb {
 // jobs[3 i] = {chain, first row of its window in lrwin, rows}.  Per job i: rows_out + i * rows * dp ((4 + rmax) rows of dp doubles),
 // vals2 + i * 2 * rmax, meta[3 i] = {chain, n_eig, ok}; *too_wide counts answers of rank > rmax.  sc (may be null): the chains'
 // scalars, where the answer's rank, log-determinant and LR_ANSWERED go.  vals_plain (may be null): [job][rmax] eigenvalues.
+template <size_t KM>
 __global__ __launch_bounds__(LRB_T) void lr_estimate_kernel(const uint64_t* jobs, uint64_t n_jobs, uint64_t dim, const double* lrwin, uint64_t lr_cap,
                                                            double gamma, double eigval_cutoff, double* scratch, uint64_t scratch_stride,
                                                            double* rows_out, uint64_t rows, uint64_t dp, double* vals2, uint64_t rmax, uint64_t* meta,
                                                            unsigned long long* too_wide, ChainScalars* sc, double* vals_plain) {
-    __shared__ Small S;
+    __shared__ SmallT<KM> S;                               // KM = 256: dim <= 256 (25 KiB: several blocks per compute unit); 512 beyond
     dm_init_lds();                                         // dlog's tables (the log-determinant)
-    DevEx ex{(int)threadIdx.x, &S};
+    DevEx ex{(int)threadIdx.x, S.red, S.redi};
     for (uint64_t job = blockIdx.x; job < n_jobs; job += gridDim.x) {
         const uint64_t c = jobs[3 * job], start = jobs[3 * job + 1], len = jobs[3 * job + 2];
         const double* win = lrwin + ((size_t)c * lr_cap + start) * 2 * dim;
@@ -195,8 +196,12 @@ size_t block_estimator_scratch_doubles(uint64_t dim, uint64_t n_max) { return sc
 hipError_t launch_estimate(unsigned grid, hipStream_t stream, const uint64_t* d_jobs, uint64_t n_jobs, uint64_t dim, const double* d_lrwin, uint64_t lr_cap,
                            double gamma, double eigval_cutoff, double* d_scratch, uint64_t scratch_stride, double* d_rows, uint64_t rows, uint64_t dp,
                            double* d_vals2, uint64_t rmax, uint64_t* d_meta, unsigned long long* d_too_wide, void* d_sc, double* d_vals_plain) {
-    hipLaunchKernelGGL(lr_estimate_kernel, dim3(grid), dim3(LRB_T), 0, stream, d_jobs, n_jobs, dim, d_lrwin, lr_cap, gamma, eigval_cutoff, d_scratch,
-                       scratch_stride, d_rows, rows, dp, d_vals2, rmax, d_meta, d_too_wide, (ChainScalars*)d_sc, d_vals_plain);
+    if (dim <= 256)
+        hipLaunchKernelGGL(lr_estimate_kernel<256>, dim3(grid), dim3(LRB_T), 0, stream, d_jobs, n_jobs, dim, d_lrwin, lr_cap, gamma, eigval_cutoff, d_scratch,
+                           scratch_stride, d_rows, rows, dp, d_vals2, rmax, d_meta, d_too_wide, (ChainScalars*)d_sc, d_vals_plain);
+    else
+        hipLaunchKernelGGL(lr_estimate_kernel<LRB_KMAX>, dim3(grid), dim3(LRB_T), 0, stream, d_jobs, n_jobs, dim, d_lrwin, lr_cap, gamma, eigval_cutoff, d_scratch,
+                           scratch_stride, d_rows, rows, dp, d_vals2, rmax, d_meta, d_too_wide, (ChainScalars*)d_sc, d_vals_plain);
     return hipGetLastError();
 }
 

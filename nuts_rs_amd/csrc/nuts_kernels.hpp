@@ -83,7 +83,7 @@ __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)
 #define NM_EDGES_IN_ACC 0
 #endif
 #ifndef NM_LF_FMA_FORM
-#define NM_LF_FMA_FORM 0          // the fused leapfrog's two fused multiply-adds: 0 inline asm, 1 volatile inline asm, 2 __builtin_fma (bisecting builds)
+#define NM_LF_FMA_FORM 0          // the fused leapfrog's two fused multiply-adds: 0 inline asm at the call sites of NM_X_ASM_SITES, 2 __builtin_fma everywhere
 #endif
 #ifndef NM_FUSED_LEAPFROG
 #define NM_FUSED_LEAPFROG 1        // 0: the leapfrog as three loops over the tile for every density (rounds 1-4; bisecting builds)
@@ -1216,30 +1216,13 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
                     // (v_fma_f64 spelled out: the source point's v and z stay live, and the compiler's two-address form — v_mov_b64 + v_fmac_f64 —
                     // costs an instruction more per fma; the same IEEE fused multiply-add)
                     double vh, zk;
-#if NM_LF_FMA_FORM == 0
-                    if constexpr ((NM_X_ASM_SITES >> SITE) & 1) {
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
+                    if constexpr (NM_LF_FMA_FORM == 0 && ((NM_X_ASM_SITES >> SITE) & 1)) {
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
                     } else {
-                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
+                        vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                        zk = __builtin_fma(epsilon, vh, s.z.a[k]);
                     }
-#elif NM_LF_FMA_FORM == 1
-                    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
-                    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
-#elif NM_LF_FMA_FORM == 3
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=&v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
-#elif NM_LF_FMA_FORM == 4
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
-                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
-#elif NM_LF_FMA_FORM == 5
-                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
-#else
-                    vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
-                    zk = __builtin_fma(epsilon, vh, s.z.a[k]);
-#endif
                     o.z.a[k] = zk;
                     const double t = zk * sgk;
                     const double xk = __builtin_fma(1.0, muk, t);
@@ -1254,17 +1237,11 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
                     if (x_out) x_out->a[k] = xk;
                     if (gx_out) gx_out->a[k] = gxk;
                 }
-#ifndef NM_X_LF_NO_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         };
         if (C.dim == DPL * 64 * W) pass(std::true_type{}); else pass(std::false_type{});
-#ifdef NM_X_LF_SUM2_UNPACKED
-        wave_sum2(acc, kacc);
-#else
         C.red.sum2(acc, kacc);
-#endif
         o.logp = C.dens.finish(acc);
         o.ke = 0.5 * kacc;
         return;

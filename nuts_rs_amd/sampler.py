@@ -503,7 +503,7 @@ class ChainBatch:
 
     def set_lowrank_estimator_place(self, place):
         """Where the built-in estimator runs (nm_engine_set_lowrank_estimator_place): 0 / "auto" the device where the block
-        algorithm takes the window (dim <= 256, <= 1024 draws), else host threads; 1 / "host"; 2 / "device" (or an error)."""
+        algorithm takes the window (dim <= 512, <= 1024 draws), else host threads; 1 / "host"; 2 / "device" (or an error)."""
         place = {"auto": 0, "host": 1, "device": 2}.get(place, place)
         check(_lib.load().nm_engine_set_lowrank_estimator_place(self._h, int(place)))
 

@@ -251,7 +251,8 @@ def twin_update(L, d, g, gamma, cutoff):
     return rc, int(ne.value), stds, mean, vals, vecs, mu
 
 
-@pytest.mark.parametrize("dim,n", [(1, 5), (5, 3), (8, 40), (20, 12), (37, 50), (64, 30), (64, 100), (128, 100), (130, 70), (256, 60)])
+@pytest.mark.parametrize("dim,n", [(1, 5), (5, 3), (8, 40), (20, 12), (37, 50), (64, 30), (64, 100), (128, 100), (130, 70), (256, 60),
+                                   (300, 40), (512, 24)])           # (dim > 256: the kernel built for the 512-column vectors, round 5)
 def test_estimator_kernel_is_its_twin_bit_for_bit(dim, n):
     """The estimator KERNEL (csrc/lowrank_device.hip: one 256-thread block per window) against its host twin (the same template
     code walked by one thread with the kernel's reduction trees): sigma, mean, mu, the eigenvalues, every eigenvector, the rank,
@@ -339,7 +340,8 @@ def test_lowrank_adaptation_device_estimator_bit_exact(oracle, case):
 
 def test_estimator_place_host_and_device_agree_statistically_and_unsupported_shapes(oracle):
     """NM_LR_PLACE_HOST keeps the estimator on the host threads (no device updates); NM_LR_PLACE_DEVICE refuses a shape the block
-    algorithm does not take (dim > 256) at the first window, NM_LR_PLACE_AUTO runs it on the host."""
+    algorithm does not take (dim > 512; 256 until round 5) at the first window, NM_LR_PLACE_AUTO runs it on the host — and takes the device
+    at dim 300, which rounds 3 - 4 left to the host threads."""
     rng = np.random.default_rng(8)
     logp = N.LogpSpec.mvn_precision(correlated_precision(rng, 24, 2)[0])
     s = lowrank_settings(num_chains=8, seed=3, num_tune=100)
@@ -353,8 +355,14 @@ def test_estimator_place_host_and_device_agree_statistically_and_unsupported_sha
         eps[place] = st["step_size"][100:].mean()
         b.close()
     assert abs(np.log(eps["host"] / eps["device"])) < np.log(1.3)
-    big = N.LogpSpec.iid_normal(300, 1.0)
     s = lowrank_settings(num_chains=2, seed=3, num_tune=40)
+    mid = N.LogpSpec.iid_normal(300, 1.0)
+    b = N.ChainBatch(s, mid, 2)
+    b.set_position(b.init_positions_uniform())
+    b.draw_many(45)
+    assert b.lowrank_device_updates() > 0                 # auto: the device (dim <= 512)
+    b.close()
+    big = N.LogpSpec.iid_normal(600, 1.0)
     b = N.ChainBatch(s, big, 2)
     b.set_position(b.init_positions_uniform())
     b.draw_many(45)

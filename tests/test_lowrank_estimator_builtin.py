@@ -137,7 +137,7 @@ def correlated_window(rng, dim, n, rank):
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("dim,n,rank", [(12, 60, 2), (30, 90, 3), (64, 200, 5), (128, 300, 6), (256, 400, 8)])
+@pytest.mark.parametrize("dim,n,rank", [(12, 60, 2), (30, 90, 3), (64, 200, 5), (128, 300, 6), (256, 400, 8), (320, 450, 8)])
 def test_builtin_compute_update_vs_literal_reference_algorithm_full_rank(dim, n, rank, impl):
     from oracle import lowrank as LR
     L = _lib.load()
@@ -160,7 +160,7 @@ def test_builtin_compute_update_vs_literal_reference_algorithm_full_rank(dim, n,
 
 
 @pytest.mark.parametrize("dim,n,rank", [(64, 10, 4), (64, 30, 4), (64, 60, 4), (128, 10, 6), (128, 50, 6), (128, 70, 6), (128, 120, 6),
-                                        (256, 30, 8), (256, 130, 8), (256, 200, 8)])
+                                        (256, 30, 8), (256, 130, 8), (256, 200, 8), (384, 40, 8)])
 @pytest.mark.parametrize("impl", IMPLS)
 def test_builtin_compute_update_vs_literal_reference_algorithm_rank_deficient(dim, n, rank, impl):
     """Windows with fewer draws than dims — every early window of a LowRankNutsSettings warm-up at these dims."""

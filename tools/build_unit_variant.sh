@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../nuts_rs_amd/csrc"
 TAG=$1; EXTRA=$2; shift 2
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-pass-failed $EXTRA"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-pass-failed -mllvm -amdgpu-function-calls=false $EXTRA"
 mkdir -p build/$TAG
 EXCL=""
 for u in "$@"; do /opt/rocm/bin/hipcc $FLAGS -c $u.hip -o build/$TAG/$u.o & EXCL="$EXCL\|build/$u.o"; done
