@@ -14,21 +14,25 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libnuts_amd.so")
 # (the slowest translation units first: the build is as long as its longest chain of jobs on the available cores)
-UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lockstep.hip", "kern_lr_mvn_prec.hip", "kern_kin_mvn_prec.hip", "kern_mvn_prec.hip",
-         "kern_lr_iid_normal.hip", "kern_lr_diag_normal.hip", "kern_lr_funnel.hip", "kern_lr_host_cb.hip",
-         "kern_kin_iid_normal.hip", "kern_kin_diag_normal.hip", "kern_kin_funnel.hip", "kern_kin_host_cb.hip",
-         "kern_lane.hip", "kern_lane_kin.hip", "kern_iid_normal.hip", "kern_diag_normal.hip", "kern_funnel.hip", "kern_host_cb.hip", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip",
-         "kern_eight_schools.hip", "kern_lr_eight_schools.hip", "kern_kin_eight_schools.hip", "math_seam.hip", "probe_bw.hip", "pooled_reduce.hip", "lowrank_device.hip",
-         "lowrank_host.cpp"]
+UNITS = ["kern_tile_mvn_prec.hip", "kern_tile_mvn_diag.hip", "kern_lockstep.hip", "kern_lr_mvn_prec.hip@large", "kern_lr_mvn_prec.hip@small",
+         "kern_kin_mvn_prec.hip@large", "kern_kin_mvn_prec.hip@small", "kern_mvn_prec.hip@large", "kern_mvn_prec.hip@small", "kern_lr_iid_normal.hip@large",
+         "kern_lr_iid_normal.hip@small", "kern_lr_diag_normal.hip@large", "kern_lr_diag_normal.hip@small", "kern_lr_funnel.hip@large", "kern_lr_funnel.hip@small",
+         "kern_lr_host_cb.hip@large", "kern_lr_host_cb.hip@small", "kern_kin_iid_normal.hip@large", "kern_kin_iid_normal.hip@small", "kern_kin_diag_normal.hip@large",
+         "kern_kin_diag_normal.hip@small", "kern_kin_funnel.hip@large", "kern_kin_funnel.hip@small", "kern_kin_host_cb.hip@large", "kern_kin_host_cb.hip@small", "kern_lane.hip",
+         "kern_lane_kin.hip", "kern_iid_normal.hip@large", "kern_iid_normal.hip@small", "kern_diag_normal.hip@large", "kern_diag_normal.hip@small", "kern_funnel.hip@large",
+         "kern_funnel.hip@small", "kern_host_cb.hip@large", "kern_host_cb.hip@small", "nuts_engine.hip", "kern_cluster.hip", "kern_cluster_kin.hip", "kern_eight_schools.hip@inl",
+         "kern_lr_eight_schools.hip@inl", "kern_kin_eight_schools.hip@inl", "math_seam.hip", "probe_bw.hip", "pooled_reduce.hip", "lowrank_device.hip", "lowrank_host.cpp"]
 # (lowrank_host.cpp holds both ISA builds of the host estimator in ONE translation unit: per-function target attributes, see there)
-VARIANT_FLAGS = {"": []}
+# Variants of a unit ("file@variant": its own object, the flags below).  A density's one-chain kernels are TWO units from one source
+# (nuts_launch.hpp NM_TU_PART): "small" = the tilings of <= 4 doubles per lane + the small-chain kernels with EVERY special function inlined — no
+# out-of-line device call (fourth incident; the scan below rejects an s_swappc_b64 there) —, "large" = the 8- and 16-doubles tilings with
+# the calls (inlined they cost K2 11 %); "inl" = a unit that only has small tilings (8 schools).
+VARIANT_FLAGS = {"": [], "small": ["-DNM_TU_PART=1", "-DNM_DETMATH_INLINE=1"], "large": ["-DNM_TU_PART=2"], "inl": ["-DNM_DETMATH_INLINE=1"]}
+NO_CALL_VARIANTS = ("small", "inl")
 HEADERS = ["nuts_kernels.hpp", "nuts_launch.hpp", "dev_math.hpp", "detmath_tables.hpp", "zig_tables.hpp", "nuts_group.hpp", "nuts_group_impl.hpp", "nuts_tile.hpp", os.path.join("..", "..", "include", "nuts_amd.h")]
 # -ffp-contract=off: FMAs only where the reference writes mul_add
 # -Wno-pass-failed: "loop not unrolled" remarks of the matrix-core kernel's partially unrolled product loops (a diagnostic only)
-# -amdgpu-function-calls=false: NO out-of-line device calls (everything is inlined into its kernel).  All four code-generation incidents of
-# DESIGN §22 were in kernels that reach their special functions through s_swappc (the one-chain-per-block family); the kernel families
-# that always inlined them never had one.  Measured on K2 / K3 / K4's shard: the same speed to three digits (profiles/r05aa_no_calls_ab.txt).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-function-calls=false"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed"]
 
 
 def _newer(target, deps):
@@ -81,7 +85,7 @@ class StoreHazardError(RuntimeError):
     """A translation unit's device assembly has a buffer store whose data registers are rewritten inside the hazard window."""
 
 
-def _scan_store_hazards(asm_path, what):
+def _scan_store_hazards(asm_path, what, allow_calls=True):
     """tools/check_store_hazard.py's rule, both modes, on one unit's device assembly: the build fails on an unguarded
     instance instead of leaving it to a parity suite that does not travel with a user's module build.  The rule lives in ONE place: the
     tool is executed, not re-implemented (it ships in the repo next to this package; a wheel without tools/ skips the scan and says so)."""
@@ -112,7 +116,16 @@ def _scan_store_hazards(asm_path, what):
             raise StoreHazardError(f"{what}: a software-managed VALU hazard without its wait states (python tools/check_valu_hazards.py):\n" + r.stdout[-3000:])
 
 
-def _compile_scanned(hipcc, flags, src, out, what, link=False):
+    # the policy of §22's fourth incident as a scan: no out-of-line device call in the units of the small tilings (and in user modules of them)
+    if not allow_calls:
+        with open(asm_path) as f:
+            n_calls = sum(1 for line in f if line.lstrip().startswith("s_swappc_b64"))
+        if n_calls:
+            raise StoreHazardError(f"{what}: {n_calls} out-of-line device call(s) (s_swappc_b64) in a unit that is built without them "
+                                   "(-DNM_DETMATH_INLINE=1; DESIGN §22)")
+
+
+def _compile_scanned(hipcc, flags, src, out, what, link=False, allow_calls=True):
     """Compile `src` (one hipcc run: -save-temps keeps the device assembly the object is assembled from), scan it, drop the temporaries."""
     import shutil
     import tempfile
@@ -125,7 +138,7 @@ def _compile_scanned(hipcc, flags, src, out, what, link=False):
         if not asms and not src.endswith(".cpp"):
             raise RuntimeError(f"{what}: no device assembly among the compiler's temporaries (-save-temps=obj)")
         for a in asms:
-            _scan_store_hazards(a, what)
+            _scan_store_hazards(a, what, allow_calls)
         os.replace(prod, out)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -141,12 +154,12 @@ def build(force=False, verbose=False, extra_flags=(), scan=True):
     def compile_unit(u):
         src, obj = _src(u), _obj(u)
         if force or _unit_stale(u):
-            host_only = VARIANT_FLAGS[u.partition("@")[2]] if u.startswith("lowrank_host.cpp") else []
-            flags = FLAGS + host_only + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
+            variant = u.partition("@")[2]
+            flags = FLAGS + VARIANT_FLAGS[variant] + list(extra_flags) + (["-Rpass-analysis=kernel-resource-usage"] if verbose else [])
             if verbose:
                 print(" ".join([hipcc] + flags + ["-c", src, "-o", obj]), file=sys.stderr)
             if scan and src.endswith(".hip"):
-                _compile_scanned(hipcc, flags, src, obj, os.path.basename(src))
+                _compile_scanned(hipcc, flags, src, obj, os.path.basename(src) + ("@" + variant if variant else ""), allow_calls=variant not in NO_CALL_VARIANTS)
             else:
                 subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
         return obj
@@ -209,12 +222,14 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         if dim > 10:
             raise ValueError("lane forms exist for dim <= 10")
         extra_flags = list(extra_flags) + [f"-DNM_MODULE_LANE_DENSITY={lane_struct}"]
-    # The special functions (nm::dexp / dlog / dlog1p, merge_math) are INLINED in every module: a user functor must not reach them through a
-    # call from a several-chains-per-wavefront kernel (tools/check_divergent_calls.py rejects it), and since round 5 the
-    # one-chain kernels of a module are built the same way — the fourth incident of §22 includes a module whose out-of-line build reported
-    # a wrong energy statistic while the inlined build of the same sources is bit-exact (profiles/r05z_module_variants.txt); a module is
-    # compiled on the USER's machine, where the engine's parity suite does not run.
-    extra_flags = list(extra_flags) + ["-DNM_DETMATH_INLINE=1"]
+    # The special functions (nm::dexp / dlog / dlog1p, merge_math, ...) are INLINED in a module of a several-chains-per-wavefront form (a user functor
+    # must not reach them through a call there: DESIGN §22, tools/check_divergent_calls.py) and, since round 5, in a module of a small tiling
+    # (<= 4 doubles per lane) exactly as in the library's own units of those tilings: §22's fourth incident includes a dim-40 module whose
+    # out-of-line build reported a wrong energy statistic while the inlined build of the same sources is bit-exact
+    # (profiles/r05z_module_variants.txt), and a module is compiled on the USER's machine, where the engine's parity suite does not run.
+    no_calls = bool(group_struct or lane_struct) or dpl <= 4
+    if no_calls:
+        extra_flags = list(extra_flags) + ["-DNM_DETMATH_INLINE=1"]
     vbits = (1 if "low_rank" in variants else 0) | (2 if "kinetic" in variants else 0)
     if vbits:
         if dim > 4096:
@@ -225,7 +240,7 @@ def build_density_module(header, struct_name, dim, out, dims_per_lane=0, waves_p
         "-shared", f"-DNM_MODULE_DENSITY={struct_name}", f'-DNM_MODULE_HEADER="{header}"', f"-DNM_MODULE_DPL={dpl}",
         f"-DNM_MODULE_W={w}", "-I", CSRC, "-I", os.path.join(HERE, "..", "include")]
     # (the user's code is compiled into the same register-capped kernels: its assembly goes through the same scan as the engine's own)
-    _compile_scanned(hipcc, flags, os.path.join(CSRC, "density_module.hip"), os.path.abspath(out), f"density module {struct_name}", link=True)
+    _compile_scanned(hipcc, flags, os.path.join(CSRC, "density_module.hip"), os.path.abspath(out), f"density module {struct_name}", link=True, allow_calls=not no_calls)
     return out
 
 

@@ -438,7 +438,10 @@ template <bool U> static __host__ __device__ __forceinline__ double dexp_impl(do
 template <bool U> static __host__ __device__ __forceinline__ double dlog_impl(double x);
 template <bool U> static __host__ __device__ __forceinline__ double dlog1p_impl(double x);
 #ifndef NM_DETMATH_INLINE
-#define NM_DETMATH_INLINE 0      // 1: exp / ln / ln_1p inlined at every call site (tuning builds; larger code, no call-boundary waits)
+#define NM_DETMATH_INLINE 0      // 1: exp / ln / ln_1p / merge_math / sin-cos / expm1 inlined at every call site: NO out-of-line device call in the unit.
+                                 // The build sets it for the kernels of the small tilings (<= 4 doubles per lane: nuts_launch.hpp NM_TU_PART 1; DESIGN §22,
+                                 // fourth incident: every instantiation that has gone wrong was one of them) and for user modules of those tilings; the
+                                 // 8- and 16-doubles tilings keep the calls (inlined, K2 loses 11 %: profiles/r05ac_inline_all_ab.txt)
 #endif
 #if NM_DETMATH_INLINE
 #define NM_DM_CALL __forceinline__
@@ -682,7 +685,7 @@ NM_HD MergeOut merge_math_impl(double a, double b, uint32_t is_main, uint32_t w_
     o.flags = (take && !fatal ? 1u : 0u) | (draws ? 2u : 0u) | (fatal ? 4u : 0u);
     return o;
 }
-static __device__ __noinline__ MergeOut merge_math(double a, double b, uint32_t is_main, uint32_t w_lo, uint32_t w_hi) { return merge_math_impl(a, b, is_main, w_lo, w_hi); }
+static __device__ NM_DM_CALL MergeOut merge_math(double a, double b, uint32_t is_main, uint32_t w_lo, uint32_t w_hi) { return merge_math_impl(a, b, is_main, w_lo, w_hi); }
 
 // exp(x) - 1 for the isokinetic momentum refresh (reference f64::exp_m1, transformed_hamiltonian.rs:800-801): the same
 // operation sequence as oracle/nmo_math.hpp det_expm1 (Taylor series to x^14 for |x| <= 0.35, else exp(x) - 1)
@@ -706,7 +709,7 @@ static __host__ __device__ __forceinline__ double dexpm1_impl(double x) {
 }
 // (out of line for the one-chain kernels; kernels with several chains per wavefront use dexpm1_impl<true>: nothing out of line under a
 // branch that is not uniform over the wavefront)
-static __host__ __device__ __noinline__ double dexpm1(double x) { return dexpm1_impl<false>(x); }
+static __host__ __device__ NM_DM_CALL double dexpm1(double x) { return dexpm1_impl<false>(x); }
 
 // sin / cos of a step size (the ExactNormal trajectory kind; reference f64::sin / f64::cos, src/math/util.rs:580-581):
 // Cody-Waite reduction by pi/2 in two fma steps and the classic minimax kernels on [-pi/4, pi/4]; the same operation
@@ -740,7 +743,7 @@ static __host__ __device__ __forceinline__ double2 dsincos_impl(double x) {     
 }
 // out of line for the one-chain kernels (every lane of the wavefront calls it together); kernels with several chains per wavefront call
 // dsincos_impl: no out-of-line call under a branch that is not uniform over the wavefront
-static __host__ __device__ __noinline__ double2 dsincos(double x) { return dsincos_impl(x); }
+static __host__ __device__ NM_DM_CALL double2 dsincos(double x) { return dsincos_impl(x); }
 
 NM_DEV bool is_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 NM_DEV double clampd(double v, double lo, double hi) {   // f64::clamp: NaN stays NaN

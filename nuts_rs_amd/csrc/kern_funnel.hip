@@ -1,7 +1,5 @@
 // kern_funnel.hip — nuts_draw_kernel / nuts_init_kernel instantiations for the Funnel density (own TU: parallel build)
 #include "nuts_launch.hpp"
 namespace nm {
-hipError_t launch_funnel(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
-    return launch_d<Funnel>(dpl, w, kind, P, grid, stream, occ);
-}
+NM_DEFINE_LAUNCH(launch_funnel, Funnel)
 }  // namespace nm

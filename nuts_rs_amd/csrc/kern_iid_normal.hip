@@ -1,7 +1,5 @@
 // kern_iid_normal.hip — nuts_draw_kernel / nuts_init_kernel instantiations for the IidNormal density (own TU: parallel build)
 #include "nuts_launch.hpp"
 namespace nm {
-hipError_t launch_iid_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
-    return launch_d<IidNormal>(dpl, w, kind, P, grid, stream, occ);
-}
+NM_DEFINE_LAUNCH(launch_iid_normal, IidNormal)
 }  // namespace nm

@@ -2,7 +2,5 @@
 // nm_settings.trajectory_kind = NM_TRAJ_EXACT_NORMAL / NM_TRAJ_MICROCANONICAL); own TU: parallel build
 #include "nuts_launch.hpp"
 namespace nm {
-hipError_t launch_diag_normal_kin(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
-    return launch_d<KinWrap<DiagNormal>>(dpl, w, kind, P, grid, stream, occ);
-}
+NM_DEFINE_LAUNCH(launch_diag_normal_kin, KinWrap<DiagNormal>)
 }  // namespace nm

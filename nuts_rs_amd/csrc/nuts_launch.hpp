@@ -6,6 +6,14 @@
 #include "nuts_kernels.hpp"
 #include "nuts_group.hpp"
 
+// A density's kernels are compiled as TWO translation units from one source (nuts_rs_amd/build.py, units "x.hip@small" / "x.hip@large"):
+//   NM_TU_PART 1: the tilings of <= 4 doubles per lane and the small-chain kernels, special functions inlined (NM_DETMATH_INLINE = 1); it also
+//                 holds the entry point, which hands the larger tilings to part 2;
+//   NM_TU_PART 2: the tilings of 8 and 16 doubles per lane, special functions out of line;
+//   NM_TU_PART 0: everything in one unit (tools/build_unit_variant.sh, user modules: one tiling each).
+#ifndef NM_TU_PART
+#define NM_TU_PART 0
+#endif
 namespace nm {
 enum KernelKind { K_INIT, K_DRAW, K_QUERY,      // K_QUERY: resident blocks per CU of the draw kernel
                   K_GROUP_DRAW, K_GROUP_TUNE, K_GROUP_QUERY,    // the small-chain kernels of nuts_group.hpp (dim <= 64): sampling / warm-up
@@ -42,9 +50,14 @@ inline hipError_t launch_group(KernelKind kind, const KParams& P, unsigned grid_
 #undef NM_LAUNCH_GROUP_NS
 // grid = number of blocks (one block of 64*W threads = one resident chain); for K_QUERY *occ receives
 // hipOccupancyMaxActiveBlocksPerMultiprocessor of the draw kernel
+inline bool is_group_kind(KernelKind kind) { return kind == K_GROUP_DRAW || kind == K_GROUP_TUNE || kind == K_GROUP_QUERY || kind == K_GROUP_DRAW_ROOMY || kind == K_GROUP_TUNE_ROOMY; }
 template <int DPL, int W, class Dens>
 inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_blocks, hipStream_t stream, int* occ) {
-    if (kind == K_GROUP_DRAW || kind == K_GROUP_TUNE || kind == K_GROUP_QUERY || kind == K_GROUP_DRAW_ROOMY || kind == K_GROUP_TUNE_ROOMY) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
+#if NM_TU_PART != 2
+    if (is_group_kind(kind)) return launch_group<Dens>(kind, P, grid_blocks, stream, occ);
+#else
+    if (is_group_kind(kind)) return hipErrorInvalidValue;      // (the small-chain kernels live in part 1)
+#endif
     if (kind == K_QUERY) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, nuts_draw_kernel<DPL, W, Dens>, 64 * W, 0);
     dim3 grid(grid_blocks), block(64 * W);
     if (kind == K_INIT) hipLaunchKernelGGL((nuts_init_kernel<DPL, W, Dens>), grid, block, 0, stream, P);
@@ -52,7 +65,7 @@ inline hipError_t launch_t(KernelKind kind, const KParams& P, unsigned grid_bloc
     return hipGetLastError();
 }
 // supported tilings: W = 1: DPL 2,4,8,16 (dim <= 1024); W = 2: DPL 8,16 (dim <= 2048); W = 4: DPL 4,16 (dim <= 4096)
-template <class Dens>
+template <class Dens, int PART = NM_TU_PART>          // (PART: the two units' instantiations are different functions)
 inline hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ) {
     switch (w * 100 + dpl) {
 #ifdef NM_DEV_ONLY_K2
@@ -62,21 +75,39 @@ inline hipError_t launch_d(int dpl, int w, KernelKind kind, const KParams& P, un
     case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
     default: return hipErrorInvalidValue;
 #else
+#if NM_TU_PART != 2
     case 102: return launch_t<2, 1, Dens>(kind, P, grid, stream, occ);
     case 104: return launch_t<4, 1, Dens>(kind, P, grid, stream, occ);
+    case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
+#endif
+#if NM_TU_PART != 1
     case 108: return launch_t<8, 1, Dens>(kind, P, grid, stream, occ);
     case 116: return launch_t<16, 1, Dens>(kind, P, grid, stream, occ);
     case 208: return launch_t<8, 2, Dens>(kind, P, grid, stream, occ);
     case 216: return launch_t<16, 2, Dens>(kind, P, grid, stream, occ);
-    case 404: return launch_t<4, 4, Dens>(kind, P, grid, stream, occ);
     case 416:   // 138 KiB of LDS already: no room for a density that keeps a block-visible vector there
         if constexpr (!Dens::kNeedsLdsVector) return launch_t<16, 4, Dens>(kind, P, grid, stream, occ);
         else return hipErrorInvalidValue;
+#endif
 #endif
     }
     return hipErrorInvalidValue;
 }
 
+// the entry point of a density's kernels, in kern_<density>.hip: NM_DEFINE_LAUNCH(launch_x, Density)
+#define NM_LAUNCH_ARGS int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ
+#if NM_TU_PART == 1
+#define NM_DEFINE_LAUNCH(name, ...)                                                                                       \
+    hipError_t name##_large(NM_LAUNCH_ARGS);                                                                              \
+    hipError_t name(NM_LAUNCH_ARGS) {                                                                                     \
+        if (dpl <= 4 || is_group_kind(kind)) return launch_d<__VA_ARGS__>(dpl, w, kind, P, grid, stream, occ);            \
+        return name##_large(dpl, w, kind, P, grid, stream, occ);                                                          \
+    }
+#elif NM_TU_PART == 2
+#define NM_DEFINE_LAUNCH(name, ...) hipError_t name##_large(NM_LAUNCH_ARGS) { return launch_d<__VA_ARGS__>(dpl, w, kind, P, grid, stream, occ); }
+#else
+#define NM_DEFINE_LAUNCH(name, ...) hipError_t name(NM_LAUNCH_ARGS) { return launch_d<__VA_ARGS__>(dpl, w, kind, P, grid, stream, occ); }
+#endif
 // one definition per density, in kern_<density>.hip
 hipError_t launch_iid_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
 hipError_t launch_diag_normal(int dpl, int w, KernelKind kind, const KParams& P, unsigned grid, hipStream_t stream, int* occ);
