@@ -43,6 +43,14 @@ struct DevEx {
         if (tid == 0) f();
         __syncthreads();
     }
+    // thread 0 runs g while the threads of the OTHER wavefronts run f over n independent items (g and f touch disjoint data: the QL iteration
+    // on the tridiagonal / the application of the previous sweeps to the eigenvector matrix)
+    template <class G, class F> __device__ __forceinline__ void split(G g, size_t n, F f) {
+        __syncthreads();
+        if (tid == 0) g();
+        else if (tid >= 64) for (size_t i = (size_t)tid - 64; i < n; i += LRB_T - 64) f(i);
+        __syncthreads();
+    }
     template <class F> __device__ __forceinline__ double sum(size_t n, F f) {
         __syncthreads();
         double p = 0.0;
@@ -112,6 +120,7 @@ struct SimEx {
     void mark(int) {}
     template <class F> void par(size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
     template <class F> void one(F f) { f(); }
+    template <class G, class F> void split(G g, size_t n, F f) { g(); for (size_t i = 0; i < n; ++i) f(i); }
     template <class F> double sum(size_t n, F f) {
         double p[LRB_T];
         for (int t = 0; t < LRB_T; ++t) p[t] = 0.0;
