@@ -61,15 +61,16 @@ struct DevEx {
         __syncthreads();
         return ((red[0] + red[1]) + red[2]) + red[3];
     }
-    // item i: *addr(i) = f(i, *addr(i)); four items in flight per thread (their loads before their stores)
+    // item i: *addr(i) = f(i, *addr(i)); RMW_N items in flight per thread (their loads before their stores)
+    static constexpr int RMW_N = 4;          // (16 measured: no faster, profiles/r05ag_*)
     template <class FA, class F> __device__ __forceinline__ void rmw(size_t n, FA addr, F f) {
         __syncthreads();
-        for (size_t i = (size_t)tid; i < n; i += 4 * LRB_T) {
-            double* p[4]; double v[4];
+        for (size_t i = (size_t)tid; i < n; i += RMW_N * LRB_T) {
+            double* p[RMW_N]; double v[RMW_N];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (i + c * LRB_T < n) { p[c] = addr(i + c * LRB_T); v[c] = *p[c]; }
+            for (int c = 0; c < RMW_N; ++c) if (i + c * LRB_T < n) { p[c] = addr(i + c * LRB_T); v[c] = *p[c]; }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (i + c * LRB_T < n) *p[c] = f(i + c * LRB_T, v[c]);
+            for (int c = 0; c < RMW_N; ++c) if (i + c * LRB_T < n) *p[c] = f(i + c * LRB_T, v[c]);
         }
         __syncthreads();
     }
