@@ -74,6 +74,22 @@ struct DevEx {
         }
         __syncthreads();
     }
+    // the same over a rows x cols grid of items, *addr(k, j) = f(k, j, *addr(k, j)): a wavefront takes a column at a time (its lanes rows k = lane,
+    // lane + 64, ...: neighbouring addresses in a column-major matrix), four rows in flight per lane; no division by the grid's shape
+    template <class FA, class F> __device__ __forceinline__ void rmw2(size_t rows, size_t cols, FA addr, F f) {
+        __syncthreads();
+        const size_t lane = (size_t)(tid & 63);
+        for (size_t j = (size_t)(tid >> 6); j < cols; j += LRB_T / 64) {
+            for (size_t k = lane; k < rows; k += 4 * 64) {
+                double* p[4]; double v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (k + c * 64 < rows) { p[c] = addr(k + c * 64, j); v[c] = *p[c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (k + c * 64 < rows) *p[c] = f(k + c * 64, j, v[c]);
+            }
+        }
+        __syncthreads();
+    }
     // out(j, sum_k f(k, j)) for j < ncols, k < len: one wavefront per column (four columns at a time), lane l sums k = l, l + 64, ...
     // then the butterfly
     template <class F, class FO> __device__ __forceinline__ void col_dots(size_t ncols, size_t len, F f, FO out) {
@@ -122,6 +138,9 @@ struct SimEx {
     template <class F> void par(size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
     template <class F> void one(F f) { f(); }
     template <class G, class F> void split(G g, size_t n, F f) { g(); for (size_t i = 0; i < n; ++i) f(i); }
+    template <class FA, class F> void rmw2(size_t rows, size_t cols, FA addr, F f) {
+        for (size_t j = 0; j < cols; ++j) for (size_t k = 0; k < rows; ++k) { double* p = addr(k, j); *p = f(k, j, *p); }
+    }
     template <class F> double sum(size_t n, F f) {
         double p[LRB_T];
         for (int t = 0; t < LRB_T; ++t) p[t] = 0.0;
