@@ -316,6 +316,15 @@ class ChainBatch:
         h = C.c_void_p()
         check(L.nm_engine_create(C.byref(self._cs), C.byref(self._cl), self.n_chains, C.byref(cfg), C.byref(h)))
         self._h = h
+        if logp.kind < LOGP_MODULE and os.environ.get("NUTS_AMD_SELFTEST", "1") != "0":
+            # every kernel instantiation has its own known answer (selftest_instantiations.json, oracle-generated data): the runs of the ONE
+            # instantiation this engine launches are checked the first time a process creates such an engine (0.1 - 0.3 s)
+            from . import selftest
+            try:
+                selftest.first_use(self, device=device)
+            except BaseException:
+                self.close()
+                raise
 
     def close(self):
         if getattr(self, "_h", None):

@@ -20,80 +20,24 @@ from helpers import STAT_FIELDS_EXACT, oracle_settings
 
 pytestmark = pytest.mark.gpu
 
-TILINGS = [(2, 1), (4, 1), (8, 1), (16, 1), (8, 2), (16, 2), (4, 4), (16, 4)]
-FAMILIES = ["nuts", "lr_frozen", "lr_adapt", "exact", "micro", "mclmc", "lr_mclmc"]
+from nuts_rs_amd import selftest_cases as SC
+
+# (the cases live in the package — nuts_rs_amd/selftest_cases.py — because the library's self-test runs the same ones against the oracle's
+# answers as data: both ends of every tiling's range of dims since round 6)
 
 
 def _cases():
-    out = []
-    for dens in ("iid", "diag", "funnel", "mvn", "schools"):
-        for (d, w) in TILINGS:
-            cap = d * 64 * w
-            if dens == "schools" and (d, w) != (2, 1):
-                continue
-            if dens == "mvn" and cap > 2048:
-                continue
-            for fam in FAMILIES:
-                if fam in ("lr_adapt", "lr_mclmc") and cap > 256:   # the device estimator's range (the oracle runs its twin); beyond it: test_gpu_lowrank, test_gpu_mclmc
-                    continue
-                # full tiles on every second tiling for the densities whose kernels have a full-tile path, ragged tiles otherwise
-                full = (TILINGS.index((d, w)) % 2 == 1) and dens in ("iid", "diag", "mvn")
-                dim = 10 if dens == "schools" else (cap if full else cap - 3)
-                if dens == "mvn":
-                    dim = min(dim, 700)                      # a dense precision matrix: O(dim^2) per leapfrog in the oracle
-                out.append(pytest.param(dens, fam, d, w, dim, id=f"{dens}-{fam}-{d}x{w}-dim{dim}"))
-    return out
+    return [pytest.param(c, id=SC.case_id(c)) for c in SC.cases()]
 
 
-def _logp(dens, dim, seed):
-    r = np.random.default_rng(seed)
-    if dens == "iid":
-        return N.LogpSpec.iid_normal(dim, float(r.normal()))
-    if dens == "diag":
-        return N.LogpSpec.diag_normal(np.exp(r.uniform(-2, 2, dim)))
-    if dens == "funnel":
-        return N.LogpSpec.funnel(dim)
-    if dens == "schools":
-        return N.LogpSpec.eight_schools()
-    a = r.normal(size=(dim, 8))
-    p = a @ a.T / 8 + np.eye(dim)
-    return N.LogpSpec.mvn_precision((p + p.T) / 2)
-
-
-@pytest.mark.parametrize("dens,fam,dpl,wpc,dim", _cases())
-def test_instantiation_bit_exact(oracle, dens, fam, dpl, wpc, dim):
+@pytest.mark.parametrize("case", _cases())
+def test_instantiation_bit_exact(oracle, case):
     O = oracle
-    n, seed = 3, 1000 + 17 * dpl + wpc
-    num_tune = 40 if dim > 600 else 70
-    draws = num_tune + 10
-    kw = dict(num_chains=n, seed=seed, num_tune=num_tune)
-    transform = None
-    if fam in ("mclmc", "lr_mclmc"):
-        mk = N.DiagMclmcSettings if fam == "mclmc" else N.LowRankMclmcSettings
-        if fam == "lr_mclmc":
-            kw["num_tune"] = num_tune = 100
-            draws = 110
-            transform = "adapt"
-        s = mk(step_size=0.4, momentum_decoherence_length=3.0, trajectory_kind=1, dynamic_step_size=True, subsample_frequency=0.5, **kw)
-    elif fam in ("lr_frozen", "lr_adapt"):
-        if fam == "lr_adapt":
-            kw["num_tune"] = num_tune = 100
-            draws = 110
-        s = N.LowRankNutsSettings(freeze_transform=(fam == "lr_frozen"), maxdepth=6, **kw)
-        if fam == "lr_adapt":
-            s.adapt_options.mass_matrix_update_freq = 5
-            transform = "adapt"
-        else:
-            r = np.random.default_rng(seed + 1)
-            rank = min(dim, 5)
-            vecs = np.linalg.qr(r.normal(size=(dim, rank)))[0].T[:rank]
-            transform = (np.exp(r.normal(0, 0.3, dim)), r.normal(0, 1, dim), np.exp(r.uniform(-1, 2, rank)), np.ascontiguousarray(vecs), r.normal(0, 0.3, dim))
-    else:
-        s = N.DiagNutsSettings(maxdepth=6, trajectory_kind={"nuts": 0, "exact": 1, "micro": 2}[fam], **kw)
-    logp = _logp(dens, dim, seed)
+    dens, fam, dpl, wpc, dim = case["dens"], case["fam"], case["dpl"], case["w"], case["dim"]
+    r = SC.make_run(N, case)
+    s, logp, transform, draws, n = r["settings"], r["logp"], r["transform"], r["draws"], r["n_chains"]
     x0 = O.init_positions_uniform(s.seed, 0, n, logp.dim)
-    eng = {} if dens == "schools" else dict(dims_per_lane=dpl, waves_per_chain=wpc)
-    b = N.ChainBatch(s, logp, n, lane_groups=1, lane_chains=1, chain_tiles=1, **eng)     # the one-chain-per-block kernels, nothing else
+    b = N.ChainBatch(s, logp, n, **r["engine"])     # the one-chain-per-block kernels, nothing else
     assert (b.dims_per_lane(), b.threads_per_chain() // 64) == ((2, 1) if dens == "schools" else (dpl, wpc))
     status = b.set_position(x0, raise_on_error=False)
     adapt = transform == "adapt"
