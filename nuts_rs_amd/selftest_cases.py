@@ -55,19 +55,41 @@ def cases(both_ends=True):
     return out
 
 
+def _dyadic(r, n, lo_exp=-2, hi_exp=2):
+    """n positive doubles (1 + k/8) * 2^e: built from integers by exact operations only.  The inputs of a known-answer run must have the
+    same BITS on every machine — no exp / log (numpy dispatches them to different SIMD implementations by CPU), no BLAS, no LAPACK (round 6:
+    the first set of answers, whose precision matrices came from `a @ a.T`, failed on the GPU box for every mvn case of dim > 256)."""
+    return np.ldexp(1.0 + r.integers(0, 8, n) / 8.0, r.integers(lo_exp, hi_exp + 1, n))
+
+
 def make_logp(N, dens, dim, seed):
     r = np.random.default_rng(seed)
     if dens == "iid":
-        return N.LogpSpec.iid_normal(dim, float(r.normal()))
+        return N.LogpSpec.iid_normal(dim, float(r.integers(-128, 129)) / 64.0)
     if dens == "diag":
-        return N.LogpSpec.diag_normal(np.exp(r.uniform(-2, 2, dim)))
+        return N.LogpSpec.diag_normal(_dyadic(r, dim))
     if dens == "funnel":
         return N.LogpSpec.funnel(dim)
     if dens == "schools":
         return N.LogpSpec.eight_schools()
-    a = r.normal(size=(dim, 8))
-    p = a @ a.T / 8 + np.eye(dim)
-    return N.LogpSpec.mvn_precision((p + p.T) / 2)
+    a = r.integers(-3, 4, size=(dim, 8)).astype(np.int64)
+    p = (a @ a.T).astype(np.float64) / 8.0 + np.eye(dim)       # integer products: exact; symmetric by construction
+    return N.LogpSpec.mvn_precision(p)
+
+
+def make_transform(dim, seed):
+    """A frozen low-rank transformation (stds, mean, eigenvalues, orthonormal eigenvectors, gradient mean) of exactly representable numbers:
+    the eigenvectors have entries +-1/2 on disjoint groups of four coordinates (unit coordinate vectors when dim < 20)."""
+    r = np.random.default_rng(seed)
+    if dim >= 20:
+        rank = 5
+        vecs = np.zeros((rank, dim))
+        for k in range(rank):
+            vecs[k, 4 * k:4 * k + 4] = 0.5 * (1 - 2 * r.integers(0, 2, 4))
+    else:
+        rank = min(dim, 5)
+        vecs = np.eye(dim)[:rank].copy()
+    return (_dyadic(r, dim, -1, 1), r.integers(-16, 17, dim) / 16.0, _dyadic(r, rank, -1, 2), np.ascontiguousarray(vecs), r.integers(-8, 9, dim) / 16.0)
 
 
 def make_run(N, c):
@@ -94,10 +116,7 @@ def make_run(N, c):
             s.adapt_options.mass_matrix_update_freq = 5
             transform = "adapt"
         else:
-            r = np.random.default_rng(seed + 1)
-            rank = min(dim, 5)
-            vecs = np.linalg.qr(r.normal(size=(dim, rank)))[0].T[:rank]
-            transform = (np.exp(r.normal(0, 0.3, dim)), r.normal(0, 1, dim), np.exp(r.uniform(-1, 2, rank)), np.ascontiguousarray(vecs), r.normal(0, 0.3, dim))
+            transform = make_transform(dim, seed + 1)
     else:
         s = N.DiagNutsSettings(maxdepth=6, trajectory_kind={"nuts": 0, "exact": 1, "micro": 2}[fam], **kw)
     logp = make_logp(N, dens, dim, seed)
