@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 15
+#define NM_ABI_VERSION 16
 
 typedef enum nm_status {
     NM_OK = 0,
@@ -625,6 +625,11 @@ nm_status nm_chain_rng_key(uint64_t seed, uint64_t chain_id, uint8_t key_out[32]
 #define NM_PROBE_COPY_NT 4   /* copy with non-temporal stores (the cache policy of the engine's candidate / per-draw stores) */
 nm_status nm_probe_bandwidth(uint64_t kind, uint64_t bytes_per_array, uint64_t iters, double* ms_per_iter,
                              uint64_t* bytes_read_per_iter, uint64_t* bytes_written_per_iter);
+/* Fixed-work issue-rate calibration: `waves` one-wavefront blocks (0 = one per SIMD of the device) each run a dependent chain of `chain`
+ * v_fma_f64; *ns_per_instruction = launch time / chain.  The engine's BASELINE kernels run one wavefront per SIMD and are bound by the
+ * instructions that wavefront issues (one per ~4.3 cycles): this figure is the box-dependent factor of their speed (bench.py prints it
+ * beside every config).  No reference counterpart (measurement support). */
+nm_status nm_probe_issue(uint64_t waves, uint64_t chain, double* ns_per_instruction);
 
 /* ---------------------------------------------------------------------------------------------
  * The per-rank half of the OPT-IN pooled adaptation (north_star's "RCCL cross-chain Welford reduction"; NOT reference

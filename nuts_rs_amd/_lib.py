@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "nm_engine_get_mass_matrix", "nm_engine_get_step_sizes", "nm_engine_get_counters", "nm_engine_reset_counters",
     "nm_engine_dim", "nm_engine_num_chains", "nm_engine_threads_per_chain", "nm_engine_dims_per_lane", "nm_engine_blocks_per_chain", "nm_engine_group_launches", "nm_engine_lane_launches", "nm_engine_stream", "nm_leapfrog_batch", "nm_turning_batch",
     "nm_scalar_math_batch", "nm_standard_normal_batch", "nm_chain_rng_key", "nm_last_error", "nm_abi_version",
-    "nm_pick_tiling", "nm_probe_bandwidth", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
+    "nm_pick_tiling", "nm_probe_bandwidth", "nm_probe_issue", "nm_settings_default_low_rank", "nm_settings_default_mclmc", "nm_engine_set_lowrank_estimator",
     "nm_lowrank_compute_update", "nm_lowrank_test_spd_mean", "nm_lowrank_test_estimate_mass_matrix", "nm_engine_set_lowrank_estimator_place", "nm_engine_lowrank_device_updates", "nm_lowrank_block_twin", "nm_lowrank_test_block_device", "nm_engine_set_transform", "nm_engine_get_lowrank", "nm_engine_lowrank_max_rank",
     "nm_lowrank_transform_batch", "nm_engine_set_positions_masked", "nm_engine_init_positions_retry",
     "nm_init_positions_uniform_at", "nm_engine_tile_launches", "nm_engine_lockstep_launches", "nm_engine_reduce_order", "nm_engine_host_logp_calls", "nm_pooled_partials", "nm_pooled_exchange", "nm_pooled_finish", "nm_pooled_last_error",
@@ -253,6 +253,7 @@ def load():
     L.nm_vec_array_normalize.argtypes = [vp, vp]
     L.nm_lowrank_transform_batch.argtypes = [u64, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nm_probe_bandwidth.argtypes = [u64, u64, u64, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
+    L.nm_probe_issue.argtypes = [u64, u64, C.POINTER(dbl)]
     L.nm_pooled_partials.argtypes = [u64, u64, vp, vp, vp, vp, vp]
     L.nm_pooled_exchange.argtypes = [vp, u64, u64, vp, vp, vp]
     L.nm_pooled_finish.argtypes = [u64, u64, vp, vp, vp, vp, vp]

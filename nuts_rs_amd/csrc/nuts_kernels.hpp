@@ -107,7 +107,36 @@ __host__ __device__ inline int layout_depth(const nm_settings& s) { return (int)
 // Measured (profiles/r05f_*): (16 doubles, 1 wave) K2 2.02e11 -> 2.13e11, (2, 1) K3 +7 %; the register-capped tilings in between lose
 // ((8, 1) at two wavefronts per SIMD: -33 %, (4, 1): -7 %: the end points go to scratch memory) and keep the slots.
 template <int DPL, int W> constexpr bool reg_edges() { return bool(NM_REG_EDGES) & bool(NM_TRIM_FIRST) & !bool(NM_TILE_MODE) & !bool(NM_CLUSTER_MODE) & (W == 1) & (DPL == 16 || DPL == 2); }
-template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= 4 && W == 1 && (!NM_TILE_MODE || NM_BATCH_IN_TILES) && !NM_CLUSTER_MODE; }
+// timing experiment only (results are wrong): the U-turn tests of levels >= 2 and the top-level test read registers instead of their scratch slots
+#ifdef NM_X_NO_TEST_LOADS
+#define NM_TLD(r, so, m, alt) make_double2((alt).a[2 * (m)], (alt).a[2 * (m) + 1])
+#else
+#define NM_TLD(r, so, m, alt) C.ld2(r, so, m)
+#endif
+// Round 6 ("NOG" + "FD", the (16 doubles, 1 wavefront) tiling with an element-wise density and the diagonal transformation: K2).  The launch is bound by the
+// bytes the tree's end points move (21 B per step x dim against 3.7 necessary; every phase that touches memory stalls), so:
+//   NOG  a point is (z, v): its transformed gradient g_z is NOT kept.  For an element-wise density g_z is three operations per element away from z
+//        (x = sigma z + mu, g_x = density'(x), g_z = sigma g_x — the very operations that produced it, hence the same bits), so the leapfrog
+//        recomputes the start point's g_z on the fly (+4 instructions per element pair) instead of holding two more tiles of 32 registers and an
+//        HBM slot per main-tree edge.  The one gradient that is NOT a function of its z — the trajectory's initial point, whose z a
+//        re-whitening may have recomputed from x (transformed_hamiltonian.rs:687-736, diagonal.rs:210-221) — is streamed from its slot P_GZ.
+//   FD   the 64 registers that frees hold (z, v) of the FIRST leaf of the doubling in progress (F[depth]): the operand of every level-k test of
+//        a sub-tree that starts at leaf 0 and of the top-level test's third pair (src/nuts.rs:143-161) — written once and read two or three
+//        times per doubling before, now never in memory: the top-level tests read registers only.
+#ifndef NM_NOG
+#define NM_NOG 1
+#endif
+#ifndef NM_FD
+#define NM_FD 0      // measured (profiles/r06n_k2_nog_variants.txt): the 64 registers cost more in spills than the loads they save
+#endif
+#ifndef NM_GTILE
+#define NM_GTILE 1     // 1: one shared gradient tile instead of recomputing the start point's g_z in every leapfrog (32 registers for 64 instructions per leapfrog)
+#endif
+template <int DPL, int W, class Dens> constexpr bool nog_mode();
+#ifndef NM_BATCH_MAX_DPL
+#define NM_BATCH_MAX_DPL 4      // the widest one-wavefront tiling with the batched merges (resolve_chunk); the host's scratch layout follows it
+#endif
+template <int DPL, int W> constexpr bool batched_merges() { return NM_BATCH_MERGES && DPL <= NM_BATCH_MAX_DPL && W == 1 && (!NM_TILE_MODE || NM_BATCH_IN_TILES) && !NM_CLUSTER_MODE; }
 
 // Per-chain scalars (everything of NutsChain / GlobalStrategy / stepsize::Strategy / DualAverage that is not a vector)
 struct ChainScalars {
@@ -320,6 +349,13 @@ NM_DEV double2 buf_load2(rsrc_t r, int voff, int soff) {
 #define NM_NT_STORES 1
 #endif
 constexpr int NM_AUX_NT = NM_NT_STORES ? 2 : 0;
+// Round 6: the one-wavefront 16-doubles tiling (K2) stores its candidates / per-draw state with the default policy: a lone wavefront waits for its
+// stores wherever the next s_waitcnt vmcnt happens to be (loads and stores share the counter), and a streaming store is acknowledged later than a
+// write-back one (measured, profiles/r06n_k2_nog_variants.txt: 2.10 -> 2.15e11 on the round-5 kernel, 2.24 -> 2.27e11 with gradient-free points).
+#ifndef NM_NT_MAX_DPL
+#define NM_NT_MAX_DPL 8
+#endif
+template <int DPL, int W> constexpr int aux_nt() { return (NM_NT_STORES && (DPL <= NM_NT_MAX_DPL || W > 1)) ? 2 : 0; }
 // Output rows of a draw: plain masked 8-byte stores (0), a per-row buffer descriptor with 16-byte stores for every vector output (1) or for the
 // position row only (2), and the cache policy of those stores.  Measured on K2 with every draw recorded (tools/gpu_wrb.sh,
 // profiles/r04zz_write_row_variants.txt): 0: 75.8 ms per 200 draws, 1: 73.4, 2: 72.4, 2 + non-temporal: 72.1 (without recording: 71 - 72 ms in
@@ -699,6 +735,7 @@ struct HostCb {
 };
 template <class D, class = void> struct elementwise_trait { static constexpr bool value = false; };
 template <class D> struct elementwise_trait<D, typename std::enable_if<D::kElementwise>::type> { static constexpr bool value = true; };
+
 template <class D, class = void> struct can_fail { static constexpr bool value = false; };
 template <class D> struct can_fail<D, typename std::enable_if<D::kCanFail>::type> { static constexpr bool value = true; };
 // status of the density's last evaluation (0 for densities that cannot fail)
@@ -725,6 +762,10 @@ template <class D> struct kin_trait<LrWrap<D>> { static constexpr bool value = t
 // GEMMs of the block's 16 chains on the matrix cores
 template <class D, class = void> struct tile_trait { static constexpr bool value = false; };
 template <class D> struct tile_trait<D, typename std::enable_if<D::kTile>::type> { static constexpr bool value = true; };
+template <int DPL, int W, class Dens> constexpr bool nog_mode() {
+    return bool(NM_NOG) && DPL == 16 && W == 1 && bool(NM_TRIM_FIRST) && !bool(NM_TILE_MODE) && !bool(NM_CLUSTER_MODE) && bool(NM_FUSED_LEAPFROG) && !batched_merges<DPL, W>() &&
+           elementwise_trait<Dens>::value && !lr_trait<Dens>::value && !kin_trait<Dens>::value && !tile_trait<Dens>::value;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-wave context: everything a chain keeps in registers / SGPRs while its kernel runs
@@ -803,7 +844,7 @@ struct ChainCtx {
     // not push the soon-to-be-re-read end points (F, L) out of the 4 MiB L2 that 128 resident chains share
     NM_DEV void storeR_nt(const Tile<DPL>& t, rsrc_t r, int so) const {
 #pragma unroll
-        for (int m = 0; m < DPL / 2; ++m) buf_store2_aux<NM_AUX_NT>(r, voff + m * (64 * W * 16), so, t.a[2 * m], t.a[2 * m + 1]);
+        for (int m = 0; m < DPL / 2; ++m) buf_store2_aux<aux_nt<DPL, W>()>(r, voff + m * (64 * W * 16), so, t.a[2 * m], t.a[2 * m + 1]);
     }
     NM_DEV void storeP_nt(const Tile<DPL>& t, int s) const { storeR_nt(t, rp, force_sgpr(s * slot_bytes)); }
     NM_DEV void storeS_nt(const Tile<DPL>& t, int s) const { storeR_nt(t, rs, force_sgpr(s * slot_bytes)); }
@@ -848,7 +889,10 @@ struct ChainCtx {
 #endif
 template <int DPL, int W, class Dens>
 NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, uint64_t chain, uint64_t wave) {
-    C.red.packed = DPL <= 4 && !NM_TILE_MODE;        // (dev_math.hpp Reducer::packed: per tiling, from the measurements of round 5)
+#ifndef NM_PACKED_MAX_DPL
+#define NM_PACKED_MAX_DPL 4
+#endif
+    C.red.packed = DPL <= NM_PACKED_MAX_DPL && !NM_TILE_MODE;        // (dev_math.hpp Reducer::packed: per tiling, from the measurements of round 5)
     const KParams& P = C.P;
     C.dim = (int)P.dim; C.gdim = (int)P.dim; C.goff = 0;
 #if NM_CLUSTER_MODE
@@ -1156,8 +1200,15 @@ NM_DEV void leapfrog_kin(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o
                                   // step-size search, 2 the tree.  Tree only: it is where the instruction pays (K2 +5 %: profiles/r05u), and every failing
                                   // build of DESIGN §22's fourth incident had the asm form at the MCLMC site (never executed by the failing runs)
 #endif
-template <int DPL, int W, class Dens, int SITE = 0>
-NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out) {
+// GMODE (round 6, nog_mode): where the start point's g_z comes from — 0: its tile s.g; 1: recomputed from s.z (element-wise densities: the operations that
+// produced it); 2: streamed from the slot `gsrc` (the trajectory's initial point: P_GZ).  With GMODE != 0 neither s.g nor o.g is touched.
+template <int DPL, int W, class Dens, int SITE = 0, int GMODE = 0>
+NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, double epsilon, Tile<DPL>* x_out, Tile<DPL>* gx_out,
+                     typename ChainCtx<DPL, W, Dens>::SlotRef gsrc = typename ChainCtx<DPL, W, Dens>::SlotRef{}, Tile<DPL>* gshared = nullptr) {
+    // GMODE 3 (NM_GTILE): ONE gradient tile shared by the chain of leapfrogs — *gshared holds g_z of the point the previous leapfrog produced (= this one's
+    // start point), is read element by element and overwritten with the end point's; modes 1 / 2 fill it when the chain of leapfrogs restarts elsewhere.
+    static_assert(GMODE == 0 || (elementwise_trait<Dens>::value && !lr_trait<Dens>::value && !kin_trait<Dens>::value && NM_FUSED_LEAPFROG && !NM_CLUSTER_MODE && !NM_TILE_MODE),
+                  "the gradient-free point needs the fused element-wise leapfrog");
 #ifdef NM_X_NO_LEAPFROG           // timing experiment only: the tree without its integrator
     if (!x_out && !gx_out) { o.z = s.z; o.v = s.v; o.g = s.g; o.logp = s.logp + epsilon * 1e-6; o.ke = s.ke; return; }
 #endif
@@ -1205,22 +1256,37 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
         auto pass = [&](auto full_tile) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tile)::value;
             double2 sg = sg2[0], mm = mu2[0];
+            [[maybe_unused]] double2 gg = make_double2(0., 0.);
+            if constexpr (GMODE == 2) gg = C.ld2(gsrc.r, gsrc.so, 0);
 #pragma unroll
             for (int m = 0; m < DPL / 2; ++m) {
                 const double2 sg_c = sg, mm_c = mm;
+                [[maybe_unused]] const double2 gg_c = gg;
                 if (m + 1 < DPL / 2) { sg = sg2[(m + 1) * 64 * W]; mm = mu2[(m + 1) * 64 * W]; }      // the next pair's sigma / mu are in flight during this pair
+                if constexpr (GMODE == 2) { if (m + 1 < DPL / 2) gg = C.ld2(gsrc.r, gsrc.so, m + 1); }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int k = 2 * m + j;
                     const double sgk = j ? sg_c.y : sg_c.x, muk = j ? mm_c.y : mm_c.x;
+                    double gsk;                      // the start point's g_z element
+                    if constexpr (GMODE == 0) gsk = s.g.a[k];
+                    else if constexpr (GMODE == 3) gsk = gshared->a[k];
+                    else if constexpr (GMODE == 2) gsk = j ? gg_c.y : gg_c.x;
+                    else {                           // the operations that produced it when this point was a leapfrog's end point (below): same bits
+                        const double ts = s.z.a[k] * sgk;
+                        const double xs = __builtin_fma(1.0, muk, ts);
+                        double unused_term;
+                        const double gxs = C.dens.template elem<W, FULL>(xs, k, C.dim, unused_term);
+                        gsk = gxs * sgk;
+                    }
                     // (v_fma_f64 spelled out: the source point's v and z stay live, and the compiler's two-address form — v_mov_b64 + v_fmac_f64 —
                     // costs an instruction more per fma; the same IEEE fused multiply-add)
                     double vh, zk;
                     if constexpr (NM_LF_FMA_FORM == 0 && ((NM_X_ASM_SITES >> SITE) & 1)) {
-                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(s.g.a[k]), "v"(s.v.a[k]));
+                        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(vh) : "v"(half), "v"(gsk), "v"(s.v.a[k]));
                         asm("v_fma_f64 %0, %1, %2, %3" : "=v"(zk) : "v"(epsilon), "v"(vh), "v"(s.z.a[k]));
                     } else {
-                        vh = __builtin_fma(half, s.g.a[k], s.v.a[k]);
+                        vh = __builtin_fma(half, gsk, s.v.a[k]);
                         zk = __builtin_fma(epsilon, vh, s.z.a[k]);
                     }
                     o.z.a[k] = zk;
@@ -1230,7 +1296,8 @@ NM_DEV void leapfrog(ChainCtx<DPL, W, Dens>& C, const Pt<DPL>& s, Pt<DPL>& o, do
                     const double gxk = C.dens.template elem<W, FULL>(xk, k, C.dim, term);
                     acc = acc + term;
                     const double gk = gxk * sgk;
-                    o.g.a[k] = gk;
+                    if constexpr (GMODE == 0) o.g.a[k] = gk;
+                    else if constexpr (NM_GTILE != 0) gshared->a[k] = gk;
                     const double vk = __builtin_fma(half, gk, vh);
                     o.v.a[k] = vk;
                     kacc = __builtin_fma(vk, vk, kacc);
@@ -2074,6 +2141,11 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     const int MD = C.maxdepth_cfg;
     Pt<DPL> E, O;
     constexpr bool RE = reg_edges<DPL, W>();
+    constexpr bool NOG = nog_mode<DPL, W, Dens>();       // points are (z, v): no g_z tile (see nog_mode)
+    constexpr bool FD = NOG && bool(NM_FD);                // the first leaf of the doubling in progress lives in FDz / FDv
+    [[maybe_unused]] Tile<DPL> Gsh;                        // NM_GTILE: g_z of the point the last leapfrog produced
+    [[maybe_unused]] Tile<DPL>* const gsh = NM_GTILE ? &Gsh : nullptr;
+    [[maybe_unused]] Tile<DPL> FDz, FDv;
     [[maybe_unused]] EdgeTile<DPL, NM_EDGES_IN_ACC != 0> MLz, MLv, MRz, MRv;   // RE: (z, v) of the main tree's left / right end point; their g_z (read only when the
                                                           // trajectory is extended on the other side) stays in the scratch slot
     // ---- initialize_trajectory (transformed_hamiltonian.rs:687-736)
@@ -2105,7 +2177,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         sc.transform_id = sc.mm_id;
     } else {
         C.loadP(E.z, P_Z);
-        C.loadP(E.g, P_GZ);
+        if constexpr (!NOG) C.loadP(E.g, P_GZ);          // (NOG: the initial point's g_z is streamed from P_GZ by the leapfrogs that start there)
     }
     const double logdet = sc.logdet;
     const double ke_init = initial_kinetic(C, E.v, !RE);
@@ -2242,8 +2314,10 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                 rz = C.ld2(mrz.r, mrz.so, m); rv = C.ld2(mrv.r, mrv.so, m);
                             }
                             double2 oz, ov;
+                            if constexpr (FD) { oz = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); ov = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }   // leaf 0 of this doubling
+                            else
                             if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
-                            else { oz = C.ld2(C.rs, so_ofz, m); ov = C.ld2(C.rs, so_ofv, m); }
+                            else { oz = NM_TLD(C.rs, so_ofz, m, E.z); ov = NM_TLD(C.rs, so_ofv, m, E.v); }
                             const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
                             const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                             turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
@@ -2263,20 +2337,24 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             { const int es = fwd ? right_slot : left_slot;
               C.loadRef(E.z, C.edge_z(es)); C.loadRef(E.v, C.edge_v(es)); C.loadRef(E.g, C.edge_g(es)); }
 #endif
-            leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
+            if constexpr (NOG) leapfrog<DPL, W, Dens, 2, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, C.edge_g(0), gsh);
+            else leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
             O.idx = edge_idx + (int64_t)sign;
             NM_LEAF_ACCOUNT(E, O, sub_log_size)
             NM_MARK(C, 27)
             sub_cand = {-2, O.logp, O.ke, O.idx};
         } else {
+            [[maybe_unused]] bool g_from_slot = false;      // NOG: the first leapfrog of this doubling starts at the trajectory's initial point
             if (!reuse_edge) {                              // same direction as the last doubling: the edge is still in O
                 const int es = fwd ? right_slot : left_slot;
                 if constexpr (RE) {
-                    C.loadRef(O.g, C.edge_g(es));
+                    if constexpr (NOG) g_from_slot = es == 0;
+                    else C.loadRef(O.g, C.edge_g(es));
                     // (a real branch: as selects the choice costs a v_cndmask per 32 bits of both tiles; the empty asm keeps the arms apart)
                     if (fwd) { asm volatile("; reload: right end"); MRz.get(O.z); MRv.get(O.v); } else { asm volatile("; reload: left end"); MLz.get(O.z); MLv.get(O.v); }
                 } else {
-                C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es)); C.loadRef(O.g, C.edge_g(es));
+                C.loadRef(O.z, C.edge_z(es)); C.loadRef(O.v, C.edge_v(es));
+                if constexpr (NOG) g_from_slot = es == 0; else C.loadRef(O.g, C.edge_g(es));
                 }
                 if constexpr (kin_trait<Dens>::value) O.ke = fwd ? right_ke : left_ke;
             }
@@ -2286,6 +2364,11 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 // ---- even leaf n
                 double wE = 0., wO = 0.;
                 NM_MARK(C, 16)
+                if constexpr (NOG) {
+                    if (n == 0 && g_from_slot) leapfrog<DPL, W, Dens, 2, 2>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, C.edge_g(0), gsh);
+                    else if (NM_GTILE && !(n == 0 && !reuse_edge)) leapfrog<DPL, W, Dens, 2, 3>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, C.edge_g(0), gsh);
+                    else leapfrog<DPL, W, Dens, 2, 1>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, C.edge_g(0), gsh);
+                } else
                 leapfrog<DPL, W, Dens, 2>(C, O, E, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 17)
                 E.idx = edge_idx + (int64_t)sign * (int64_t)(n + 1);
@@ -2293,6 +2376,8 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 if (stop != STOP_NONE) break;
                 // ---- odd leaf n + 1
                 NM_MARK(C, 18)
+                if constexpr (NOG) leapfrog<DPL, W, Dens, 2, (NM_GTILE ? 3 : 1)>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr, C.edge_g(0), gsh);
+                else
                 leapfrog<DPL, W, Dens, 2>(C, E, O, epsilon, (Tile<DPL>*)nullptr, (Tile<DPL>*)nullptr);
                 NM_MARK(C, 19)
                 O.idx = edge_idx + (int64_t)sign * (int64_t)(n + 2);
@@ -2316,12 +2401,17 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         const int so_afz = C.soS(slot_F(fa)), so_afv = C.soS(slot_F(fa) + 1);
                         const int so_alz = C.soS(slot_L(MD, k - 1)), so_alv = C.soS(slot_L(MD, k - 1) + 1);
                         double s1 = 0., s2 = 0., s3 = 0., s4 = 0., s5 = 0., s6 = 0.;
+                        // (NOG: A.first is the doubling's first leaf when the sub-tree starts there — registers FDz / FDv instead of the slot F[depth])
+                        auto level_rows = [&](auto a_in_fd) __attribute__((always_inline)) {
+                        constexpr bool AFD = decltype(a_in_fd)::value;
                         if (k == 2) {
                             const double2* l1z2 = C.tptr(C.l1z);      // A.last = L[1] lives in LDS
                             const double2* l1v2 = C.tptr(C.l1v);
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
+                                double2 az, av;
+                                if constexpr (AFD) { az = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); av = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }
+                                else { az = NM_TLD(C.rs, so_afz, m, E.z); av = NM_TLD(C.rs, so_afv, m, E.v); }
                                 const double2 lz = l1z2[m * 64 * W], lv = l1v2[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
@@ -2339,9 +2429,11 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                             const int so_bfz = C.soS(slot_F(k - 1)), so_bfv = C.soS(slot_F(k - 1) + 1);
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
-                                const double2 az = C.ld2(C.rs, so_afz, m), av = C.ld2(C.rs, so_afv, m);
-                                const double2 lz = C.ld2(C.rs, so_alz, m), lv = C.ld2(C.rs, so_alv, m);
-                                const double2 bz2 = C.ld2(C.rs, so_bfz, m), bv2 = C.ld2(C.rs, so_bfv, m);
+                                double2 az, av;
+                                if constexpr (AFD) { az = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); av = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }
+                                else { az = NM_TLD(C.rs, so_afz, m, E.z); av = NM_TLD(C.rs, so_afv, m, E.v); }
+                                const double2 lz = NM_TLD(C.rs, so_alz, m, O.z), lv = NM_TLD(C.rs, so_alv, m, O.v);
+                                const double2 bz2 = NM_TLD(C.rs, so_bfz, m, E.v), bv2 = NM_TLD(C.rs, so_bfv, m, O.z);
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -2355,6 +2447,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                 NM_GROUP_BARRIER(m);
                             }
                         }
+                        };
+                        if constexpr (FD) { if (a_first == 0) level_rows(std::true_type{}); else level_rows(std::false_type{}); }
+                        else level_rows(std::false_type{});
                         { double sv6[6] = {s1, s2, s3, s4, s5, s6}; if (C.red.any_sign(sv6, fwd)) turn_bits |= 1u << k; }
                     }
                 }
@@ -2387,17 +2482,25 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                 // F: the even leaf (still in E) is the first leaf of the sub-trees of level >= 2 that start at n.  Stored here,
                 // after the merges: every call of the merge arithmetic waits for all stores in flight, and nothing reads F
                 // before the next pair.  (At depth 1 leaf 0 is still in E when the top-level tests need it.)
+#ifndef NM_X_NO_SCRATCH_STORES   // (timing experiment only: results are wrong without the stores)
+                if (FD && n == 0) { FDz = E.z; FDv = E.v; }          // the doubling's first leaf stays in registers (any depth >= 1)
+                else
                 if ((n & 3) == 0 && (depth > 1 || !NM_TRIM_FIRST)) {
                     const int fs = slot_F(n == 0 ? (int)depth : (int)__builtin_ctzll(n));
                     C.storeS(E.z, fs);
                     C.storeS(E.v, fs + 1);
                 }
+#endif
                 if (n + 2 < nleaf) {
                     // O is the last leaf of the pending level-t sub-tree; its candidate leaves the registers
+#ifndef NM_X_NO_SCRATCH_STORES
                     if (t == 1) { C.store(O.z, C.l1z); C.store(O.v, C.l1v); }
                     else { C.storeS(O.z, slot_L(MD, t)); C.storeS(O.v, slot_L(MD, t) + 1); }
                     if (sub_cand.slot == -2) sub_cand.slot = cand_to_pool(C, used, O.z);
                     else if (sub_cand.slot == -3) sub_cand.slot = cand_to_pool(C, used, E.z);
+#else
+                    if (sub_cand.slot < 0) sub_cand.slot = 0;
+#endif
                     PendEntry e;
                     e.log_size = sub_log_size; e.cand_logp = sub_cand.logp; e.cand_ke = sub_cand.ke;
                     e.cand_idx = sub_cand.idx; e.cand_slot = sub_cand.slot; e.pad = 0;
@@ -2630,13 +2733,13 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
             const int other_side = fwd ? left_slot : right_slot;
             if (ns == 0) ns = other_side == 1 ? 2 : 1;          // id 0 (the initial point) is read-only
             if constexpr (RE) {
-                C.storeRef(O.g, C.edge_g(ns));
+                if constexpr (!NOG) C.storeRef(O.g, C.edge_g(ns));
                 if (fwd) { asm volatile("; new right end"); MRz.put(O.z); MRv.put(O.v); } else { asm volatile("; new left end"); MLz.put(O.z); MLv.put(O.v); }
             } else {
-            C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); C.storeRef(O.g, C.edge_g(ns));
+            C.storeRef(O.z, C.edge_z(ns)); C.storeRef(O.v, C.edge_v(ns)); if constexpr (!NOG) C.storeRef(O.g, C.edge_g(ns));
             }
 #ifdef NM_EXTRA_TRAFFIC   // development: is the kernel bound by the bytes it moves? (two more tile stores per doubling)
-            C.storeS(O.g, slot_F(MD)); C.storeS(O.z, slot_F(MD) + 1);
+            C.storeS(O.v, slot_F(MD)); C.storeS(O.z, slot_F(MD) + 1);
 #endif
             if (fwd) right_slot = ns; else left_slot = ns;
             o_is_edge = true; o_edge_sign = sign;

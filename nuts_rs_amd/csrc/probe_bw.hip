@@ -172,3 +172,72 @@ extern "C" int nm_probe_bandwidth_impl(uint64_t kind, uint64_t bytes_per_array, 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     return fin(e);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-work issue-rate calibration (round 6): `waves` one-wavefront blocks each run a DEPENDENT chain of
+// `chain` v_fma_f64 (64 per loop trip, one asm block).  Every BASELINE kernel of this engine runs one useful wavefront per SIMD and is bound
+// by the instructions that wavefront issues, so the time of this loop — nanoseconds per dependent instruction of a lone wavefront —
+// is the box-dependent factor of their speed: the bench line prints it beside every config so that a slower box is not read as a regression.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void issue_kernel(double* out, uint64_t trips, double a, double b) {
+    double x = (double)threadIdx.x * 1e-3;
+    for (uint64_t t = 0; t < trips; ++t) {
+        asm volatile(
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            "v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n"
+            : "+v"(x) : "v"(a), "v"(b));
+    }
+    if (x == 12345.678) out[0] = x;      // keeps the chain alive
+}
+}  // namespace
+
+// declared in include/nuts_amd.h (nm_probe_issue)
+extern "C" int nm_probe_issue_impl(uint64_t waves, uint64_t chain, double* ns_per_instruction, const char** err) {
+    *err = nullptr;
+    if (chain < 64) { *err = "chain shorter than one loop trip (64 instructions)"; return 1; }
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = waves ? (unsigned)waves : (unsigned)cus * 4u;          // default: one wavefront per SIMD
+    const uint64_t trips = chain / 64;
+    double* out = nullptr;
+    hipError_t e = hipMalloc(&out, 8);
+    if (e != hipSuccess) { *err = hipGetErrorString(e); return 3; }
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipFree(out); *err = hipGetErrorString(e); return 3; }
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    double best = -1.0;
+    for (int rep = 0; rep < 4 && e == hipSuccess; ++rep) {                      // (the first is the warm-up; the fastest of the rest is the answer)
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(issue_kernel, dim3(grid), dim3(64), 0, st, out, trips, 0.999999, 1e-9);
+        e = hipGetLastError();
+        (void)hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        const double ns = (double)ms * 1e6 / (double)(trips * 64);
+        if (e == hipSuccess && rep > 0 && (best < 0.0 || ns < best)) best = ns;
+    }
+    if (ns_per_instruction) *ns_per_instruction = best;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(out);
+    if (e != hipSuccess) { *err = hipGetErrorString(e); return 3; }
+    return 0;
+}
+
