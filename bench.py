@@ -16,7 +16,12 @@
             (torch.distributed.run) when it is not already running under a launcher.  Chains shard with no data-path
             collective (global chain id = rank * 4096 + local id; results are invariant to the partition) => "weak"
             scaling; value = all ranks' steps*dims / max-over-ranks time.
-  roofline: HBM.  `achieved` = bytes the dominant kernel (nuts_draw_kernel) actually moved through the memory-side
+  roofline: (schema_version 6) `bound`, `achieved`, `peak`, `unit`, `frac` describe ONE bound — the binding one of bound_model: for K2 the issue
+            rate of necessary 64-lane f64 instructions (`valu_issue`), frac = achieved / peak = t_min / t_kernel.  What the kernel moved through
+            HBM is `hbm_moved` (below: how it is measured).  Rounds 4 - 5 printed HBM GB/s in achieved / peak beside the issue bound's frac.
+            `calibration` (beside every config): this box's ns per dependent f64 fma of a lone wavefront and its copy rate, and the ratio of the
+            config's value to the driver's record of the previous round.
+            HBM.  `hbm_moved.achieved_GBps` = bytes the dominant kernel (nuts_draw_kernel) actually moved through the memory-side
             counters (rocprofv3 FETCH_SIZE / WRITE_SIZE in separate --pmc passes of this same workload, taken live by
             this script on rank 0 at N = 1, corrected with the factors calibrated on known-size streams,
             profiles/*hbm_calibration.json) / its launch time (HIP events on the engine's stream, un-profiled run);
@@ -207,6 +212,7 @@ def bound_model(st, D, kern_s, traffic):
     t_valu = nec_cycles / (N_SIMD * SHADER_HZ)
     t_min = max(t_hbm, t_valu)
     return {"frac": t_min / kern_s, "t_min_ms": t_min * 1e3, "t_kernel_ms": kern_s * 1e3, "binding": "valu" if t_valu >= t_hbm else "hbm",
+            "terms_ms": {"hbm": t_hbm * 1e3, "valu": t_valu * 1e3}, "necessary_valu_instr": nec_ops_elem * (D / 64.0),
             "hbm": {"necessary_bytes": nec_bytes, "t_ms": t_hbm * 1e3, "frac": t_hbm / kern_s,
                     "necessary_bytes_per_chain_draw": nec_bytes / max(1, depth.size),
                     "moved_over_necessary": (traffic / nec_bytes) if traffic else None,
@@ -248,8 +254,59 @@ def generic_bound(n_steps_cd, depth_cd, D, kern_s, traffic, elems_per_lane=None,
     binding = max(terms, key=terms.get)
     t_min = terms[binding]
     return {"frac": t_min / kern_s, "binding": binding, "t_min_ms": t_min * 1e3, "t_kernel_ms": kern_s * 1e3,
-            "terms_ms": {k: v * 1e3 for k, v in terms.items()}, "necessary_bytes": nec_bytes,
+            "terms_ms": {k: v * 1e3 for k, v in terms.items()}, "necessary_bytes": nec_bytes, "necessary_valu_instr": ops_elem * (D / 64.0),
             "waste_ratio": (traffic / nec_bytes) if traffic else None}
+
+
+ISSUE_PEAK_INSTR_S = N_SIMD * SHADER_HZ / F64_VALU_CYCLES_PER_WAVE_INSTR      # 64-lane f64 instructions per second the chip can issue
+SCHEMA_VERSION = 6
+# the driver's records of the previous round (BENCH_r05.json), for `calibration.ratio_to_previous_round`
+PREVIOUS_ROUND = {"round": 5, "k2": 2.047e11, "k3": 1.81e8, "k4_65536": 4.79e9, "k4_8192": 2.08e9, "k5": 4.30e7,
+                  "unit": {"k2": "leapfrog-steps*dims/s", "k3": "leapfrogs/s", "k4_65536": "leapfrogs/s", "k4_8192": "leapfrogs/s", "k5": "leapfrogs/s"}}
+
+
+def one_bound(binding, terms_ms, kern_s, nec_valu_instr=None, nec_bytes=None):
+    """The roofline object's four scalars for ONE bound: `bound`, `achieved`, `peak`, `unit` describe the SAME thing `frac` does
+    (frac = achieved / peak = t_min / t_kernel <= 1).  valu_issue: necessary 64-lane f64 instructions per second against the chip's issue rate;
+    hbm: necessary bytes per second against 8 TB/s; slowest_chain: the necessary issue time of the deepest chain against the launch time."""
+    t_min = terms_ms[binding] * 1e-3
+    if binding == "valu" and nec_valu_instr:
+        return {"bound": "valu_issue", "achieved": nec_valu_instr / kern_s, "peak": ISSUE_PEAK_INSTR_S, "unit": "necessary 64-lane f64 instructions/s",
+                "frac": (nec_valu_instr / kern_s) / ISSUE_PEAK_INSTR_S}
+    if binding == "hbm" and nec_bytes:
+        return {"bound": "hbm", "achieved": nec_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (necessary bytes)", "frac": nec_bytes / kern_s / 1e9 / HBM_PEAK_GBS}
+    return {"bound": binding, "achieved": t_min * 1e3, "peak": kern_s * 1e3, "unit": "ms (necessary / measured)", "frac": t_min / kern_s}
+
+
+_calibration_cache = {}
+
+
+def box_calibration(key=None, value=None):
+    """Fixed-work figures of THIS box beside every config: a lone wavefront's nanoseconds per dependent v_fma_f64 with one
+    wavefront per SIMD (nm_probe_issue: what every BASELINE kernel here is bound by) and the copy rate of the engine's access shape
+    (nm_probe_bandwidth) — so that a slower box is not read as a regression — and the ratio of this config's value to the driver's record of the
+    previous round."""
+    import ctypes as C
+    from nuts_rs_amd import _lib
+    if "box" not in _calibration_cache:
+        L = _lib.load()
+        out = {}
+        try:
+            ns = C.c_double()
+            _lib.check(L.nm_probe_issue(0, 1 << 20, C.byref(ns)))
+            out["issue_ns_per_dependent_f64_fma"] = ns.value
+            out["issue_cycles_at_2p4GHz"] = ns.value * 2.4
+            ms, rd, wr = C.c_double(), C.c_uint64(), C.c_uint64()
+            _lib.check(L.nm_probe_bandwidth(0, 1 << 30, 5, C.byref(ms), C.byref(rd), C.byref(wr)))
+            out["copy_GBps"] = (rd.value + wr.value) / (ms.value * 1e-3) / 1e9
+        except Exception as e:  # noqa: BLE001
+            out["error"] = f"{type(e).__name__}: {e}"
+        _calibration_cache["box"] = out
+    cal = dict(_calibration_cache["box"])
+    if key in PREVIOUS_ROUND and value:
+        cal["previous_round"] = {"round": PREVIOUS_ROUND["round"], "value": PREVIOUS_ROUND[key], "unit": PREVIOUS_ROUND["unit"][key]}
+        cal["ratio_to_previous_round"] = value / PREVIOUS_ROUND[key]
+    return cal
 
 
 def pmc_profile(steps_dims):
@@ -451,8 +508,10 @@ def other_config_roofline(args, key, res, deadline):
                 roof["pmc_failed"] = why
         # `frac` is a BOUND (t_min / t_kernel <= 1, cannot be raised by moving more bytes); the utilisation of moved bytes is `frac_moved`
         bm = generic_bound(res["_n_steps"], res["_depth"], D, kern_s, roof["traffic"], latency=(key == "k3"))
+        roof["hbm_moved"] = {"achieved_GBps": roof["achieved"], "peak_GBps": HBM_PEAK_GBS, "frac_moved": roof["frac"]}
         roof["frac_moved"] = roof["frac"]
-        roof.update(frac=bm["frac"], binding=bm["binding"], waste_ratio=bm["waste_ratio"], t_min_ms=bm["t_min_ms"], bound_terms_ms=bm["terms_ms"],
+        roof.update(one_bound(bm["binding"], bm["terms_ms"], kern_s, bm.get("necessary_valu_instr"), bm.get("necessary_bytes")))
+        roof.update(binding=bm["binding"], waste_ratio=bm["waste_ratio"], t_min_ms=bm["t_min_ms"], bound_terms_ms=bm["terms_ms"],
                     frac_sec8d_model=roof["algorithmic"]["frac_sec8d_model"],
                     frac_definition="frac = t_min / t_kernel, t_min = max(necessary HBM bytes / 8 TB/s, necessary f64 VALU instructions / chip issue rate"
                                     + (", leapfrogs of the deepest chain x issue cycles of one leapfrog" if key == "k3" else "") + "); waste_ratio = HBM bytes moved / necessary")
@@ -496,6 +555,7 @@ def other_configs(args):
             res["roofline"] = other_config_roofline(args, k, res, deadline)
             res.pop("_n_steps", None); res.pop("_depth", None)
             res["key"] = k
+            res["calibration"] = box_calibration(k, res["value"] if k == "k2" else res["leapfrogs_per_s"])
             out.append(res)
         except Exception as e:  # noqa: BLE001  (the bench line must still be printed)
             out.append({"workload": OTHER_CONFIGS[k]["name"], "key": k, "error": f"{type(e).__name__}: {e}"})
@@ -811,14 +871,17 @@ def main():
             "leapfrogs_per_draw": steps_total / (args.steps * C_ * world),
             "adaptation": {"value": tune_steps_total * D / t_tune_max, "unit": "leapfrog-steps*dims/s",
                            "draws": args.num_tune, "seconds": t_tune_max},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         # `frac` is the BOUND: t_min / t_kernel <= 1, and moving more bytes cannot raise it
-                         "frac": bm["frac"] if bm.get("frac") is not None else None,
+            "schema_version": SCHEMA_VERSION,
+            "roofline": {**(one_bound(bm["binding"], bm["terms_ms"], kern_s, bm.get("necessary_valu_instr"), (bm.get("hbm") or {}).get("necessary_bytes"))
+                            if bm.get("binding") else {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}),
+                         # bound / achieved / peak / unit / frac describe ONE bound (schema 6; rounds 4 - 5 printed HBM GB/s beside the issue bound's frac);
+                         # what the kernel MOVED through HBM is `hbm_moved`
+                         "hbm_moved": {"achieved_GBps": achieved, "peak_GBps": HBM_PEAK_GBS, "frac_moved": (achieved / HBM_PEAK_GBS) if achieved else None},
                          "binding": bm.get("binding"), "waste_ratio": (bm.get("hbm") or {}).get("moved_over_necessary"),
                          "t_min_ms": bm.get("t_min_ms"), "t_kernel_ms": kern_s * 1e3,
                          "frac_moved": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "frac_sec8d_model": algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                         "frac_definition": "frac = t_min / t_kernel with t_min = max(necessary HBM bytes / 8 TB/s, necessary f64 VALU instructions / "
+                         "frac_definition": "frac = achieved / peak of the BINDING bound = t_min / t_kernel with t_min = max(necessary HBM bytes / 8 TB/s, necessary f64 VALU instructions / "
                                             "(1024 SIMDs x 2.4 GHz / 4)) — a bound: <= 1 and not raised by moving more bytes (bound_model has the "
                                             "enumeration); waste_ratio = HBM bytes moved / necessary; frac_moved = moved bytes (PMC) / launch time / "
                                             "8 TB/s = achieved / peak (a utilisation); frac_sec8d_model = 64 B x steps x dims / launch time / 8 TB/s "
@@ -835,6 +898,8 @@ def main():
                                                  "stay in registers / LDS, HBM carries the tree's end points instead"},
                          "pmc": pmc_detail},
         }
+        if world == 1:
+            out["calibration"] = box_calibration("k2", value)
         if world == 1 and args.other_configs != "none":
             batch.close()                                    # (K2's 1.5 GB of chain state and the record buffers go first)
             batch = None

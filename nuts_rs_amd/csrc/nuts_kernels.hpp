@@ -2749,6 +2749,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
         if constexpr (kin_trait<Dens>::value) { if (fwd) right_ke = O.ke; else left_ke = O.ke; }
         depth += 1;
         log_size = total;
+#ifdef NM_X_SABOTAGE_LR41   // (tools/runs/gpu_r06p.sh only: ONE deliberately wrong instantiation, to show that the known-answer checks reject it)
+        if constexpr (DPL == 4 && W == 1 && lr_trait<Dens>::value) log_size = 0.5 * total;
+#endif
         if (turning && !in_extra) { in_extra = true; extra_left = s.extra_doublings; }
     }
     R.depth = depth;

@@ -126,15 +126,16 @@ def make_run(N, c):
 
 
 def family_of(settings):
-    """The settings family of `cases()` an engine's settings select the kernels of (the LrWrap / KinWrap / plain instantiation and its sampler)."""
-    name = type(settings).__name__
-    kind = int(getattr(settings, "trajectory_kind", 0) or 0)
-    if name == "LowRankMclmcSettings":
-        return ["lr_mclmc"]
-    if name == "DiagMclmcSettings":
-        return ["mclmc"]
-    if name == "LowRankNutsSettings":
+    """The settings families of `cases()` whose kernels an engine with these settings launches (the LrWrap / KinWrap / plain instantiation and its
+    sampler).  `LowRankNutsSettings` / `LowRankMclmcSettings` are the Diag classes with `LowRankSettings` as mass_matrix_options (sampler.py)."""
+    mo = getattr(getattr(settings, "adapt_options", None), "mass_matrix_options", None)
+    low_rank = type(mo).__name__ == "LowRankSettings"
+    if type(settings).__name__ == "DiagMclmcSettings":
+        return ["lr_mclmc"] if low_rank else ["mclmc"]
+    if low_rank:
         return ["lr_frozen", "lr_adapt"]
+    tk = getattr(settings, "trajectory_kind", 0)
+    kind = int(getattr(tk, "value", tk) or 0)
     return [{0: "nuts", 1: "exact", 2: "micro"}.get(kind, "nuts")]
 
 
