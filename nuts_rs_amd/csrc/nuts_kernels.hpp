@@ -126,6 +126,9 @@ template <int DPL, int W> constexpr bool reg_edges() { return bool(NM_REG_EDGES)
 #ifndef NM_NOG
 #define NM_NOG 1
 #endif
+#ifndef NM_NOG_82
+#define NM_NOG_82 0   // the gradient-free points on the (8 doubles, 2 wavefronts) tiling too (measured: profiles/r06s_*)
+#endif
 #ifndef NM_FD
 #define NM_FD 0      // measured (profiles/r06n_k2_nog_variants.txt): the 64 registers cost more in spills than the loads they save
 #endif
@@ -763,7 +766,7 @@ template <class D> struct kin_trait<LrWrap<D>> { static constexpr bool value = t
 template <class D, class = void> struct tile_trait { static constexpr bool value = false; };
 template <class D> struct tile_trait<D, typename std::enable_if<D::kTile>::type> { static constexpr bool value = true; };
 template <int DPL, int W, class Dens> constexpr bool nog_mode() {
-    return bool(NM_NOG) && DPL == 16 && W == 1 && bool(NM_TRIM_FIRST) && !bool(NM_TILE_MODE) && !bool(NM_CLUSTER_MODE) && bool(NM_FUSED_LEAPFROG) && !batched_merges<DPL, W>() &&
+    return bool(NM_NOG) && ((DPL == 16 && W == 1) || (bool(NM_NOG_82) && DPL == 8 && W == 2)) && bool(NM_TRIM_FIRST) && !bool(NM_TILE_MODE) && !bool(NM_CLUSTER_MODE) && bool(NM_FUSED_LEAPFROG) && !batched_merges<DPL, W>() &&
            elementwise_trait<Dens>::value && !lr_trait<Dens>::value && !kin_trait<Dens>::value && !tile_trait<Dens>::value;
 }
 

@@ -168,3 +168,18 @@ def test_leapfrog_batch_other_densities(oracle, kind, dim, dpl):
             assert (bits(g[i].cpu().numpy()) == bits(e)).all(), (name, i)
         for name, g, e in zip(("logp", "ke", "energy_error"), souts, so):
             assert bits(g[i].item()) == bits(e.value), (name, i, g[i].item(), e.value)
+
+
+def test_issue_rate_probe_reports_a_plausible_figure():
+    """nm_probe_issue (ABI v16): nanoseconds per dependent v_fma_f64 of a lone wavefront, one wavefront per SIMD — the box calibration bench.py
+    prints beside every config.  A 64-lane f64 instruction occupies a SIMD for 4 cycles: between 4 and ~10 cycles at 1.4 - 2.5 GHz."""
+    import ctypes as C
+    from nuts_rs_amd import _lib
+    L = _lib.load()
+    ns = C.c_double()
+    _lib.check(L.nm_probe_issue(0, 1 << 18, C.byref(ns)))
+    assert 1.5 < ns.value < 8.0, ns.value
+    one = C.c_double()
+    _lib.check(L.nm_probe_issue(64, 1 << 18, C.byref(one)))      # 64 wavefronts on the whole chip: the same chain, no neighbours
+    assert 1.5 < one.value <= ns.value * 1.05
+    assert L.nm_probe_issue(0, 8, C.byref(ns)) != 0                # a chain shorter than one loop trip is refused

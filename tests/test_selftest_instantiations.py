@@ -79,3 +79,14 @@ def test_run_all_names_every_failing_instantiation(monkeypatch):
     assert all(v in str(e.value) for v in victims) and "2 of" in str(e.value)
     monkeypatch.setattr(selftest, "_inst_gold", None)
     assert selftest.run_all(only="diag-micro-4x1") == 2
+
+
+def test_family_of_maps_every_settings_constructor_to_its_kernel_family():
+    """`LowRankNutsSettings` / `LowRankMclmcSettings` are factories that return the Diag classes with LowRankSettings inside: the first-use check
+    must still find the LrWrap instantiations (round 6: the first version keyed on the class name and let a wrong low-rank kernel through)."""
+    assert SC.family_of(N.DiagNutsSettings()) == ["nuts"]
+    assert SC.family_of(N.DiagNutsSettings(trajectory_kind=1)) == ["exact"]
+    assert SC.family_of(N.DiagNutsSettings(trajectory_kind=2)) == ["micro"]
+    assert SC.family_of(N.LowRankNutsSettings()) == ["lr_frozen", "lr_adapt"]
+    assert SC.family_of(N.DiagMclmcSettings()) == ["mclmc"]
+    assert SC.family_of(N.LowRankMclmcSettings()) == ["lr_mclmc"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Wave-level phase timeline of the one-chain-per-lane kernel (block 0), from a -DNM_LANE_PROF=1 build:
-  tools/build_unit_variant.sh lprof "-DNM_LANE_PROF=1" kern_lane && NUTS_AMD_LIB=nuts_rs_amd/libnuts_amd_lprof.so python tools/prof_lane.py
+  python tools/build_variant.py lprof "-DNM_LANE_PROF=1" kern_lane.hip && NUTS_AMD_LIB=nuts_rs_amd/libnuts_amd_lprof.so python tools/prof_lane.py
 Prints one JSON line: s_memtime ticks (100 MHz) per phase and per draw for the post-warm-up draws of the K4 model."""
 import argparse, ctypes as Ct, json, sys, os
 import numpy as np

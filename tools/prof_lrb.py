@@ -1,4 +1,4 @@
-"""Phase profile of the estimator kernel (a -DNM_LRB_PROF build of lowrank_device.hip: tools/build_unit_variant.sh lrbprof "-DNM_LRB_PROF=1" lowrank_device):
+"""Phase profile of the estimator kernel (a -DNM_LRB_PROF build of lowrank_device.hip: python tools/build_variant.py lrbprof "-DNM_LRB_PROF=1" lowrank_device.hip):
    NUTS_AMD_LIB=nuts_rs_amd/libnuts_amd_lrbprof.so python tools/prof_lrb.py [--dim 128] [--n 100] [--windows 1024]"""
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np

@@ -1,5 +1,5 @@
 #!/bin/bash
-# K3 / K4 with the regular build and a tuning build (tools/build_unit_variant.sh <tag> ...): tools/run_variant_k34.sh <tag>
+# K3 / K4 with the regular build and a tuning build (python tools/build_variant.py <tag> "<flags>" unit.hip[@variant]): tools/run_variant_k34.sh <tag>
 for lib in "" $1; do
   if [ -n "$lib" ]; then export NUTS_AMD_LIB=$PWD/nuts_rs_amd/libnuts_amd_$lib.so; else unset NUTS_AMD_LIB; fi
   echo "== ${lib:-regular}"

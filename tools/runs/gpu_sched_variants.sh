@@ -1,5 +1,5 @@
 #!/bin/bash
-# K2 on tuning builds of kern_iid_normal with other instruction-scheduling strategies (tools/build_unit_variant.sh <tag> "-mllvm -amdgpu-sched-strategy=..."):
+# K2 on tuning builds of kern_iid_normal with other instruction-scheduling strategies (python tools/build_variant.py <tag> "-mllvm -amdgpu-sched-strategy=..."):
 # rate (tools/quick_k2.py, twice) and the iid parity cases on each
 export TMPDIR=/tmp; O=gpurun_out/sched; mkdir -p $O
 for tag in base ${VARIANTS:-ilp memcl itilp}; do
