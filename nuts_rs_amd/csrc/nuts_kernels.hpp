@@ -129,6 +129,12 @@ template <int DPL, int W> constexpr bool reg_edges() { return bool(NM_REG_EDGES)
 #ifndef NM_NOG_82
 #define NM_NOG_82 0   // the gradient-free points on the (8 doubles, 2 wavefronts) tiling too (measured: profiles/r06s_*)
 #endif
+#ifndef NM_TEST_CHUNK
+#define NM_TEST_CHUNK 4      // (16-doubles tiling) iterations the level-k / top-level U-turn tests request their slots' rows ahead: measured 0 / 2 / 4 / 8 (profiles/r06u_*)
+#endif
+#ifndef NM_TEST_CHUNK3_MAX
+#define NM_TEST_CHUNK3_MAX 2
+#endif
 #ifndef NM_FD
 #define NM_FD 0      // measured (profiles/r06n_k2_nog_variants.txt): the 64 registers cost more in spills than the loads they save
 #endif
@@ -2146,6 +2152,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
     constexpr bool RE = reg_edges<DPL, W>();
     constexpr bool NOG = nog_mode<DPL, W, Dens>();       // points are (z, v): no g_z tile (see nog_mode)
     constexpr bool FD = NOG && bool(NM_FD);                // the first leaf of the doubling in progress lives in FDz / FDv
+    constexpr int TCH = (DPL == 16 && W == 1 && !batched_merges<DPL, W>()) ? NM_TEST_CHUNK : 0;     // iterations a U-turn test requests its slots' rows ahead (16-doubles tiling)
     [[maybe_unused]] Tile<DPL> Gsh;                        // NM_GTILE: g_z of the point the last leapfrog produced
     [[maybe_unused]] Tile<DPL>* const gsh = NM_GTILE ? &Gsh : nullptr;
     [[maybe_unused]] Tile<DPL> FDz, FDv;
@@ -2306,9 +2313,9 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                     // In generation order (tree side first; turning_regs' note: a pair the other way round is the same sums negated) both
                     // are (left, O) (right, O) (X, first leaf) with X = the tree's edge FAR from `other`: left going forward, right going
                     // backward.  One loop per direction (they differ in one operand; selecting it per element would be 8 v_cndmask per row).
-                    auto rows = [&](auto far_is_left) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int m = 0; m < DPL / 2; ++m) {
+                    auto rows = [&](auto far_is_left, auto of_regs) __attribute__((always_inline)) {
+                        constexpr bool OFR = decltype(of_regs)::value;       // other.first is in registers (E at depth 1, FDz / FDv with NM_FD)
+                        auto row = [&](int m, double2 oz, double2 ov) __attribute__((always_inline)) {
                             double2 lz, lv, rz, rv;
                             if constexpr (RE) {
                                 lz = MLz.pair(m); lv = MLv.pair(m); rz = MRz.pair(m); rv = MRv.pair(m);
@@ -2316,21 +2323,38 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                 lz = C.ld2(mlz.r, mlz.so, m); lv = C.ld2(mlv.r, mlv.so, m);
                                 rz = C.ld2(mrz.r, mrz.so, m); rv = C.ld2(mrv.r, mrv.so, m);
                             }
-                            double2 oz, ov;
-                            if constexpr (FD) { oz = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); ov = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }   // leaf 0 of this doubling
-                            else
-                            if (of_in_regs) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
-                            else { oz = NM_TLD(C.rs, so_ofz, m, E.z); ov = NM_TLD(C.rs, so_ofv, m, E.v); }
                             const double cz0 = O.z.a[2 * m], cz1 = O.z.a[2 * m + 1];
                             const double cv0 = O.v.a[2 * m], cv1 = O.v.a[2 * m + 1];
                             turn_acc(lz.x, lv.x, cz0, cv0, s1, s2); turn_acc(lz.y, lv.y, cz1, cv1, s1, s2);
                             turn_acc(rz.x, rv.x, cz0, cv0, s3, s4); turn_acc(rz.y, rv.y, cz1, cv1, s3, s4);
                             if constexpr (decltype(far_is_left)::value) { turn_acc(lz.x, lv.x, oz.x, ov.x, s5, s6); turn_acc(lz.y, lv.y, oz.y, ov.y, s5, s6); }
                             else { turn_acc(rz.x, rv.x, oz.x, ov.x, s5, s6); turn_acc(rz.y, rv.y, oz.y, ov.y, s5, s6); }
+                        };
+                        if constexpr (!OFR && TCH > 0) {                     // the slot's rows requested TCH iterations ahead (see the level-k tests)
+#pragma unroll
+                            for (int m0 = 0; m0 < DPL / 2; m0 += (TCH > 0 ? TCH : 1)) {
+                                double2 ozb[TCH > 0 ? TCH : 1], ovb[TCH > 0 ? TCH : 1];
+#pragma unroll
+                                for (int c = 0; c < TCH; ++c) if (m0 + c < DPL / 2) { ozb[c] = NM_TLD(C.rs, so_ofz, m0 + c, E.z); ovb[c] = NM_TLD(C.rs, so_ofv, m0 + c, E.v); }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int c = 0; c < TCH; ++c) if (m0 + c < DPL / 2) row(m0 + c, ozb[c], ovb[c]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else {
+#pragma unroll
+                        for (int m = 0; m < DPL / 2; ++m) {
+                            double2 oz, ov;
+                            if constexpr (FD) { oz = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); ov = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }   // leaf 0 of this doubling
+                            else if constexpr (OFR) { oz = make_double2(E.z.a[2 * m], E.z.a[2 * m + 1]); ov = make_double2(E.v.a[2 * m], E.v.a[2 * m + 1]); }
+                            else { oz = NM_TLD(C.rs, so_ofz, m, E.z); ov = NM_TLD(C.rs, so_ofv, m, E.v); }
+                            row(m, oz, ov);
                             NM_GROUP_BARRIER(m);
                         }
+                        }
                     };
-                    if (fwd) rows(std::true_type{}); else rows(std::false_type{});
+                    if (FD || of_in_regs) { if (fwd) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
+                    else { if (fwd) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
                     { double sv6[6] = {s1, s2, s3, s4, s5, s6}; return C.red.any_sign(sv6, fwd); }
                 }
         };
@@ -2410,11 +2434,7 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                         if (k == 2) {
                             const double2* l1z2 = C.tptr(C.l1z);      // A.last = L[1] lives in LDS
                             const double2* l1v2 = C.tptr(C.l1v);
-#pragma unroll
-                            for (int m = 0; m < DPL / 2; ++m) {
-                                double2 az, av;
-                                if constexpr (AFD) { az = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); av = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }
-                                else { az = NM_TLD(C.rs, so_afz, m, E.z); av = NM_TLD(C.rs, so_afv, m, E.v); }
+                            auto row2 = [&](int m, double2 az, double2 av) __attribute__((always_inline)) {
                                 const double2 lz = l1z2[m * 64 * W], lv = l1v2[m * 64 * W];
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
@@ -2426,17 +2446,33 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                     turn_acc(lzj, lvj, cz, cv, s3, s4);
                                     turn_acc(azj, avj, bz, bv, s5, s6);
                                 }
-                                NM_GROUP_BARRIER(m);
-                            }
-                        } else {
-                            const int so_bfz = C.soS(slot_F(k - 1)), so_bfv = C.soS(slot_F(k - 1) + 1);
+                            };
+                            if constexpr (!AFD && TCH > 0) {
+                                // (round 6) the slot's rows REQUESTED TCH iterations ahead of their use: left to itself the compiler issues two loads, waits for
+                                // both, computes, and issues the next two — eight serialised round trips per test at 16 doubles per lane
+#pragma unroll
+                                for (int m0 = 0; m0 < DPL / 2; m0 += (TCH > 0 ? TCH : 1)) {
+                                    double2 azb[TCH > 0 ? TCH : 1], avb[TCH > 0 ? TCH : 1];
+#pragma unroll
+                                    for (int c = 0; c < TCH; ++c) if (m0 + c < DPL / 2) { azb[c] = NM_TLD(C.rs, so_afz, m0 + c, E.z); avb[c] = NM_TLD(C.rs, so_afv, m0 + c, E.v); }
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int c = 0; c < TCH; ++c) if (m0 + c < DPL / 2) row2(m0 + c, azb[c], avb[c]);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else {
 #pragma unroll
                             for (int m = 0; m < DPL / 2; ++m) {
                                 double2 az, av;
                                 if constexpr (AFD) { az = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); av = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }
                                 else { az = NM_TLD(C.rs, so_afz, m, E.z); av = NM_TLD(C.rs, so_afv, m, E.v); }
-                                const double2 lz = NM_TLD(C.rs, so_alz, m, O.z), lv = NM_TLD(C.rs, so_alv, m, O.v);
-                                const double2 bz2 = NM_TLD(C.rs, so_bfz, m, E.v), bv2 = NM_TLD(C.rs, so_bfv, m, O.z);
+                                row2(m, az, av);
+                                NM_GROUP_BARRIER(m);
+                            }
+                            }
+                        } else {
+                            const int so_bfz = C.soS(slot_F(k - 1)), so_bfv = C.soS(slot_F(k - 1) + 1);
+                            auto row3 = [&](int m, double2 az, double2 av, double2 lz, double2 lv, double2 bz2, double2 bv2) __attribute__((always_inline)) {
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const double azj = j ? az.y : az.x, avj = j ? av.y : av.x;
@@ -2447,7 +2483,35 @@ NM_DEV uint64_t nuts_transition(ChainCtx<DPL, W, Dens>& C, AcceptCollector& col,
                                     turn_acc(lzj, lvj, cz, cv, s3, s4);
                                     turn_acc(azj, avj, bz, bv, s5, s6);
                                 }
+                            };
+                            constexpr int TCH3 = TCH >= 2 ? (TCH / 2 < NM_TEST_CHUNK3_MAX ? TCH / 2 : NM_TEST_CHUNK3_MAX) : 0;      // six loads per iteration here: fewer iterations ahead
+                            if constexpr (!AFD && TCH3 > 0) {
+#pragma unroll
+                                for (int m0 = 0; m0 < DPL / 2; m0 += (TCH3 > 0 ? TCH3 : 1)) {
+                                    constexpr int T3 = TCH3 > 0 ? TCH3 : 1;
+                                    double2 azb[T3], avb[T3], lzb[T3], lvb[T3], bzb[T3], bvb[T3];
+#pragma unroll
+                                    for (int c = 0; c < TCH3; ++c) if (m0 + c < DPL / 2) {
+                                        azb[c] = NM_TLD(C.rs, so_afz, m0 + c, E.z); avb[c] = NM_TLD(C.rs, so_afv, m0 + c, E.v);
+                                        lzb[c] = NM_TLD(C.rs, so_alz, m0 + c, O.z); lvb[c] = NM_TLD(C.rs, so_alv, m0 + c, O.v);
+                                        bzb[c] = NM_TLD(C.rs, so_bfz, m0 + c, E.v); bvb[c] = NM_TLD(C.rs, so_bfv, m0 + c, O.z);
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int c = 0; c < TCH3; ++c) if (m0 + c < DPL / 2) row3(m0 + c, azb[c], avb[c], lzb[c], lvb[c], bzb[c], bvb[c]);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else {
+#pragma unroll
+                            for (int m = 0; m < DPL / 2; ++m) {
+                                double2 az, av;
+                                if constexpr (AFD) { az = make_double2(FDz.a[2 * m], FDz.a[2 * m + 1]); av = make_double2(FDv.a[2 * m], FDv.a[2 * m + 1]); }
+                                else { az = NM_TLD(C.rs, so_afz, m, E.z); av = NM_TLD(C.rs, so_afv, m, E.v); }
+                                const double2 lz = NM_TLD(C.rs, so_alz, m, O.z), lv = NM_TLD(C.rs, so_alv, m, O.v);
+                                const double2 bz2 = NM_TLD(C.rs, so_bfz, m, E.v), bv2 = NM_TLD(C.rs, so_bfv, m, O.z);
+                                row3(m, az, av, lz, lv, bz2, bv2);
                                 NM_GROUP_BARRIER(m);
+                            }
                             }
                         }
                         };

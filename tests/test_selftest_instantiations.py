@@ -70,7 +70,8 @@ def test_first_use_checks_the_instantiation_and_rejects_a_wrong_answer(monkeypat
 @pytest.mark.gpu
 def test_run_all_names_every_failing_instantiation(monkeypatch):
     bad = copy.deepcopy(selftest._gold_inst())
-    victims = ["diag-micro-4x1-dim253", "diag-micro-4x1-dim129"]
+    victims = [SC.case_id(c) for c in SC.cases() if (c["dens"], c["fam"], c["dpl"], c["w"]) == ("diag", "micro", 4, 1)]
+    assert len(victims) == 2
     for v in victims:
         bad[v]["sha256"] = "f" * 64
     monkeypatch.setattr(selftest, "_inst_gold", bad)
