@@ -20,6 +20,12 @@ namespace nm {
 #define NM_DEV __device__ __forceinline__
 
 #define NM_HD __host__ __device__ __forceinline__
+#ifndef NM_PACKED_LF2
+#define NM_PACKED_LF2 1       // the leapfrog's two sums (logp term, kinetic energy) too
+#endif
+#ifndef NM_PACKED_TESTS_N2
+#define NM_PACKED_TESTS_N2 1     // the level-1 test's two sums as well
+#endif
 #ifndef NM_PACKED_SUMS
 #define NM_PACKED_SUMS 1      // several sums of a wavefront through one transposed butterfly (wave_sum_packed); 0: one butterfly per value (rounds 1-4)
 #endif
@@ -179,6 +185,7 @@ template <int W>
 struct Reducer {
     double* buf;   // LDS [2][RED_MAX_VALUES][W] (+ RED_MAX_VALUES + 1 + 2 RED_MAX_VALUES CL_MAX_MEMBERS in cluster mode)
     int par;
+    bool packed_tests = false;   // the six sums of a level-k / top-level U-turn test only (any_sign<6>): the 16-doubles tiling, where packing everything spills
     bool packed = false;   // several sums through ONE transposed butterfly (wave_sum_packed: same bits).  Set by the kernel per tiling: measured
                            // (2 doubles per lane) K3 +6.6 %, dim 100 +7 %; (4) dim 256 +4 %; (8) dim 512 -12 %; (16) K2 -24 % (96 more bytes of scratch): profiles/r05k_*, r05l_*
 #if NM_CLUSTER_MODE
@@ -291,7 +298,7 @@ struct Reducer {
     template <int N>
     NM_DEV void sum_n(double (&v)[N]) {
         static_assert(N <= RED_MAX_VALUES, "too many values");
-        if (NM_PACKED_SUMS && packed) {
+        if (NM_PACKED_SUMS && (packed || (packed_tests && N == 2 && NM_PACKED_LF2))) {
             if constexpr (N == 1) v[0] = swap_add32(swap_add16(wave_rows(v[0])));
             else {
                 const double pk = wave_sum_packed<N>(v);       // one shared butterfly (same tree, same bits per value), the totals read out as uniform values
@@ -331,7 +338,7 @@ struct Reducer {
     // so the answer is a compare and a ballot — no total is read out.  Same decision as sum_n + N scalar compares.
     template <int N>
     NM_DEV bool any_sign(double (&v)[N], bool neg) {
-        if (NM_PACKED_SUMS && packed && W == 1 && !NM_CLUSTER_MODE) {
+        if (NM_PACKED_SUMS && (packed || (packed_tests && (N == 6 || (N == 2 && NM_PACKED_TESTS_N2)))) && W == 1 && !NM_CLUSTER_MODE) {
             const double pk = wave_sum_packed<N>(v);
             return __ballot(neg ? pk < 0. : pk > 0.) != 0ull;
         }

@@ -901,6 +901,10 @@ NM_DEV void ctx_begin(ChainCtx<DPL, W, Dens>& C, BlockShared<DPL, W, Dens>& sh, 
 #ifndef NM_PACKED_MAX_DPL
 #define NM_PACKED_MAX_DPL 4
 #endif
+#ifndef NM_PACKED_TESTS_16
+#define NM_PACKED_TESTS_16 1     // the six sums of a level-k / top-level test through one transposed butterfly on the 16-doubles tiling too (2.48 -> 2.555e11: profiles/r06n_*)
+#endif
+    C.red.packed_tests = bool(NM_PACKED_TESTS_16) && DPL == 16 && W == 1 && !NM_TILE_MODE && !NM_CLUSTER_MODE;
     C.red.packed = DPL <= NM_PACKED_MAX_DPL && !NM_TILE_MODE;        // (dev_math.hpp Reducer::packed: per tiling, from the measurements of round 5)
     const KParams& P = C.P;
     C.dim = (int)P.dim; C.gdim = (int)P.dim; C.goff = 0;

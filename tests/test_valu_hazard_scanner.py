@@ -51,3 +51,13 @@ def test_transcendental_forwarding_and_labels(tmp_path):
     # a local label does not reset the window (the fall-through path is a path); the next function's label does
     assert scan(tmp_path, ["v_rcp_f64_e32 v[0:1], v[2:3]", ".LBB0_1:", "v_mul_f64 v[4:5], v[0:1], v[6:7]"])[0] == 1
     assert scan(tmp_path, ["v_rcp_f64_e32 v[0:1], v[2:3]", "_Z5otherv:", "v_mul_f64 v[4:5], v[0:1], v[6:7]"])[0] == 0
+
+
+def test_an_unconditional_branch_ends_the_window(tmp_path):
+    """What follows an `s_branch` in the TEXT is another block, not the next instruction executed (round 6: the scan paired a v_readlane in front of
+    a branch with the first load of the block printed behind it and failed a correct build)."""
+    vm = "global_load_dwordx2 v[80:81], v47, s[0:1]"
+    rc, out = scan(tmp_path, ["v_readlane_b32 s1, v252, 53", vm])
+    assert rc == 1 and "'G': 1" in out                                      # the hazard itself is still seen in straight-line code
+    assert scan(tmp_path, ["v_readlane_b32 s1, v252, 53", "s_branch .LBB0_9", vm])[0] == 0
+    assert scan(tmp_path, ["v_readlane_b32 s1, v252, 53", "s_cbranch_vccnz .LBB0_9", vm])[0] == 1      # a conditional branch may fall through

@@ -47,6 +47,11 @@ def scan(path):
         op = t.split(None, 1)
         name = op[0]
         args = op[1] if len(op) > 1 else ""
+        if name in ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+            # an unconditional transfer: the next line of TEXT is not what executes next (round 6: a v_readlane in front of an `s_branch` was paired
+            # with the first load of the block that merely follows it in the file); a taken branch or a call outlasts every wait-state window
+            window = []
+            continue
         if name == "s_nop":
             n = int(args.strip() or 0) + 1
             window = [(w + n, a, b, c, d, e) for (w, a, b, c, d, e) in window]
