@@ -192,3 +192,12 @@ def first_use(batch, device=-1):
                     raise SelfTestError("the kernel instantiation this engine is about to launch does not reproduce its known answer: " + msg +
                                         "; the library was built by a compiler / from headers other than the verified ones (DESIGN §22), or the runtime differs")
     return n
+
+
+if __name__ == "__main__":      # python -m nuts_rs_amd.selftest [--all] [-v]: for hosts that do not go through sampler.ChainBatch (C / C++ / Rust over the C ABI)
+    import sys
+    os.environ["NUTS_AMD_SELFTEST"] = "0"          # (run_all checks everything itself)
+    n = run(verbose="-v" in sys.argv)
+    print(f"{n} small runs on the wave / group / lane kernels reproduce their known answers")
+    if "--all" in sys.argv:
+        print(f"{run_all(verbose='-v' in sys.argv)} kernel instantiations reproduce their known answers")
