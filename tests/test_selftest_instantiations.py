@@ -91,3 +91,27 @@ def test_family_of_maps_every_settings_constructor_to_its_kernel_family():
     assert SC.family_of(N.LowRankNutsSettings()) == ["lr_frozen", "lr_adapt"]
     assert SC.family_of(N.DiagMclmcSettings()) == ["mclmc"]
     assert SC.family_of(N.LowRankMclmcSettings()) == ["lr_mclmc"]
+
+
+def test_answers_on_file_are_what_the_oracle_computes_today():
+    """A sample of the 349 answers recomputed by the CPU oracle (no GPU): the data file and the oracle cannot drift apart unnoticed."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_selftest_golden", os.path.join(root, "tools", "gen_selftest_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    sys.modules["gen_selftest_golden"] = gen
+    spec.loader.exec_module(gen)
+    gold = json.load(open(selftest.GOLDEN_INST))["cases"]
+    want = {"iid-nuts-2x1-dim2", "schools-nuts-2x1-dim10", "diag-micro-4x1-dim129", "funnel-lr_frozen-2x1-dim125", "iid-lr_adapt-4x1-dim129", "mvn-mclmc-2x1-dim2",
+            "iid-nuts-16x1-dim513"}
+    seen = set()
+    for c in SC.cases():
+        cid = SC.case_id(c)
+        if cid not in want:
+            continue
+        pos, st, steps, failed = gen.oracle_answer(c)
+        assert failed == gold[cid]["failed"] == 0
+        assert steps == gold[cid]["leapfrogs"] and SC.digest(pos, st) == gold[cid]["sha256"], cid
+        seen.add(cid)
+    assert seen == want, want - seen
