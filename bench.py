@@ -134,7 +134,7 @@ def pmc_live(args, config="k2", passes=None, kernel=KERNEL, steps=None, deadline
     out = {}
     deadline = deadline or (time.time() + args.pmc_timeout)
     tmp = tempfile.mkdtemp(prefix="nm_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", NUTS_AMD_SELFTEST="0")     # (the parent process has checked the instantiations it runs: no self-test kernels under the counters)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", config, "--gpus", "1", "--steps", str(steps or args.steps),
